@@ -1,0 +1,385 @@
+"""ctypes binding of libds2i_hip.so + a Python mirror of ds2i's Index / query-operator concepts.
+
+Names follow the reference (queries.hpp): and_query, or_query, ranked_and_query, wand_query,
+maxscore_query, ranked_or_query; an operator is called as op(index, terms) and ranked operators
+expose topk(), exactly like queries.cpp:13-62 drives them. Batched entry points take a list of
+queries (the batch boundary this framework inserts at queries.cpp:26).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4}
+OPS = {"and": 0, "and_freq": 1, "or": 2, "or_freq": 3, "ranked_and": 4, "wand": 5, "maxscore": 6, "ranked_or": 7}
+REFERENCE_ORDER = 0x100
+_RANKED = {4, 5, 6, 7}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class Ds2iError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ds2i_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("docs_blocks_decoded", C.c_uint64), ("freqs_blocks_decoded", C.c_uint64),
+                ("block_max_examined", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("postings_scored", C.c_uint64),
+                ("rounds", C.c_uint64)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("num_docs", C.c_uint32), ("num_terms", C.c_uint32), ("zipf_exp", C.c_double),
+                ("top_df_frac", C.c_double), ("min_len", C.c_uint32), ("clustered_every", C.c_uint32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libds2i_hip.so")
+
+
+def lib():
+    """Loads the shared library; raises loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError("libds2i_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the query path)")
+        L = C.CDLL(path)
+        vp, u32p, u64p, fp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+        L.ds2i_hip_last_error.restype = C.c_char_p
+        L.ds2i_hip_index_open.argtypes = [C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp)]
+        L.ds2i_hip_index_close.argtypes = [vp]
+        L.ds2i_hip_index_close.restype = None
+        for f in ("ds2i_hip_index_size", "ds2i_hip_index_num_docs", "ds2i_hip_index_device_bytes"):
+            getattr(L, f).argtypes = [vp]
+            getattr(L, f).restype = C.c_uint64
+        L.ds2i_hip_list_size.argtypes = [vp, C.c_uint32, u64p]
+        L.ds2i_hip_decode_list.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, u64p]
+        L.ds2i_hip_query_batch.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(Stats)]
+        L.ds2i_hip_batch_prepare.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
+        L.ds2i_hip_batch_run.argtypes = [vp, C.POINTER(Stats)]
+        L.ds2i_hip_batch_class_stats.argtypes = [vp, C.c_int, C.POINTER(Stats), u32p]
+        L.ds2i_hip_batch_fetch.argtypes = [vp, vp, vp, vp, vp]
+        L.ds2i_hip_batch_match_total.argtypes = [vp, u64p]
+        L.ds2i_hip_batch_fetch_matches.argtypes = [vp, vp, vp]
+        L.ds2i_hip_batch_free.argtypes = [vp]
+        L.ds2i_hip_batch_free.restype = None
+        L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
+        # build side
+        L.ds2i_blob_data.argtypes = [vp]
+        L.ds2i_blob_data.restype = vp
+        L.ds2i_blob_size.argtypes = [vp]
+        L.ds2i_blob_size.restype = C.c_size_t
+        L.ds2i_blob_free.argtypes = [vp]
+        L.ds2i_blob_free.restype = None
+        L.ds2i_builder_create.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp)]
+        L.ds2i_builder_add_posting_list.argtypes = [vp, C.c_uint64, vp, vp]
+        L.ds2i_builder_freeze.argtypes = [vp, C.POINTER(vp)]
+        L.ds2i_builder_free.argtypes = [vp]
+        L.ds2i_builder_free.restype = None
+        L.ds2i_wand_create.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.ds2i_wand_add_list.argtypes = [vp, C.c_uint64, vp, vp]
+        L.ds2i_wand_freeze.argtypes = [vp, C.POINTER(vp)]
+        L.ds2i_wand_free.argtypes = [vp]
+        L.ds2i_wand_free.restype = None
+        L.ds2i_encode_block.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.ds2i_encode_vbyte.argtypes = [C.c_uint32, C.POINTER(vp)]
+        L.ds2i_encode_posting_list.argtypes = [C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]
+        L.ds2i_synth_list_upper_bound.argtypes = [C.POINTER(SynthParams), C.c_uint32]
+        L.ds2i_synth_list_upper_bound.restype = C.c_uint64
+        L.ds2i_synth_list.argtypes = [C.POINTER(SynthParams), C.c_uint32, vp, vp, C.c_uint64, u64p]
+        L.ds2i_synth_doc_sizes.argtypes = [C.POINTER(SynthParams), vp]
+        L.ds2i_synth_queries.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]
+        L.ds2i_synth_build.argtypes = [C.POINTER(SynthParams), C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), u64p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise Ds2iError(rc, lib().ds2i_hip_last_error().decode("utf-8", "replace"))
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _take_blob(handle):
+    L = lib()
+    n = L.ds2i_blob_size(handle)
+    out = C.string_at(L.ds2i_blob_data(handle), n) if n else b""
+    L.ds2i_blob_free(handle)
+    return out
+
+
+def _codec(c):
+    return CODECS[c] if isinstance(c, str) else int(c)
+
+
+# ---------------------------------------------------------------- build side (host, CPU)
+def encode_block(codec, values, sum_of_values=0xFFFFFFFF):
+    v = _u32(values)
+    h = C.c_void_p()
+    _check(lib().ds2i_encode_block(_codec(codec), _ptr(v), C.c_uint32(sum_of_values & 0xFFFFFFFF), len(v), C.byref(h)))
+    return _take_blob(h)
+
+
+def encode_vbyte(value):
+    h = C.c_void_p()
+    _check(lib().ds2i_encode_vbyte(value, C.byref(h)))
+    return _take_blob(h)
+
+
+def encode_posting_list(codec, docs, freqs):
+    d, f = _u32(docs), _u32(freqs)
+    h = C.c_void_p()
+    _check(lib().ds2i_encode_posting_list(_codec(codec), len(d), _ptr(d), _ptr(f), C.byref(h)))
+    return _take_blob(h)
+
+
+def build_index(codec, num_docs, lists):
+    """lists: iterable of (docs, freqs). Returns the frozen block_freq_index image (bytes)."""
+    L = lib()
+    b = C.c_void_p()
+    _check(L.ds2i_builder_create(_codec(codec), num_docs, C.byref(b)))
+    try:
+        for docs, freqs in lists:
+            d, f = _u32(docs), _u32(freqs)
+            _check(L.ds2i_builder_add_posting_list(b, len(d), _ptr(d), _ptr(f)))
+        h = C.c_void_p()
+        _check(L.ds2i_builder_freeze(b, C.byref(h)))
+        return _take_blob(h)
+    finally:
+        L.ds2i_builder_free(b)
+
+
+def build_wand(doc_sizes, lists):
+    L = lib()
+    s = _u32(doc_sizes)
+    w = C.c_void_p()
+    _check(L.ds2i_wand_create(_ptr(s), len(s), C.byref(w)))
+    try:
+        for docs, freqs in lists:
+            d, f = _u32(docs), _u32(freqs)
+            _check(L.ds2i_wand_add_list(w, len(d), _ptr(d), _ptr(f)))
+        h = C.c_void_p()
+        _check(L.ds2i_wand_freeze(w, C.byref(h)))
+        return _take_blob(h)
+    finally:
+        L.ds2i_wand_free(w)
+
+
+def synth_list(p, term):
+    cap = int(p.num_docs)
+    d = np.empty(cap, dtype=np.uint32)
+    f = np.empty(cap, dtype=np.uint32)
+    n = C.c_uint64()
+    _check(lib().ds2i_synth_list(C.byref(p), term, _ptr(d), _ptr(f), cap, C.byref(n)))
+    return d[:n.value].copy(), f[:n.value].copy()
+
+
+def synth_doc_sizes(p):
+    s = np.empty(int(p.num_docs), dtype=np.uint32)
+    _check(lib().ds2i_synth_doc_sizes(C.byref(p), _ptr(s)))
+    return s
+
+
+def synth_queries(seed, num_terms, nq):
+    t = np.empty(11 * nq + 1, dtype=np.uint32)
+    o = np.empty(nq + 1, dtype=np.uint32)
+    _check(lib().ds2i_synth_queries(seed, num_terms, nq, _ptr(t), _ptr(o)))
+    return [t[o[i]:o[i + 1]].tolist() for i in range(nq)]
+
+
+def synth_build(p, codec, threads=0):
+    """Returns (index_image, wand_image, total_postings) for the synthetic collection p."""
+    hi, hw = C.c_void_p(), C.c_void_p()
+    tot = C.c_uint64()
+    _check(lib().ds2i_synth_build(C.byref(p), _codec(codec), threads, C.byref(hi), C.byref(hw), C.byref(tot)))
+    return _take_blob(hi), _take_blob(hw), tot.value
+
+
+# ---------------------------------------------------------------- query side (GPU)
+def _flatten(queries):
+    offs = np.zeros(len(queries) + 1, dtype=np.uint32)
+    for i, q in enumerate(queries):
+        offs[i + 1] = offs[i] + len(q)
+    terms = np.zeros(max(int(offs[-1]), 1), dtype=np.uint32)
+    pos = 0
+    for q in queries:
+        terms[pos:pos + len(q)] = q
+        pos += len(q)
+    return terms, offs
+
+
+def _op(op):
+    return OPS[op] if isinstance(op, str) else int(op)
+
+
+class Batch:
+    """A prepared query batch resident in HBM (ds2i_hip_batch_*)."""
+
+    def __init__(self, index, op, queries, k=10, want_matches=False, reference_order=False):
+        self.index, self.nq, self.k = index, len(queries), k
+        self.op = _op(op) | (REFERENCE_ORDER if reference_order else 0)
+        terms, offs = _flatten(queries)
+        self._h = C.c_void_p()
+        _check(lib().ds2i_hip_batch_prepare(index._h, self.op, k, _ptr(terms), _ptr(offs), self.nq,
+                                            1 if want_matches else 0, C.byref(self._h)))
+        self.k = k if (self.op & 0xFF) in _RANKED else max(k, 1)
+
+    def run(self):
+        st = Stats()
+        _check(lib().ds2i_hip_batch_run(self._h, C.byref(st)))
+        return st
+
+    def class_stats(self, cls):
+        st, n = Stats(), C.c_uint32()
+        _check(lib().ds2i_hip_batch_class_stats(self._h, cls, C.byref(st), C.byref(n)))
+        return st, n.value
+
+    def fetch(self):
+        nq = max(self.nq, 1)
+        count = np.zeros(nq, dtype=np.uint64)
+        topk = np.full((nq, min(self.k, 64)), -np.inf, dtype=np.float32)
+        tlen = np.zeros(nq, dtype=np.uint32)
+        fsum = np.zeros(nq, dtype=np.uint64)
+        _check(lib().ds2i_hip_batch_fetch(self._h, _ptr(count), _ptr(topk), _ptr(tlen), _ptr(fsum)))
+        return count[:self.nq], topk[:self.nq], tlen[:self.nq], fsum[:self.nq]
+
+    def fetch_matches(self, counts):
+        tot = C.c_uint64()
+        _check(lib().ds2i_hip_batch_match_total(self._h, C.byref(tot)))
+        offs = np.zeros(self.nq + 1, dtype=np.uint64)
+        m = np.zeros(max(tot.value, 1), dtype=np.uint32)
+        _check(lib().ds2i_hip_batch_fetch_matches(self._h, _ptr(offs), _ptr(m)))
+        return [m[int(offs[i]):int(offs[i]) + int(counts[i])].copy() for i in range(self.nq)]
+
+    def close(self):
+        if self._h:
+            lib().ds2i_hip_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """block_freq_index resident in one GPU's HBM (Index concept: size(), num_docs(), operator[])."""
+
+    def __init__(self, kind, index_image, wand_image=None, device=0):
+        self._h = C.c_void_p()
+        self.kind = _codec(kind)
+        wi = wand_image if wand_image is not None else None
+        _check(lib().ds2i_hip_index_open(device, self.kind, index_image, len(index_image), wi,
+                                         len(wand_image) if wand_image is not None else 0, C.byref(self._h)))
+
+    def size(self):
+        return lib().ds2i_hip_index_size(self._h)
+
+    def num_docs(self):
+        return lib().ds2i_hip_index_num_docs(self._h)
+
+    def device_bytes(self):
+        return lib().ds2i_hip_index_device_bytes(self._h)
+
+    def list_size(self, term):
+        n = C.c_uint64()
+        _check(lib().ds2i_hip_list_size(self._h, term, C.byref(n)))
+        return n.value
+
+    def __getitem__(self, term):
+        """index[term]: the whole list enumerated on the GPU -> (docs, freqs)."""
+        n = self.list_size(term)
+        d = np.empty(n, dtype=np.uint32)
+        f = np.empty(n, dtype=np.uint32)
+        got = C.c_uint64()
+        _check(lib().ds2i_hip_decode_list(self._h, term, _ptr(d), _ptr(f), n, C.byref(got)))
+        return d, f
+
+    def query_batch(self, op, queries, k=10):
+        terms, offs = _flatten(queries)
+        nq = len(queries)
+        count = np.zeros(max(nq, 1), dtype=np.uint64)
+        topk = np.full((max(nq, 1), k), -np.inf, dtype=np.float32)
+        tlen = np.zeros(max(nq, 1), dtype=np.uint32)
+        st = Stats()
+        _check(lib().ds2i_hip_query_batch(self._h, _op(op), k, _ptr(terms), _ptr(offs), nq, _ptr(count), _ptr(topk),
+                                          _ptr(tlen), C.byref(st)))
+        return count[:nq], topk[:nq], tlen[:nq], st
+
+    def close(self):
+        if self._h:
+            lib().ds2i_hip_index_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- query-operator concept
+class _query_op:
+    op = None
+    ranked = False
+
+    def __init__(self, wdata=None, k=10):
+        self.k = k
+        self._topk = []
+
+    def __call__(self, index, terms):
+        """uint64_t operator()(Index const&, term_id_vec) -- a batch of one query."""
+        return int(self.batch(index, [list(terms)])[0])
+
+    def batch(self, index, queries):
+        count, topk, tlen, _ = index.query_batch(self.op, queries, self.k)
+        if self.ranked:
+            self._topk = [topk[i, :tlen[i]].copy() for i in range(len(queries))]
+        return count
+
+    def topk(self, i=-1):
+        return self._topk[i]
+
+
+class and_query(_query_op):
+    def __init__(self, with_freqs=False):
+        super().__init__()
+        self.op = "and_freq" if with_freqs else "and"
+
+
+class or_query(_query_op):
+    def __init__(self, with_freqs=False):
+        super().__init__()
+        self.op = "or_freq" if with_freqs else "or"
+
+
+class ranked_and_query(_query_op):
+    op, ranked = "ranked_and", True
+
+
+class wand_query(_query_op):
+    op, ranked = "wand", True
+
+
+class maxscore_query(_query_op):
+    op, ranked = "maxscore", True
+
+
+class ranked_or_query(_query_op):
+    op, ranked = "ranked_or", True

@@ -1,0 +1,60 @@
+"""Builds libds2i_hip.so (HIP kernels + C-ABI + host index builder) in-tree with hipcc for gfx950.
+
+The shared library is the product's only compute path; there is no CPU fallback.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libds2i_hip.so")
+ARCH = "gfx950"
+
+DEVICE_SRCS = ["kernels.hip"]
+HOST_SRCS = ["capi.cpp", "capi_build.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    inc = os.path.join(HERE, "..", "include")
+    hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    return hs
+
+
+def build(verbose=False, force=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers()
+    objs = []
+    for src in DEVICE_SRCS + HOST_SRCS:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [sp] + hdrs):
+            cmd = [hipcc, "--offload-arch=" + ARCH] + COMMON + ["-c", sp, "-o", obj]
+            if src.endswith(".cpp"):
+                cmd[1:1] = ["-x", "hip"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))

@@ -1,0 +1,55 @@
+// Plain structs shared by the HIP kernels (kernels.hip) and the host C-ABI (capi.cpp).
+#pragma once
+#include <stdint.h>
+
+namespace ds2i_dev {
+
+// One query term as prepared by the host: byte range of its posting list inside the device
+// arena + BM25 weights (bm25.hpp:17-24 needs logf -> computed on the host).
+struct QTerm {
+    uint64_t list_off; // byte offset of vbyte(n) in the arena
+    uint64_t list_end; // byte offset one past the list
+    uint32_t n;        // postings
+    float q_weight;
+    float max_weight; // q_weight * max_term_weight[term]
+    uint32_t term;
+};
+
+struct Stats {
+    unsigned long long docs_blocks, freqs_blocks, block_max_examined, algorithmic_bytes, postings_scored, rounds;
+};
+
+enum { OP_AND = 0, OP_AND_FREQ = 1, OP_OR = 2, OP_OR_FREQ = 3, OP_RANKED_AND = 4, OP_WAND = 5, OP_MAXSCORE = 6,
+       OP_RANKED_OR = 7, OP_REFERENCE_ORDER = 0x100 };
+
+struct BatchArgs {
+    const uint8_t* arena;
+    const float* norm_lens;
+    const QTerm* qterms;      // terms of all queries, already in enumerator order
+    const uint32_t* q_off;    // nq+1 offsets into qterms
+    const uint32_t* order;    // nslice query ids, scheduling order (costliest first)
+    uint32_t nslice;
+    uint32_t num_docs;
+    uint32_t k;
+    int codec;
+    unsigned int* ticket;     // persistent-wave work queue
+    unsigned long long* out_count; // nq
+    float* out_topk;          // nq*k, descending, padded with -inf
+    uint32_t* out_topk_len;   // nq
+    unsigned long long* out_freq_sum; // nq (and_freq / or_freq checksum of touched freqs) or null
+    uint32_t* out_matches;    // optional doc-id lists (and) or null
+    const unsigned long long* match_off; // nq+1 capacity offsets
+    Stats* stats;
+};
+
+struct DecodeArgs {
+    const uint8_t* arena;
+    QTerm term;
+    int codec;
+    uint32_t num_docs;
+    uint32_t* out_docs;
+    uint32_t* out_freqs;
+    Stats* stats;
+};
+
+} // namespace ds2i_dev

@@ -1,0 +1,499 @@
+// Host implementation of include/ds2i_hip.h: index upload, query-batch preparation
+// (the host half of queries.hpp: term normalisation, BM25 query weights, list ordering)
+// and kernel launches. The device half lives in kernels.hip. There is NO CPU fallback:
+// every query result comes from the HIP kernels or the call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ds2i_hip.h"
+#include "abi_structs.hpp"
+#include "capi_error.hpp"
+#include "host_index.hpp"
+
+using ds2i_dev::BatchArgs;
+using ds2i_dev::DecodeArgs;
+using ds2i_dev::QTerm;
+using ds2i_dev::Stats;
+
+extern "C" {
+hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s);
+}
+
+// ------------------------------------------------------------------ errors
+namespace {
+thread_local std::string g_last_error;
+}
+int ds2i_set_error(int code, const char* msg) {
+    g_last_error = msg ? msg : "";
+    return code;
+}
+const char* ds2i_get_error() { return g_last_error.c_str(); }
+
+#define HIP_OK(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return ds2i_set_error(DS2I_EDEVICE, m_.c_str());                                       \
+        }                                                                                          \
+    } while (0)
+
+// ------------------------------------------------------------------ handles
+struct ds2i_hip_index {
+    int device = 0, kind = 0, num_cus = 256;
+    uint64_t size = 0, num_docs = 0;
+    uint8_t* d_arena = nullptr;
+    uint64_t arena_bytes = 0;
+    float* d_norm_lens = nullptr;
+    bool has_wand = false;
+    std::vector<uint64_t> list_off; // arena offsets, size+1 (list i spans [off[i], end[i]))
+    std::vector<uint64_t> list_end;
+    std::vector<uint32_t> list_n;
+    std::vector<float> max_term_weight;
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Stats* d_stats = nullptr;     // [2]
+    unsigned int* d_ticket = nullptr; // [2]
+};
+
+struct ds2i_hip_batch {
+    ds2i_hip_index* idx = nullptr;
+    int op = 0;
+    uint32_t k = 0, nq = 0;
+    bool want_matches = false;
+    uint32_t ncls[2] = {0, 0};
+    QTerm* d_qterms = nullptr;
+    uint32_t* d_qoff = nullptr;
+    uint32_t* d_order[2] = {nullptr, nullptr};
+    unsigned long long* d_count = nullptr;
+    float* d_topk = nullptr;
+    uint32_t* d_topk_len = nullptr;
+    unsigned long long* d_freq_sum = nullptr;
+    uint32_t* d_matches = nullptr;
+    unsigned long long* d_match_off = nullptr;
+    std::vector<unsigned long long> match_off;
+    float cls_ms[2] = {0, 0};
+    Stats cls_stats[2] = {};
+};
+
+namespace {
+
+const float kNegInf = -std::numeric_limits<float>::infinity();
+
+uint32_t host_vbyte(const uint8_t* p, size_t avail, uint32_t& val) {
+    uint32_t v = 0, shift = 0, i = 0;
+    while (i < avail && i < 5) {
+        uint8_t c = p[i++];
+        v += uint32_t(c & 127) << shift;
+        if (c & 128) { val = v; return i; }
+        shift += 7;
+    }
+    return 0;
+}
+
+void free_index(ds2i_hip_index* x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    if (x->d_arena) (void)hipFree(x->d_arena);
+    if (x->d_norm_lens) (void)hipFree(x->d_norm_lens);
+    if (x->d_stats) (void)hipFree(x->d_stats);
+    if (x->d_ticket) (void)hipFree(x->d_ticket);
+    for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
+    for (auto& e : x->ev) if (e) (void)hipEventDestroy(e);
+    delete x;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
+
+int ds2i_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
+                        size_t wand_bytes, ds2i_hip_index** out) {
+    if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
+    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_BLOCK_MIXED)
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
+    int ndev = ds2i_hip_device_count();
+    if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
+    std::unique_ptr<ds2i_hip_index, void (*)(ds2i_hip_index*)> x(new ds2i_hip_index, free_index);
+    x->device = device;
+    x->kind = kind;
+    ds2i_host::block_index_view view;
+    ds2i_host::wand_view wv;
+    try {
+        view.parse(index_image, index_bytes);
+        if (wand_image) wv.parse(wand_image, wand_bytes);
+    } catch (std::exception const& e) {
+        return ds2i_set_error(DS2I_EFORMAT, e.what());
+    }
+    x->size = view.size;
+    x->num_docs = view.num_docs;
+    if (wand_image) {
+        if (wv.num_docs != view.num_docs || wv.num_terms < view.size)
+            return ds2i_set_error(DS2I_EFORMAT, "wand data does not match the index (num_docs / terms)");
+        x->has_wand = true;
+        x->max_term_weight.resize(wv.num_terms);
+        std::memcpy(x->max_term_weight.data(), wv.max_term_weight, 4 * wv.num_terms);
+    }
+    // Device arena: every list is copied byte-for-byte, shifted by <= 3 pad bytes so that its
+    // block_max / block_endpoint tables (which follow vbyte(n)) are dword aligned in HBM.
+    const uint64_t V = view.size;
+    x->list_off.resize(V);
+    x->list_end.resize(V);
+    x->list_n.resize(V);
+    uint64_t cursor = 0;
+    for (uint64_t t = 0; t < V; ++t) {
+        const uint8_t* lp = view.lists + view.list_offsets[t];
+        const uint64_t len = view.list_offsets[t + 1] - view.list_offsets[t];
+        uint32_t n = 0;
+        uint32_t vl = host_vbyte(lp, len, n);
+        if (!vl || !n) return ds2i_set_error(DS2I_EFORMAT, "posting list header is corrupt");
+        const uint64_t nb = (uint64_t(n) + 127) / 128;
+        if (len < vl + 8 * nb - 4) return ds2i_set_error(DS2I_EFORMAT, "posting list shorter than its block tables");
+        uint64_t off = cursor;
+        while ((off + vl) & 3) ++off;
+        x->list_off[t] = off;
+        x->list_end[t] = off + len;
+        x->list_n[t] = n;
+        cursor = off + len;
+    }
+    x->arena_bytes = ((cursor + 3) & ~uint64_t(3)) + 4096; // zero slack: decoders may over-read
+    std::vector<uint8_t> arena;
+    try {
+        arena.assign(x->arena_bytes, 0);
+    } catch (std::bad_alloc const&) {
+        return ds2i_set_error(DS2I_ENOMEM, "out of host memory staging the index");
+    }
+    for (uint64_t t = 0; t < V; ++t)
+        std::memcpy(arena.data() + x->list_off[t], view.lists + view.list_offsets[t],
+                    view.list_offsets[t + 1] - view.list_offsets[t]);
+    HIP_OK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    x->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_OK(hipMalloc((void**)&x->d_arena, x->arena_bytes));
+    HIP_OK(hipMemcpy(x->d_arena, arena.data(), x->arena_bytes, hipMemcpyHostToDevice));
+    if (x->has_wand) {
+        HIP_OK(hipMalloc((void**)&x->d_norm_lens, 4 * (wv.num_docs + 1)));
+        HIP_OK(hipMemcpy(x->d_norm_lens, wv.norm_lens, 4 * wv.num_docs, hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMalloc((void**)&x->d_stats, 2 * sizeof(Stats)));
+    HIP_OK(hipMalloc((void**)&x->d_ticket, 2 * sizeof(unsigned int)));
+    for (auto& s : x->stream) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (auto& e : x->ev) HIP_OK(hipEventCreate(&e));
+    *out = x.release();
+    return DS2I_OK;
+}
+
+void ds2i_hip_index_close(ds2i_hip_index* idx) { free_index(idx); }
+uint64_t ds2i_hip_index_size(const ds2i_hip_index* idx) { return idx ? idx->size : 0; }
+uint64_t ds2i_hip_index_num_docs(const ds2i_hip_index* idx) { return idx ? idx->num_docs : 0; }
+uint64_t ds2i_hip_index_device_bytes(const ds2i_hip_index* idx) {
+    return idx ? idx->arena_bytes + (idx->has_wand ? 4 * idx->num_docs : 0) : 0;
+}
+
+int ds2i_hip_list_size(const ds2i_hip_index* idx, uint32_t term, uint64_t* n) {
+    if (!idx || !n) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_size: null argument");
+    if (term >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+    *n = idx->list_n[term];
+    return DS2I_OK;
+}
+
+int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,
+                         uint64_t* n) {
+    if (!idx || !docs || !freqs || !n) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_decode_list: null argument");
+    if (term >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+    const uint64_t len = idx->list_n[term];
+    *n = len;
+    if (capacity < len) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_decode_list: capacity too small");
+    HIP_OK(hipSetDevice(idx->device));
+    const uint64_t nb = (len + 127) / 128;
+    uint32_t *d_docs = nullptr, *d_freqs = nullptr;
+    HIP_OK(hipMalloc((void**)&d_docs, 4 * nb * 128));
+    HIP_OK(hipMalloc((void**)&d_freqs, 4 * nb * 128));
+    DecodeArgs a{};
+    a.arena = idx->d_arena;
+    a.term.list_off = idx->list_off[term];
+    a.term.list_end = idx->list_end[term];
+    a.term.n = (uint32_t)len;
+    a.term.term = term;
+    a.codec = idx->kind;
+    a.num_docs = (uint32_t)idx->num_docs;
+    a.out_docs = d_docs;
+    a.out_freqs = d_freqs;
+    a.stats = nullptr;
+    unsigned grid = (unsigned)std::min<uint64_t>(nb, uint64_t(idx->num_cus) * 16);
+    hipError_t e = ds2i_launch_decode_list(&a, grid, idx->stream[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->stream[0]);
+    if (e == hipSuccess) e = hipMemcpy(docs, d_docs, 4 * len, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(freqs, d_freqs, 4 * len, hipMemcpyDeviceToHost);
+    (void)hipFree(d_docs);
+    (void)hipFree(d_freqs);
+    if (e != hipSuccess) return ds2i_set_error(DS2I_EDEVICE, hipGetErrorString(e));
+    return DS2I_OK;
+}
+
+void ds2i_hip_batch_free(ds2i_hip_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->idx->device);
+    (void)hipFree(b->d_qterms);
+    (void)hipFree(b->d_qoff);
+    (void)hipFree(b->d_order[0]);
+    (void)hipFree(b->d_order[1]);
+    (void)hipFree(b->d_count);
+    (void)hipFree(b->d_topk);
+    (void)hipFree(b->d_topk_len);
+    (void)hipFree(b->d_freq_sum);
+    (void)hipFree(b->d_matches);
+    (void)hipFree(b->d_match_off);
+    delete b;
+}
+
+int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                           const uint32_t* query_offsets, uint32_t nq, int want_matches, ds2i_hip_batch** out) {
+    if (!idx || !out || !query_offsets || (!terms && nq && query_offsets[nq] > 0))
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
+    const int base_op = op & ~DS2I_OP_REFERENCE_ORDER;
+    if (base_op < DS2I_OP_AND || base_op > DS2I_OP_RANKED_OR)
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
+    const bool conj = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
+    if ((op & DS2I_OP_REFERENCE_ORDER) && !conj)
+        return ds2i_set_error(DS2I_EINVAL, "DS2I_OP_REFERENCE_ORDER only applies to and / and_freq / ranked_and");
+    const bool ranked = base_op >= DS2I_OP_RANKED_AND;
+    if (ranked && !idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
+    if (ranked && (k == 0 || k > DS2I_HIP_MAX_K)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1,64]");
+    if (!ranked && k == 0) k = 1;
+    if (k > DS2I_HIP_MAX_K) k = DS2I_HIP_MAX_K;
+
+    std::unique_ptr<ds2i_hip_batch, void (*)(ds2i_hip_batch*)> b(new ds2i_hip_batch, ds2i_hip_batch_free);
+    b->idx = idx;
+    b->op = op;
+    b->k = k;
+    b->nq = nq;
+    b->want_matches = want_matches && (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ);
+
+    std::vector<QTerm> qterms;
+    std::vector<uint32_t> qoff(nq + 1, 0);
+    std::vector<std::pair<double, uint32_t>> cls[2];
+    b->match_off.assign(nq + 1, 0);
+    std::vector<uint32_t> t;
+    std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (query_offsets[q + 1] < query_offsets[q])
+            return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
+        t.assign(terms + query_offsets[q], terms + query_offsets[q + 1]);
+        std::sort(t.begin(), t.end()); // queries.hpp:31 / 139
+        tf.clear();
+        for (size_t i = 0; i < t.size(); ++i) {
+            if (t[i] >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+            if (i == 0 || t[i] != t[i - 1]) tf.emplace_back(t[i], 1u);
+            else tf.back().second += 1;
+        }
+        if (tf.size() > DS2I_HIP_MAX_TERMS) return ds2i_set_error(DS2I_ETOOLONG, "query has more than 16 distinct terms");
+        const size_t begin = qterms.size();
+        for (auto const& p : tf) {
+            QTerm qt;
+            qt.list_off = idx->list_off[p.first];
+            qt.list_end = idx->list_end[p.first];
+            qt.n = idx->list_n[p.first];
+            qt.term = p.first;
+            qt.q_weight = 0.f;
+            qt.max_weight = 0.f;
+            if (ranked) {
+                qt.q_weight = ds2i_host::bm25::query_term_weight(p.second, qt.n, idx->num_docs);
+                qt.max_weight = qt.q_weight * idx->max_term_weight[p.first];
+            }
+            qterms.push_back(qt);
+        }
+        double cost = 0;
+        if (conj) { // sort by increasing frequency (queries.hpp:53-56, 357-360)
+            std::stable_sort(qterms.begin() + begin, qterms.end(),
+                             [](QTerm const& l, QTerm const& r) { return l.n < r.n; });
+            if (!tf.empty()) {
+                double n0 = qterms[begin].n;
+                for (size_t i = begin; i < qterms.size(); ++i) cost += std::min<double>(qterms[i].n, 128.0 * n0);
+                b->match_off[q + 1] = (unsigned long long)qterms[begin].n;
+            }
+        } else {
+            for (size_t i = begin; i < qterms.size(); ++i) cost += qterms[i].n;
+        }
+        qoff[q + 1] = (uint32_t)qterms.size();
+        cls[tf.size() <= 4 ? 0 : 1].emplace_back(cost, q);
+    }
+    for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
+
+    HIP_OK(hipSetDevice(idx->device));
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 4);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_OK(upload((void**)&b->d_qterms, qterms.data(), qterms.size() * sizeof(QTerm)));
+    HIP_OK(upload((void**)&b->d_qoff, qoff.data(), qoff.size() * 4));
+    for (int c = 0; c < 2; ++c) {
+        std::stable_sort(cls[c].begin(), cls[c].end(),
+                         [](auto const& l, auto const& r) { return l.first > r.first; }); // costliest first
+        std::vector<uint32_t> order(cls[c].size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = cls[c][i].second;
+        b->ncls[c] = (uint32_t)order.size();
+        HIP_OK(upload((void**)&b->d_order[c], order.data(), order.size() * 4));
+    }
+    HIP_OK(hipMalloc((void**)&b->d_count, 8 * (size_t)(nq ? nq : 1)));
+    HIP_OK(hipMalloc((void**)&b->d_topk, 4 * (size_t)(nq ? nq : 1) * k));
+    HIP_OK(hipMalloc((void**)&b->d_topk_len, 4 * (size_t)(nq ? nq : 1)));
+    HIP_OK(hipMalloc((void**)&b->d_freq_sum, 8 * (size_t)(nq ? nq : 1)));
+    HIP_OK(hipMemset(b->d_topk_len, 0, 4 * (size_t)(nq ? nq : 1)));
+    if (b->want_matches) {
+        HIP_OK(hipMalloc((void**)&b->d_matches, 4 * (size_t)(b->match_off[nq] ? b->match_off[nq] : 1)));
+        HIP_OK(upload((void**)&b->d_match_off, b->match_off.data(), b->match_off.size() * 8));
+    }
+    *out = b.release();
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_run: null batch");
+    ds2i_hip_index* idx = b->idx;
+    HIP_OK(hipSetDevice(idx->device));
+    hipStream_t s0 = idx->stream[0], s1 = idx->stream[1];
+    HIP_OK(hipMemsetAsync(idx->d_ticket, 0, 2 * sizeof(unsigned int), s0));
+    HIP_OK(hipMemsetAsync(idx->d_stats, 0, 2 * sizeof(Stats), s0));
+    // ev[0] start (s0) ; class 0 kernel on s0 between ev[1],ev[2] ; class 1 kernel on s1 between ev[3],ev[4] ; ev[5] end
+    HIP_OK(hipEventRecord(idx->ev[0], s0));
+    HIP_OK(hipStreamWaitEvent(s1, idx->ev[0], 0));
+    for (int c = 0; c < 2; ++c) {
+        hipStream_t s = c ? s1 : s0;
+        HIP_OK(hipEventRecord(idx->ev[1 + 2 * c], s));
+        if (b->ncls[c]) {
+            BatchArgs a{};
+            a.arena = idx->d_arena;
+            a.norm_lens = idx->d_norm_lens;
+            a.qterms = b->d_qterms;
+            a.q_off = b->d_qoff;
+            a.order = b->d_order[c];
+            a.nslice = b->ncls[c];
+            a.num_docs = (uint32_t)idx->num_docs;
+            a.k = b->k;
+            a.codec = idx->kind;
+            a.ticket = idx->d_ticket + c;
+            a.out_count = b->d_count;
+            a.out_topk = b->d_topk;
+            a.out_topk_len = b->d_topk_len;
+            a.out_freq_sum = b->d_freq_sum;
+            a.out_matches = b->want_matches ? b->d_matches : nullptr;
+            a.match_off = b->d_match_off;
+            a.stats = idx->d_stats + c;
+            const unsigned per_cu = c ? 7u : 24u; // resident one-wave workgroups per CU (LDS bound)
+            unsigned grid = (unsigned)std::min<uint64_t>(b->ncls[c], uint64_t(idx->num_cus) * per_cu);
+            HIP_OK(ds2i_launch_batch(b->op, c, &a, grid, s));
+        }
+        HIP_OK(hipEventRecord(idx->ev[2 + 2 * c], s));
+    }
+    HIP_OK(hipStreamWaitEvent(s0, idx->ev[4], 0));
+    HIP_OK(hipEventRecord(idx->ev[5], s0));
+    HIP_OK(hipStreamSynchronize(s0));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[5]));
+    for (int c = 0; c < 2; ++c) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], idx->ev[1 + 2 * c], idx->ev[2 + 2 * c]));
+    HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, 2 * sizeof(Stats), hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->kernel_ms = ms;
+        stats->docs_blocks_decoded = b->cls_stats[0].docs_blocks + b->cls_stats[1].docs_blocks;
+        stats->freqs_blocks_decoded = b->cls_stats[0].freqs_blocks + b->cls_stats[1].freqs_blocks;
+        stats->block_max_examined = b->cls_stats[0].block_max_examined + b->cls_stats[1].block_max_examined;
+        stats->algorithmic_bytes = b->cls_stats[0].algorithmic_bytes + b->cls_stats[1].algorithmic_bytes;
+        stats->postings_scored = b->cls_stats[0].postings_scored + b->cls_stats[1].postings_scored;
+        stats->rounds = b->cls_stats[0].rounds + b->cls_stats[1].rounds;
+    }
+    return DS2I_OK;
+}
+
+// per kernel-class timing / bytes of the last run (class 0: <=4 distinct terms, class 1: 5..16)
+int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries) {
+    if (!b || !out || cls < 0 || cls > 1) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_class_stats: bad argument");
+    out->kernel_ms = b->cls_ms[cls];
+    out->docs_blocks_decoded = b->cls_stats[cls].docs_blocks;
+    out->freqs_blocks_decoded = b->cls_stats[cls].freqs_blocks;
+    out->block_max_examined = b->cls_stats[cls].block_max_examined;
+    out->algorithmic_bytes = b->cls_stats[cls].algorithmic_bytes;
+    out->postings_scored = b->cls_stats[cls].postings_scored;
+    out->rounds = b->cls_stats[cls].rounds;
+    if (nqueries) *nqueries = b->ncls[cls];
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_fetch(ds2i_hip_batch* b, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len,
+                         uint64_t* out_freq_sum) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch: null batch");
+    HIP_OK(hipSetDevice(b->idx->device));
+    const size_t nq = b->nq;
+    if (!nq) return DS2I_OK;
+    if (out_count) HIP_OK(hipMemcpy(out_count, b->d_count, 8 * nq, hipMemcpyDeviceToHost));
+    if (out_topk) HIP_OK(hipMemcpy(out_topk, b->d_topk, 4 * nq * b->k, hipMemcpyDeviceToHost));
+    if (out_topk_len) HIP_OK(hipMemcpy(out_topk_len, b->d_topk_len, 4 * nq, hipMemcpyDeviceToHost));
+    if (out_freq_sum) HIP_OK(hipMemcpy(out_freq_sum, b->d_freq_sum, 8 * nq, hipMemcpyDeviceToHost));
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total) {
+    if (!b || !total) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_match_total: null argument");
+    *total = b->want_matches ? b->match_off[b->nq] : 0;
+    return DS2I_OK;
+}
+
+// matches of query q occupy [match_offsets[q], match_offsets[q] + out_count[q]) (capacity = shortest list)
+int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches) {
+    if (!b || !match_offsets || !matches) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch_matches: null argument");
+    if (!b->want_matches) return ds2i_set_error(DS2I_EINVAL, "batch was prepared without want_matches");
+    HIP_OK(hipSetDevice(b->idx->device));
+    for (size_t i = 0; i <= b->nq; ++i) match_offsets[i] = b->match_off[i];
+    if (b->match_off[b->nq])
+        HIP_OK(hipMemcpy(matches, b->d_matches, 4 * (size_t)b->match_off[b->nq], hipMemcpyDeviceToHost));
+    return DS2I_OK;
+}
+
+int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                         const uint32_t* query_offsets, uint32_t nq, uint64_t* out_count, float* out_topk,
+                         uint32_t* out_topk_len, ds2i_hip_stats* stats) {
+    ds2i_hip_batch* b = nullptr;
+    int rc = ds2i_hip_batch_prepare(idx, op, k, terms, query_offsets, nq, 0, &b);
+    if (rc) return rc;
+    rc = ds2i_hip_batch_run(b, stats);
+    if (!rc) rc = ds2i_hip_batch_fetch(b, out_count, out_topk, out_topk_len, nullptr);
+    ds2i_hip_batch_free(b);
+    return rc;
+}
+
+int ds2i_hip_selftest_scan(int device, const uint32_t* in, uint32_t* out, uint32_t rows) {
+    if (!in || !out || !rows) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_selftest_scan: bad argument");
+    if (device < 0 || device >= ds2i_hip_device_count()) return ds2i_set_error(DS2I_EDEVICE, "no such HIP device");
+    HIP_OK(hipSetDevice(device));
+    uint32_t *di = nullptr, *dout = nullptr;
+    HIP_OK(hipMalloc((void**)&di, 256 * rows));
+    HIP_OK(hipMalloc((void**)&dout, 256 * rows));
+    hipError_t e = hipMemcpy(di, in, 256 * rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ds2i_launch_selftest(di, dout, rows, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dout, 256 * rows, hipMemcpyDeviceToHost);
+    (void)hipFree(di);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return ds2i_set_error(DS2I_EDEVICE, hipGetErrorString(e));
+    return DS2I_OK;
+}
+
+} // extern "C"

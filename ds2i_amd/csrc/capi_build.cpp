@@ -1,0 +1,220 @@
+// Host-side (CPU) implementation of include/ds2i_build.h. No GPU work here.
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "../../include/ds2i_build.h"
+#include "capi_error.hpp"
+#include "host_encode.hpp"
+#include "host_index.hpp"
+#include "host_synth.hpp"
+
+using namespace ds2i_host;
+
+struct ds2i_blob { bytes_t data; };
+struct ds2i_builder {
+    std::unique_ptr<block_index_builder> b;
+};
+struct ds2i_wand_builder {
+    std::vector<float> norm_lens, max_w;
+};
+
+namespace {
+synth_params to_params(const ds2i_synth_params* p) {
+    synth_params s;
+    s.seed = p->seed; s.num_docs = p->num_docs; s.num_terms = p->num_terms; s.zipf_exp = p->zipf_exp;
+    s.top_df_frac = p->top_df_frac; s.min_len = p->min_len; s.clustered_every = p->clustered_every;
+    return s;
+}
+} // namespace
+
+#define DS2I_TRY try {
+#define DS2I_CATCH                                                                       \
+    } catch (std::bad_alloc const&) { return ds2i_set_error(-7, "out of memory"); }     \
+    catch (std::invalid_argument const& e) { return ds2i_set_error(-1, e.what()); }      \
+    catch (std::exception const& e) { return ds2i_set_error(-2, e.what()); }
+
+extern "C" {
+
+const uint8_t* ds2i_blob_data(const ds2i_blob* b) { return b ? b->data.data() : nullptr; }
+size_t ds2i_blob_size(const ds2i_blob* b) { return b ? b->data.size() : 0; }
+void ds2i_blob_free(ds2i_blob* b) { delete b; }
+
+int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out) {
+    if (!out || codec < 0 || codec > 4) return ds2i_set_error(-1, "ds2i_builder_create: bad argument");
+    DS2I_TRY
+    auto* h = new ds2i_builder;
+    h->b.reset(new block_index_builder(codec, num_docs));
+    *out = h;
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_builder_add_posting_list(ds2i_builder* b, uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
+    if (!b || !docs || !freqs) return ds2i_set_error(-1, "ds2i_builder_add_posting_list: null argument");
+    DS2I_TRY
+    b->b->add_posting_list(n, docs, freqs);
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_builder_freeze(ds2i_builder* b, ds2i_blob** image) {
+    if (!b || !image) return ds2i_set_error(-1, "ds2i_builder_freeze: null argument");
+    DS2I_TRY
+    auto* blob = new ds2i_blob;
+    b->b->freeze(blob->data);
+    *image = blob;
+    return 0;
+    DS2I_CATCH
+}
+void ds2i_builder_free(ds2i_builder* b) { delete b; }
+
+int ds2i_wand_create(const uint32_t* doc_sizes, uint64_t num_docs, ds2i_wand_builder** out) {
+    if (!doc_sizes || !out || !num_docs) return ds2i_set_error(-1, "ds2i_wand_create: bad argument");
+    DS2I_TRY
+    auto* w = new ds2i_wand_builder;
+    compute_norm_lens(doc_sizes, num_docs, w->norm_lens);
+    *out = w;
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_wand_add_list(ds2i_wand_builder* w, uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
+    if (!w || !docs || !freqs) return ds2i_set_error(-1, "ds2i_wand_add_list: null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        if (docs[i] >= w->norm_lens.size()) return ds2i_set_error(-1, "ds2i_wand_add_list: doc id out of range");
+    w->max_w.push_back(list_max_weight(w->norm_lens.data(), n, docs, freqs));
+    return 0;
+}
+int ds2i_wand_freeze(ds2i_wand_builder* w, ds2i_blob** image) {
+    if (!w || !image) return ds2i_set_error(-1, "ds2i_wand_freeze: null argument");
+    DS2I_TRY
+    auto* blob = new ds2i_blob;
+    wand_freeze(w->norm_lens, w->max_w, blob->data);
+    *image = blob;
+    return 0;
+    DS2I_CATCH
+}
+void ds2i_wand_free(ds2i_wand_builder* w) { delete w; }
+
+int ds2i_encode_block(int codec, const uint32_t* values, uint32_t sum, uint32_t n, ds2i_blob** out) {
+    if (!values || !out || n == 0 || n > BLOCK) return ds2i_set_error(-1, "ds2i_encode_block: bad argument");
+    DS2I_TRY
+    auto* blob = new ds2i_blob;
+    block_encode(codec, values, sum, n, blob->data);
+    *out = blob;
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out) {
+    if (!out) return ds2i_set_error(-1, "ds2i_encode_vbyte: null argument");
+    auto* blob = new ds2i_blob;
+    vbyte_encode(value, blob->data);
+    *out = blob;
+    return 0;
+}
+int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const uint32_t* freqs, ds2i_blob** out) {
+    if (!docs || !freqs || !out || !n) return ds2i_set_error(-1, "ds2i_encode_posting_list: bad argument");
+    DS2I_TRY
+    auto* blob = new ds2i_blob;
+    write_posting_list(codec, blob->data, n, docs, freqs);
+    *out = blob;
+    return 0;
+    DS2I_CATCH
+}
+
+uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term) {
+    (void)term;
+    return p ? p->num_docs : 0;
+}
+int ds2i_synth_list(const ds2i_synth_params* p, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,
+                    uint64_t* n) {
+    if (!p || !docs || !freqs || !n) return ds2i_set_error(-1, "ds2i_synth_list: null argument");
+    DS2I_TRY
+    std::vector<uint32_t> d, f;
+    uint64_t len = synth_list(to_params(p), term, d, f);
+    *n = len;
+    if (len > capacity) return ds2i_set_error(-1, "ds2i_synth_list: capacity too small");
+    std::memcpy(docs, d.data(), 4 * len);
+    std::memcpy(freqs, f.data(), 4 * len);
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_synth_doc_sizes(const ds2i_synth_params* p, uint32_t* sizes) {
+    if (!p || !sizes) return ds2i_set_error(-1, "ds2i_synth_doc_sizes: null argument");
+    DS2I_TRY
+    std::vector<uint32_t> s;
+    synth_doc_sizes(to_params(p), s);
+    std::memcpy(sizes, s.data(), 4 * s.size());
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t* terms, uint32_t* offsets) {
+    if (!terms || !offsets || !num_terms) return ds2i_set_error(-1, "ds2i_synth_queries: bad argument");
+    DS2I_TRY
+    std::vector<uint32_t> t, o;
+    synth_queries(seed, num_terms, nq, t, o);
+    std::memcpy(terms, t.data(), 4 * t.size());
+    std::memcpy(offsets, o.data(), 4 * o.size());
+    return 0;
+    DS2I_CATCH
+}
+
+int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_blob** index_image,
+                     ds2i_blob** wand_image, uint64_t* total_postings) {
+    if (!pp || !index_image || codec < 0 || codec > 4) return ds2i_set_error(-1, "ds2i_synth_build: bad argument");
+    DS2I_TRY
+    const synth_params p = to_params(pp);
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<uint32_t> sizes;
+    synth_doc_sizes(p, sizes);
+    std::vector<float> norm_lens;
+    compute_norm_lens(sizes.data(), p.num_docs, norm_lens);
+    sizes.clear();
+    sizes.shrink_to_fit();
+    const uint32_t V = p.num_terms;
+    std::vector<bytes_t> enc(V);
+    std::vector<float> max_w(V);
+    std::atomic<uint32_t> next(0);
+    std::atomic<uint64_t> postings(0);
+    std::string err;
+    std::mutex err_mu;
+    auto worker = [&]() {
+        std::vector<uint32_t> d, f;
+        try {
+            for (;;) {
+                uint32_t t = next.fetch_add(1);
+                if (t >= V) break;
+                uint64_t n = synth_list(p, t, d, f);
+                write_posting_list(codec, enc[t], (uint32_t)n, d.data(), f.data());
+                max_w[t] = list_max_weight(norm_lens.data(), n, d.data(), f.data());
+                postings += n;
+            }
+        } catch (std::exception const& e) {
+            std::lock_guard<std::mutex> g(err_mu);
+            err = e.what();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
+    if (!err.empty()) return ds2i_set_error(-2, err.c_str());
+    block_index_builder builder(codec, p.num_docs);
+    for (uint32_t t = 0; t < V; ++t) {
+        builder.add_encoded_list(enc[t].data(), enc[t].size());
+        bytes_t().swap(enc[t]);
+    }
+    auto* ib = new ds2i_blob;
+    builder.freeze(ib->data);
+    *index_image = ib;
+    if (wand_image) {
+        auto* wb = new ds2i_blob;
+        wand_freeze(norm_lens, max_w, wb->data);
+        *wand_image = wb;
+    }
+    if (total_postings) *total_postings = postings.load();
+    return 0;
+    DS2I_CATCH
+}
+
+} // extern "C"

@@ -1,0 +1,397 @@
+// CDNA4 (gfx950, wave64) device-side block decoders for the ds2i block index formats.
+// One wavefront decodes one 128-posting block cooperatively:
+//   coalesced dword loads of the encoded block -> per-wave LDS staging window ->
+//   per-lane bit extraction (v_alignbit/v_alignbyte) -> wave prefix sums (DPP).
+// No MFMA: this is integer/bit work bound by HBM latency/bandwidth.
+//
+// Replaces (reference file:line):
+//   TightVariableByte::decode        block_codecs.hpp:84-98
+//   interpolative_block::decode      block_codecs.hpp:127-147, interpolative_coding.hpp:79-153
+//   optpfor_block::decode            block_codecs.hpp:210-226 (+ FastPFor OPTPFor/Simple16, restated)
+//   varint_G8IU_block::decode        block_codecs.hpp:239-258,287-314
+//   qmx_block::decode                block_codecs.hpp:336-349, qmx_codec.hpp:636-6115
+//   mixed_block::decode              mixed_block.hpp:198-217
+//
+// Value layout in registers ("layout A"): value i of a block lives in lane (i & 63),
+// slot (i >> 6); a lane therefore returns two values v0 (index lane) and v1 (index lane+64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ds2i_dev {
+
+#define DS2I_DEV __device__ __forceinline__
+
+enum { CODEC_OPTPFOR = 0, CODEC_VARINT = 1, CODEC_INTERPOLATIVE = 2, CODEC_QMX = 3, CODEC_MIXED = 4 };
+
+static constexpr uint32_t STAGE_DW = 160; // staging window, dwords (640 B)
+static constexpr uint32_t EXC_DW = 256;   // Simple16 exception scratch / generic out scratch
+
+DS2I_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// All kernels run wave-uniform control flow with one wave per LDS region, so a
+// wave-level fence is the only synchronisation ever needed between LDS phases.
+DS2I_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+DS2I_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DS2I_DEV uint32_t bcast(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane); }
+DS2I_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---- wave64 inclusive prefix sum, DPP (row_shr 1/2/4/8 + row_bcast15 + row_bcast31)
+template <int CTRL, int ROW_MASK>
+DS2I_DEV uint32_t dpp_add(uint32_t x) {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return x + t;
+}
+DS2I_DEV uint32_t wave_incl_scan(uint32_t x) {
+    x = dpp_add<0x111, 0xF>(x); // row_shr:1
+    x = dpp_add<0x112, 0xF>(x); // row_shr:2
+    x = dpp_add<0x114, 0xF>(x); // row_shr:4
+    x = dpp_add<0x118, 0xF>(x); // row_shr:8
+    x = dpp_add<0x142, 0xA>(x); // row_bcast:15 -> rows 1,3
+    x = dpp_add<0x143, 0xC>(x); // row_bcast:31 -> rows 2,3
+    return x;
+}
+
+// ---- unaligned global loads (lists are byte-aligned on disk; gfx950 under HSA runs
+// in unaligned-access mode, the compiler emits one global_load_dword per memcpy)
+DS2I_DEV uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+DS2I_DEV uint32_t ld8(const uint8_t* p) { return *p; }
+
+// ---- staging window: a run of aligned dwords of the arena cached in LDS
+struct Window {
+    const uint8_t* gbase; // 4-byte aligned global address of st[0]
+    uint32_t nbytes;      // staged bytes from gbase
+    uint32_t* st;         // LDS, STAGE_DW dwords
+
+    DS2I_DEV void load(const uint8_t* p, uint32_t want_bytes) {
+        uintptr_t a = (uintptr_t)p;
+        gbase = (const uint8_t*)(a & ~(uintptr_t)3);
+        uint32_t sh = (uint32_t)(a & 3);
+        uint32_t ndw = (sh + want_bytes + 3) >> 2;
+        if (ndw > STAGE_DW) ndw = STAGE_DW;
+        nbytes = ndw * 4;
+        const uint32_t* g = (const uint32_t*)gbase;
+        for (uint32_t i = lane_id(); i < ndw; i += 64) st[i] = g[i];
+        wave_sync();
+    }
+    DS2I_DEV bool covers(const uint8_t* p, uint32_t len) const {
+        return p >= gbase && (uint32_t)(p - gbase) + len <= nbytes;
+    }
+    // 32 bits at arbitrary byte address
+    DS2I_DEV uint32_t rd32(const uint8_t* p) const {
+        uint32_t off = (uint32_t)(p - gbase);
+        if (p >= gbase && off + 8 <= nbytes) {
+            uint32_t w = off >> 2, r = off & 3;
+            return __builtin_amdgcn_alignbyte(st[w + 1], st[w], r);
+        }
+        return ld32(p);
+    }
+    // 64 bits at arbitrary byte address
+    DS2I_DEV uint64_t rd64(const uint8_t* p) const {
+        uint32_t off = (uint32_t)(p - gbase);
+        uint32_t lo, hi;
+        if (p >= gbase && off + 12 <= nbytes) {
+            uint32_t w = off >> 2, r = off & 3;
+            uint32_t d0 = st[w], d1 = st[w + 1], d2 = st[w + 2];
+            lo = __builtin_amdgcn_alignbyte(d1, d0, r);
+            hi = __builtin_amdgcn_alignbyte(d2, d1, r);
+        } else {
+            lo = ld32(p);
+            hi = ld32(p + 4);
+        }
+        return ((uint64_t)hi << 32) | lo;
+    }
+    DS2I_DEV uint32_t rd8(const uint8_t* p) const {
+        uint32_t off = (uint32_t)(p - gbase);
+        if (p >= gbase && off < nbytes) return (st[off >> 2] >> ((off & 3) * 8)) & 0xFF;
+        return ld8(p);
+    }
+};
+
+// ---- vbyte (terminator has bit 7 set); wave-uniform, returns bytes consumed
+DS2I_DEV uint32_t vbyte_decode(const Window& w, const uint8_t* p, uint32_t& val) {
+    uint32_t v = 0, shift = 0, i = 0;
+    for (;;) {
+        uint32_t c = uniform(w.rd8(p + i));
+        ++i;
+        v += (c & 127u) << shift;
+        if ((c & 128u) || i == 5) break;
+        shift += 7;
+    }
+    val = v;
+    return i;
+}
+
+// ---- binary interpolative (serial bit stream; executed wave-uniformly, lane 0 stores)
+struct BitReader {
+    const Window* w;
+    const uint8_t* in;
+    uint64_t buf;
+    uint32_t avail, pos;
+    DS2I_DEV uint32_t read(uint32_t len) {
+        if (!len) return 0;
+        if (avail < len) {
+            buf |= (uint64_t)uniform(w->rd32(in)) << avail;
+            in += 4;
+            avail += 32;
+        }
+        uint32_t val = (uint32_t)(buf & ((uint64_t(1) << len) - 1));
+        buf >>= len;
+        avail -= len;
+        pos += len;
+        return val;
+    }
+    DS2I_DEV uint32_t read_int(uint32_t u) { // u > 0
+        uint32_t b = 31u - (uint32_t)__builtin_clz(u);
+        uint64_t m = (uint64_t(1) << (b + 1)) - u;
+        uint32_t val = read(b);
+        if (val >= m) val = (val << 1) + read(1) - (uint32_t)m;
+        return val;
+    }
+};
+
+// Decodes n (<=128) values into out[] (LDS, index order) as PREFIX SUMS P_i
+// (P_{n-1} = sum). Returns bytes consumed. The bit stream is inherently serial
+// (interpolative_coding.hpp:124-146), so lane 0 runs it alone; `stk` is >= 8 dwords of LDS
+// used as the explicit pre-order stack (packed offset<<8 | count). Bounds of a segment
+// [o,o+c) are read back from out[]: low = P_{o-1} (0 at o==0), high = P_{o+c}.
+DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p, uint32_t sum, uint32_t n,
+                                              uint32_t* out, uint32_t* stk) {
+    uint32_t consumed = 0;
+    if (lane_id() == 0) {
+        if (sum == 0xFFFFFFFFu) {
+            consumed = vbyte_decode(w, p, sum);
+            p += consumed;
+        }
+        out[n - 1] = sum;
+        if (n > 1) {
+            BitReader br{&w, p, 0, 0, 0};
+            int sp = 0;
+            stk[sp++] = n - 1; // offset 0, count n-1
+            while (sp > 0) {
+                uint32_t e = stk[--sp];
+                uint32_t o = e >> 8, c = e & 0xFFu;
+                while (c > 0) {
+                    uint32_t h = c >> 1;
+                    uint32_t low = o ? out[o - 1] : 0u;
+                    uint32_t high = out[o + c];
+                    uint32_t val = low + br.read_int(high - low + 1);
+                    out[o + h] = val;
+                    uint32_t rc = c - h - 1;
+                    if (rc) stk[sp++] = ((o + h + 1) << 8) | rc;
+                    c = h;
+                }
+            }
+            consumed += (br.pos + 7) >> 3;
+        }
+    }
+    wave_sync();
+    return bcast(consumed, 0);
+}
+
+// ---- Simple16 layouts (selector -> per-value widths), packed 5 bits per entry is
+// overkill; use run descriptors: up to 3 runs of (count,width).
+__device__ static const uint8_t S16_RUNS[16][6] = {
+    {28, 1, 0, 0, 0, 0}, {7, 2, 14, 1, 0, 0}, {7, 1, 7, 2, 7, 1}, {14, 1, 7, 2, 0, 0},
+    {14, 2, 0, 0, 0, 0}, {1, 4, 8, 3, 0, 0},  {1, 3, 4, 4, 3, 3}, {7, 4, 0, 0, 0, 0},
+    {4, 5, 2, 4, 0, 0},  {2, 4, 4, 5, 0, 0},  {3, 6, 2, 5, 0, 0}, {2, 5, 3, 6, 0, 0},
+    {4, 7, 0, 0, 0, 0},  {1, 10, 2, 9, 0, 0}, {2, 14, 0, 0, 0, 0}, {1, 28, 0, 0, 0, 0}};
+__device__ static const uint8_t S16_COUNT[16] = {28, 21, 21, 21, 14, 9, 8, 7, 6, 6, 5, 5, 4, 3, 2, 1};
+
+// ---- OptPFor full block (128 values). Returns bytes consumed; values in v0/v1 (layout A).
+// scratch `exc` (EXC_DW dwords) and `out` (128 dwords) are LDS.
+DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* exc, uint32_t* out, uint32_t& v0,
+                                 uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const uint32_t hdr = uniform(w.rd32(p));
+    const uint32_t b = hdr >> 26;
+    const uint32_t nexc = (hdr >> 16) & 0x3FFu;
+    const uint32_t ew = hdr & 0xFFFFu;
+    const uint8_t* data = p + 4 + 4 * ew;
+    if (b >= 32) {
+        v0 = w.rd32(data + 4 * lane);
+        v1 = w.rd32(data + 4 * (lane + 64));
+        return 4 * (1 + 128);
+    }
+    if (b == 0) {
+        v0 = v1 = 0;
+    } else {
+        const uint32_t mask = (1u << b) - 1u;
+        uint32_t bit0 = lane * b, bit1 = (lane + 64) * b;
+        uint64_t x0 = w.rd64(data + 4 * (bit0 >> 5));
+        uint64_t x1 = w.rd64(data + 4 * (bit1 >> 5));
+        v0 = (uint32_t)(x0 >> (bit0 & 31)) & mask;
+        v1 = (uint32_t)(x1 >> (bit1 & 31)) & mask;
+    }
+    if (nexc) {
+        // expand Simple16 words: lane j handles word j (+64 per round)
+        uint32_t total = 0;
+        const uint32_t need = 2 * nexc;
+        for (uint32_t base = 0; base < ew && total < need; base += 64) {
+            uint32_t j = base + lane;
+            uint32_t word = (j < ew) ? w.rd32(p + 4 + 4 * j) : 0;
+            uint32_t sel = word >> 28;
+            uint32_t cnt = (j < ew) ? S16_COUNT[sel] : 0;
+            uint32_t incl = wave_incl_scan(cnt);
+            uint32_t off = total + incl - cnt;
+            if (j < ew) {
+                uint32_t pos = 28, k = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    uint32_t rc = S16_RUNS[sel][2 * r], rw = S16_RUNS[sel][2 * r + 1];
+                    for (uint32_t c = 0; c < rc; ++c, ++k) {
+                        pos -= rw;
+                        uint32_t val = (word >> pos) & ((1u << rw) - 1u);
+                        if (off + k < EXC_DW) exc[off + k] = val;
+                    }
+                }
+            }
+            total += bcast(incl, 63);
+        }
+        out[lane] = v0;
+        out[lane + 64] = v1;
+        wave_sync();
+        // positions are delta coded: lpos_e = sum_{j<=e}(exc[j]+1) - 1
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nexc; base += 64) {
+            uint32_t e = base + lane;
+            uint32_t d = (e < nexc) ? exc[e] + 1 : 0;
+            uint32_t incl = wave_incl_scan(d);
+            uint32_t lpos = carry + incl - 1;
+            if (e < nexc && lpos < 128) out[lpos] |= (exc[e + nexc] + 1) << b;
+            carry += bcast(incl, 63);
+        }
+        wave_sync();
+        v0 = out[lane];
+        v1 = out[lane + 64];
+        wave_sync();
+    }
+    return 4 * (1 + ew + 4 * b);
+}
+
+// ---- VarInt-G8IU full block. Values are scattered to out[] (LDS) then re-read.
+DS2I_DEV uint32_t varint_g8iu_decode(const Window& w, const uint8_t* p, uint32_t* out, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const uint8_t* g = p + 9 * lane;
+    uint32_t desc = w.rd8(g);
+    uint32_t cnt = (uint32_t)__builtin_popcount(~desc & 0xFFu);
+    uint32_t incl = wave_incl_scan(cnt);
+    uint32_t excl = incl - cnt;
+    uint64_t active = ballot(excl < 128);
+    uint32_t groups = (uint32_t)__builtin_popcountll(active);
+    if (excl < 128) {
+        uint64_t bytes = w.rd64(g + 1);
+        uint32_t val = 0, k = 0, o = excl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            val |= (uint32_t)((bytes >> (8 * j)) & 0xFF) << (8 * k);
+            ++k;
+            if (!((desc >> j) & 1u)) {
+                if (o < 128) out[o] = val;
+                ++o;
+                val = 0;
+                k = 0;
+            }
+        }
+    }
+    wave_sync();
+    v0 = out[lane];
+    v1 = out[lane + 64];
+    wave_sync();
+    return 9 * groups;
+}
+
+// ---- QMX full block: vbyte(enc_len) | payload vectors | keys (reversed)
+__device__ static const uint8_t QMX_BITS[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32};
+__device__ static const uint16_t QMX_CAP[15] = {256, 128, 64, 40, 32, 24, 20, 36, 16, 28, 12, 20, 8, 12, 4};
+
+DS2I_DEV uint32_t qmx_extract(const Window& w, const uint8_t* vec, uint32_t type, uint32_t j) {
+    const uint32_t bits = QMX_BITS[type];
+    if (type == 0) return 1u;
+    if (type == 8) return w.rd8(vec + j);
+    if (type == 12) return w.rd32(vec + 2 * j) & 0xFFFFu;
+    if (type == 14) return w.rd32(vec + 4 * j);
+    const uint32_t l = j & 3, r = j >> 2;
+    const uint32_t mask = (1u << bits) - 1u;
+    if (type != 7 && type != 9 && type != 11 && type != 13) return (w.rd32(vec + 4 * l) >> (r * bits)) & mask;
+    const uint32_t R1 = 32u / bits;
+    const uint32_t lowpart = 32u - R1 * bits;
+    const uint32_t off2 = (bits == 12) ? 8u : (bits == 21) ? 11u : (bits - lowpart);
+    if (r < R1) return (w.rd32(vec + 4 * l) >> (r * bits)) & mask;
+    uint32_t second = w.rd32(vec + 16 + 4 * l);
+    if (r == R1) return ((w.rd32(vec + 4 * l) >> (r * bits)) | (second << lowpart)) & mask;
+    return (second >> ((r - R1 - 1) * bits + off2)) & mask;
+}
+
+DS2I_DEV uint32_t qmx_decode(Window& w, const uint8_t* p, uint32_t* out, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    uint32_t enc_len;
+    uint32_t vl = vbyte_decode(w, p, enc_len);
+    const uint8_t* src = p + vl;
+    if (!w.covers(src, enc_len + 16) && enc_len + 16 + 4 <= STAGE_DW * 4) w.load(src, enc_len + 16);
+    uint32_t in = 0;
+    int32_t kp = (int32_t)enc_len - 1;
+    uint32_t outpos = 0;
+    while ((int32_t)in <= kp) {
+        uint32_t key = uniform(w.rd8(src + kp));
+        --kp;
+        uint32_t type = key >> 4, reps = 16u - (key & 15u);
+        if (type == 15) { in += reps; continue; }
+        const uint32_t cap = QMX_CAP[type];
+        const uint32_t vbytes = (type == 0) ? 0u : (type == 7 || type == 9 || type == 11 || type == 13) ? 32u : 16u;
+        for (uint32_t r = 0; r < reps; ++r) {
+            if (outpos < 128) {
+                for (uint32_t j = lane; j < cap; j += 64) {
+                    uint32_t o = outpos + j;
+                    if (o < 128) out[o] = qmx_extract(w, src + in, type, j);
+                }
+            }
+            in += vbytes;
+            outpos += cap;
+        }
+    }
+    wave_sync();
+    v0 = out[lane];
+    v1 = out[lane + 64];
+    wave_sync();
+    return vl + enc_len;
+}
+
+// ---- generic block decode: n values (gap-1 / freq-1) -> v0,v1 (layout A; lanes >= n get 0).
+// `out` = 128-dword LDS scratch (may be the destination buffer itself), `exc` = EXC_DW dwords.
+// Returns bytes consumed.
+DS2I_DEV uint32_t decode_block(int codec, Window& w, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out,
+                               uint32_t* exc, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    uint32_t consumed = 0;
+    int c = codec;
+    if (n == 128 && codec == CODEC_MIXED) {
+        uint32_t t = uniform(w.rd8(p));
+        ++p;
+        consumed = 1;
+        c = (t == 0) ? CODEC_OPTPFOR : (t == 1) ? CODEC_VARINT : CODEC_INTERPOLATIVE;
+    }
+    if (n < 128 || c == CODEC_INTERPOLATIVE) {
+        consumed += interpolative_decode_prefix(w, p, sum, n, out, exc);
+        uint32_t a0 = (lane < n) ? out[lane] : 0, a1 = (lane + 64 < n) ? out[lane + 64] : 0;
+        uint32_t b0 = (lane >= 1 && lane < n) ? out[lane - 1] : 0;
+        uint32_t b1 = (lane + 64 < n) ? out[lane + 63] : 0;
+        wave_sync();
+        v0 = a0 - b0;
+        v1 = a1 - b1;
+        return consumed;
+    }
+    switch (c) {
+    case CODEC_OPTPFOR: consumed += optpfor_decode(w, p, exc, out, v0, v1); break;
+    case CODEC_VARINT: consumed += varint_g8iu_decode(w, p, out, v0, v1); break;
+    default: consumed += qmx_decode(w, p, out, v0, v1); break;
+    }
+    return consumed;
+}
+
+} // namespace ds2i_dev

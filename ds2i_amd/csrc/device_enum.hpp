@@ -1,0 +1,265 @@
+// Wave-cooperative posting-list enumerator over a block_freq_index arena in HBM.
+// One wavefront owns up to TMAX list "slots"; each slot keeps its current decoded
+// block in LDS as 128 absolute doc-ids (+ 128 freqs, decoded lazily).
+//
+// Mirrors block_posting_list<>::document_enumerator (reference block_posting_list.hpp:84-354):
+//   open()          ctor 86-103 (vbyte n, three pointers, decode block 0)
+//   next()          110-122
+//   next_geq()      124-146 -- block_max skip = 64-wide ballot scan instead of the linear scan,
+//                   in-block search = two ballots over the LDS-resident doc-ids (O(1))
+//   freq()          165-171 (lazy decode_freqs_block 321-331)
+//   decode_docs()   292-319
+// Exhaustion sentinel: docid == num_docs (115,130).
+#pragma once
+#include "abi_structs.hpp"
+#include "device_codecs.hpp"
+
+namespace ds2i_dev {
+
+enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
+       M_QW, M_MAXW, M_END_LO, M_END_HI, M_WORDS };
+
+struct Ctx {
+    uint32_t* docs;  // [TMAX][128]
+    uint32_t* freqs; // [TMAX][128]
+    uint32_t* meta;  // [TMAX][M_WORDS]
+    uint32_t* exc;   // [EXC_DW]
+    Window win;
+    const uint8_t* arena;
+    int codec;
+    uint32_t num_docs;
+    // per-wave statistics (wave-uniform)
+    uint32_t s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
+    unsigned long long s_bytes;
+
+    DS2I_DEV uint32_t* D(uint32_t s) const { return docs + 128 * s; }
+    DS2I_DEV uint32_t* F(uint32_t s) const { return freqs + 128 * s; }
+    DS2I_DEV uint32_t m(uint32_t s, int f) const { return uniform(meta[s * M_WORDS + f]); }
+    DS2I_DEV void setm(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) meta[s * M_WORDS + f] = v; }
+    DS2I_DEV const uint8_t* ptr(uint32_t s, int lo) const {
+        return arena + (((uint64_t)m(s, lo + 1) << 32) | m(s, lo));
+    }
+    DS2I_DEV uint32_t docid(uint32_t s) const { return m(s, M_DOCID); }
+    DS2I_DEV uint32_t size(uint32_t s) const { return m(s, M_N); }
+
+    DS2I_DEV void init_stats() {
+        s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
+        s_bytes = 0;
+    }
+    DS2I_DEV void flush_stats(Stats* st) {
+        if (st && lane_id() == 0) {
+            atomicAdd(&st->docs_blocks, (unsigned long long)s_docs_blocks);
+            atomicAdd(&st->freqs_blocks, (unsigned long long)s_freqs_blocks);
+            atomicAdd(&st->block_max_examined, (unsigned long long)s_bm_examined);
+            atomicAdd(&st->algorithmic_bytes, s_bytes);
+            atomicAdd(&st->postings_scored, (unsigned long long)s_scored);
+            atomicAdd(&st->rounds, (unsigned long long)s_rounds);
+        }
+    }
+
+    // ---- decode_docs_block (block_posting_list.hpp:292-319)
+    DS2I_DEV void decode_docs(uint32_t s, uint32_t b) {
+        const uint32_t lane = lane_id();
+        const uint8_t* maxs = ptr(s, M_MAXS_LO);
+        const uint32_t n = m(s, M_N), nb = m(s, M_NB);
+        const uint8_t* endpoints = maxs + 4ull * nb;
+        const uint8_t* data = endpoints + 4ull * (nb - 1);
+        // four independent header words: lanes 0..3 fetch one each, then broadcast
+        const uint8_t* lend = ptr(s, M_END_LO);
+        uint32_t hv = 0;
+        if (lane == 0) hv = b ? ld32(endpoints + 4ull * (b - 1)) : 0u;
+        if (lane == 1) hv = ld32(maxs + 4ull * b);
+        if (lane == 2) hv = b ? ld32(maxs + 4ull * (b - 1)) + 1u : 0u;
+        if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
+        const uint32_t ep = bcast(hv, 0), bmax = bcast(hv, 1), base = bcast(hv, 2), next_ep = bcast(hv, 3);
+        const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
+        uint32_t hint = next_ep - ep; // docs+freqs bytes of this block when endpoints are monotone
+        if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+        const uint8_t* p = data + ep;
+        win.load(p, hint);
+        uint32_t v0, v1;
+        uint32_t* dst = D(s);
+        uint32_t consumed = decode_block(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
+        uint32_t g0 = (lane < sz) ? v0 + 1u : 0u;
+        uint32_t g1 = (lane + 64 < sz) ? v1 + 1u : 0u;
+        uint32_t i0 = wave_incl_scan(g0);
+        uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
+        uint32_t d0 = (lane < sz) ? base + i0 - 1u : 0xFFFFFFFFu;
+        uint32_t d1 = (lane + 64 < sz) ? base + i1 - 1u : 0xFFFFFFFFu;
+        dst[lane] = d0;
+        dst[lane + 64] = d1;
+        const uint64_t fo = (uint64_t)(p + consumed - arena);
+        if (lane == 0) {
+            uint32_t* mm = meta + s * M_WORDS;
+            mm[M_CUR] = b;
+            mm[M_SIZE] = sz;
+            mm[M_BMAX] = bmax;
+            mm[M_POS] = 0;
+            mm[M_DOCID] = d0;
+            mm[M_FREQ_LO] = (uint32_t)fo;
+            mm[M_FREQ_HI] = (uint32_t)(fo >> 32);
+            mm[M_FDEC] = 0;
+        }
+        wave_sync();
+        ++s_docs_blocks;
+        s_bytes += 4 + consumed; // endpoint + docs part
+    }
+
+    // ---- decode_freqs_block (block_posting_list.hpp:321-331)
+    DS2I_DEV void decode_freqs(uint32_t s) {
+        const uint32_t lane = lane_id();
+        const uint8_t* p = ptr(s, M_FREQ_LO);
+        const uint32_t sz = m(s, M_SIZE);
+        if (!win.covers(p, 64)) {
+            uint64_t room = (uint64_t)(ptr(s, M_END_LO) - p);
+            win.load(p, room < 256 ? (uint32_t)room + 8 : 256u);
+        }
+        uint32_t v0, v1;
+        uint32_t* dst = F(s);
+        uint32_t consumed = decode_block(codec, win, p, 0xFFFFFFFFu, sz, dst, exc, v0, v1);
+        dst[lane] = v0 + 1u;
+        dst[lane + 64] = v1 + 1u;
+        setm(s, M_FDEC, 1);
+        wave_sync();
+        ++s_freqs_blocks;
+        s_bytes += consumed;
+    }
+
+    // ---- ctor (block_posting_list.hpp:86-103)
+    DS2I_DEV void open(uint32_t s, const QTerm& t) {
+        const uint32_t n = t.n;
+        const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
+        const uint64_t maxs = t.list_off + vl;
+        if (lane_id() == 0) {
+            uint32_t* mm = meta + s * M_WORDS;
+            mm[M_MAXS_LO] = (uint32_t)maxs;
+            mm[M_MAXS_HI] = (uint32_t)(maxs >> 32);
+            mm[M_N] = n;
+            mm[M_NB] = (n + 127u) >> 7;
+            mm[M_QW] = __float_as_uint(t.q_weight);
+            mm[M_MAXW] = __float_as_uint(t.max_weight);
+            mm[M_END_LO] = (uint32_t)t.list_end;
+            mm[M_END_HI] = (uint32_t)(t.list_end >> 32);
+        }
+        wave_sync();
+        s_bytes += vl + 8 + 4; // vbyte(n) + list offset + block_max[0]
+        ++s_bm_examined;
+        decode_docs(s, 0);
+    }
+
+    // first block >= from whose block_max >= lb, or nb if none. 64 entries per probe.
+    DS2I_DEV uint32_t find_block(uint32_t s, uint32_t from, uint32_t lb) {
+        const uint8_t* maxs = ptr(s, M_MAXS_LO);
+        const uint32_t nb = m(s, M_NB);
+        uint32_t blk = from;
+        while (blk < nb) {
+            uint32_t idx = blk + lane_id();
+            uint32_t v = (idx < nb) ? ld32(maxs + 4ull * idx) : 0xFFFFFFFFu;
+            uint64_t hit = ballot(v >= lb);
+            if (hit) {
+                blk += (uint32_t)__builtin_ctzll(hit);
+                break;
+            }
+            blk += 64;
+        }
+        return blk < nb ? blk : nb;
+    }
+
+    // ---- next_geq (block_posting_list.hpp:124-146)
+    DS2I_DEV void next_geq(uint32_t s, uint32_t lb) {
+        if (lb > m(s, M_BMAX)) {
+            const uint32_t cur = m(s, M_CUR);
+            uint32_t blk = find_block(s, cur + 1, lb);
+            if (blk >= m(s, M_NB)) {
+                s_bm_examined += 1; // block_max(nb-1) test
+                s_bytes += 4;
+                setm(s, M_DOCID, num_docs);
+                wave_sync();
+                return;
+            }
+            s_bm_examined += blk - cur;
+            s_bytes += 4ull * (blk - cur);
+            decode_docs(s, blk);
+        }
+        const uint32_t lane = lane_id();
+        const uint32_t* d = D(s);
+        uint32_t d0 = d[lane], d1 = d[lane + 64];
+        uint64_t m0 = ballot(d0 >= lb), m1 = ballot(d1 >= lb);
+        uint32_t idx, val;
+        if (m0) {
+            idx = (uint32_t)__builtin_ctzll(m0);
+            val = bcast(d0, idx);
+        } else {
+            uint32_t l = (uint32_t)__builtin_ctzll(m1);
+            idx = 64 + l;
+            val = bcast(d1, l);
+        }
+        if (lane == 0) {
+            meta[s * M_WORDS + M_POS] = idx;
+            meta[s * M_WORDS + M_DOCID] = val;
+        }
+        wave_sync();
+    }
+
+    // ---- next (block_posting_list.hpp:110-122)
+    DS2I_DEV void next(uint32_t s) {
+        uint32_t pos = m(s, M_POS) + 1;
+        if (pos == m(s, M_SIZE)) {
+            uint32_t cur = m(s, M_CUR);
+            if (cur + 1 == m(s, M_NB)) {
+                setm(s, M_POS, pos);
+                setm(s, M_DOCID, num_docs);
+                wave_sync();
+                return;
+            }
+            ++s_bm_examined;
+            s_bytes += 4;
+            decode_docs(s, cur + 1);
+        } else {
+            uint32_t v = D(s)[pos];
+            if (lane_id() == 0) {
+                meta[s * M_WORDS + M_POS] = pos;
+                meta[s * M_WORDS + M_DOCID] = v;
+            }
+            wave_sync();
+        }
+    }
+
+    // ---- freq (block_posting_list.hpp:165-171)
+    DS2I_DEV uint32_t freq(uint32_t s) {
+        if (!m(s, M_FDEC)) decode_freqs(s);
+        return uniform(F(s)[m(s, M_POS)]);
+    }
+};
+
+// bm25::doc_term_weight (bm25.hpp:11-15). Compiled with -ffp-contract=off so the
+// float32 operation order matches the reference exactly.
+DS2I_DEV float doc_term_weight(uint32_t freq, float norm_len) {
+    const float b = 0.5f, k1 = 1.2f;
+    float f = (float)freq;
+    return f / (f + k1 * (1.0f - b + b * norm_len));
+}
+
+// ---- top-k scores (topk_queue, queries.hpp:152-197), k <= 64: lane j keeps the j-th
+// largest score. insert() enters iff size<k or score > min (strict), like the reference.
+struct TopK {
+    float v;      // per lane
+    uint32_t n;   // uniform
+    uint32_t k;
+    DS2I_DEV void init(uint32_t k_) { v = -__builtin_inff(); n = 0; k = k_; }
+    DS2I_DEV float threshold() const { return __uint_as_float(bcast(__float_as_uint(v), k - 1)); }
+    DS2I_DEV bool would_enter(float s) const { return n < k || s > threshold(); }
+    DS2I_DEV bool insert(float s) { // s wave-uniform
+        if (!would_enter(s)) return false;
+        const uint32_t lane = lane_id();
+        uint64_t ge = ballot(lane < n && v >= s);
+        uint32_t p = (uint32_t)__builtin_popcountll(ge);
+        float up = __shfl_up(v, 1);
+        v = (lane < p) ? v : (lane == p) ? s : up;
+        if (n < k) ++n;
+        if (lane >= k) v = -__builtin_inff();
+        return true;
+    }
+};
+
+} // namespace ds2i_dev

@@ -1,0 +1,286 @@
+// Host-side (CPU, build-time) index construction and image parsing.
+//   block_posting_list::write      reference block_posting_list.hpp:13-53
+//   compact_elias_fano::write      reference compact_elias_fano.hpp:69-136 (offsets 14-61)
+//   block_freq_index builder/map   reference block_freq_index.hpp:18-70,124-134
+//   wand_data                      reference wand_data.hpp:17-83
+//   global_parameters              reference global_parameters.hpp:5-31
+// The frozen image layout follows succinct::mapper::freeze as restated in SURVEY.md
+// Appendix B (succinct is an empty submodule in /root/reference -> "parity unpinned").
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_bits.hpp"
+#include "host_encode.hpp"
+
+namespace ds2i_host {
+
+struct global_parameters {
+    uint8_t ef_log_sampling0 = 9, ef_log_sampling1 = 8, rb_log_rank1_sampling = 9, rb_log_sampling1 = 8,
+            log_partition_size = 7;
+};
+
+// ------------------------------------------------------------ posting list (A2)
+// vbyte(n) | u32 block_max[nb] | u32 block_endpoint[nb-1] | block0 docs | block0 freqs | ...
+inline void write_posting_list(int codec, bytes_t& out, uint32_t n, const uint32_t* docs, const uint32_t* freqs) {
+    vbyte_encode(n, out);
+    const uint64_t blocks = ceil_div((uint64_t)n, (uint64_t)BLOCK);
+    const size_t begin_maxs = out.size();
+    const size_t begin_endpoints = begin_maxs + 4 * blocks;
+    const size_t begin_blocks = begin_endpoints + 4 * (blocks - 1);
+    out.resize(begin_blocks);
+    uint32_t dbuf[BLOCK], fbuf[BLOCK];
+    uint32_t last_doc = uint32_t(-1), block_base = 0;
+    size_t k = 0;
+    for (uint64_t b = 0; b < blocks; ++b) {
+        uint32_t cur = ((b + 1) * BLOCK <= n) ? BLOCK : (n % BLOCK);
+        for (uint32_t i = 0; i < cur; ++i, ++k) {
+            dbuf[i] = docs[k] - last_doc - 1;
+            last_doc = docs[k];
+            fbuf[i] = freqs[k] - 1;
+        }
+        std::memcpy(&out[begin_maxs + 4 * b], &last_doc, 4);
+        block_encode(codec, dbuf, last_doc - block_base - (cur - 1), cur, out);
+        block_encode(codec, fbuf, uint32_t(-1), cur, out);
+        if (b != blocks - 1) {
+            uint32_t ep = (uint32_t)(out.size() - begin_blocks);
+            std::memcpy(&out[begin_endpoints + 4 * b], &ep, 4);
+        }
+        block_base = last_doc + 1;
+    }
+}
+
+// ------------------------------------------------------------ Elias-Fano (a13)
+struct ef_offsets {
+    uint64_t universe, n, log_sampling0, log_sampling1, lower_bits, mask, higher_bits_length, pointer_size,
+        pointers0, pointers1, pointers0_offset, pointers1_offset, higher_bits_offset, lower_bits_offset, end;
+    ef_offsets(uint64_t base, uint64_t u, uint64_t n_, global_parameters const& p)
+        : universe(u), n(n_), log_sampling0(p.ef_log_sampling0), log_sampling1(p.ef_log_sampling1) {
+        lower_bits = u > n ? msb64(u / n) : 0;
+        mask = (uint64_t(1) << lower_bits) - 1;
+        higher_bits_length = n + (u >> lower_bits) + 2;
+        pointer_size = ceil_log2(higher_bits_length);
+        pointers0 = (higher_bits_length - n) >> log_sampling0;
+        pointers1 = n >> log_sampling1;
+        pointers0_offset = base;
+        pointers1_offset = pointers0_offset + pointers0 * pointer_size;
+        higher_bits_offset = pointers1_offset + pointers1 * pointer_size;
+        lower_bits_offset = higher_bits_offset + higher_bits_length;
+        end = lower_bits_offset + n * lower_bits;
+    }
+};
+
+template <class It>
+inline void ef_write(bitvec_builder& bvb, It begin, uint64_t universe, uint64_t n, global_parameters const& params) {
+    const uint64_t base = bvb.size();
+    ef_offsets of(base, universe, n, params);
+    bvb.zero_extend(of.end - base);
+    const uint64_t sample1_mask = (uint64_t(1) << of.log_sampling1) - 1;
+    auto set_ptr0s = [&](uint64_t b, uint64_t e, uint64_t rank_end) {
+        uint64_t bz = b - rank_end, ez = e - rank_end;
+        for (uint64_t p0 = ceil_div(bz, uint64_t(1) << of.log_sampling0); (p0 << of.log_sampling0) < ez; ++p0) {
+            if (!p0) continue;
+            bvb.set_bits(of.pointers0_offset + (p0 - 1) * of.pointer_size, (p0 << of.log_sampling0) + rank_end,
+                         (unsigned)of.pointer_size);
+        }
+    };
+    uint64_t last = 0, last_high = 0;
+    It it = begin;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t v = *it++;
+        if (i && v < last) throw std::runtime_error("Sequence is not sorted");
+        uint64_t high = (v >> of.lower_bits) + i + 1;
+        bvb.set(of.higher_bits_offset + high, 1);
+        bvb.set_bits(of.lower_bits_offset + i * of.lower_bits, v & of.mask, (unsigned)of.lower_bits);
+        if (i && (i & sample1_mask) == 0)
+            bvb.set_bits(of.pointers1_offset + ((i >> of.log_sampling1) - 1) * of.pointer_size, high,
+                         (unsigned)of.pointer_size);
+        set_ptr0s(last_high + 1, high, i);
+        last_high = high;
+        last = v;
+    }
+    set_ptr0s(last_high + 1, of.higher_bits_length, n);
+}
+
+// sequential decode of all n values (upload-time flattening of m_endpoints, a12)
+inline void ef_decode_all(bitview const& bv, uint64_t base, uint64_t universe, uint64_t n,
+                          global_parameters const& params, std::vector<uint64_t>& out) {
+    ef_offsets of(base, universe, n, params);
+    if (of.end > bv.nbits) throw std::runtime_error("EF sequence exceeds bit vector");
+    out.resize(n);
+    uint64_t hp = of.higher_bits_offset;
+    for (uint64_t i = 0; i < n; ++i) {
+        while (!bv.get(hp)) {
+            ++hp;
+            if (hp >= of.lower_bits_offset) throw std::runtime_error("EF high bits truncated");
+        }
+        uint64_t high = hp - of.higher_bits_offset;
+        ++hp;
+        uint64_t low = bv.get_bits(of.lower_bits_offset + i * of.lower_bits, (unsigned)of.lower_bits);
+        out[i] = ((high - i - 1) << of.lower_bits) | low;
+    }
+}
+
+// ------------------------------------------------------------ freeze helpers
+template <class T> inline void put_pod(bytes_t& out, T v) {
+    const uint8_t* p = (const uint8_t*)&v;
+    out.insert(out.end(), p, p + sizeof(T));
+}
+struct reader {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    reader(const void* d, size_t len) : p((const uint8_t*)d), n(len) {}
+    template <class T> T pod() {
+        if (pos + sizeof(T) > n) throw std::runtime_error("image truncated");
+        T v;
+        std::memcpy(&v, p + pos, sizeof(T));
+        pos += sizeof(T);
+        return v;
+    }
+    const uint8_t* take(size_t len) {
+        if (len > n - pos) throw std::runtime_error("image truncated");
+        const uint8_t* r = p + pos;
+        pos += len;
+        return r;
+    }
+};
+
+// ------------------------------------------------------------ block_freq_index
+class block_index_builder {
+public:
+    block_index_builder(int codec, uint64_t num_docs, global_parameters const& params = global_parameters())
+        : m_codec(codec), m_num_docs(num_docs), m_params(params) {
+        m_endpoints.push_back(0);
+    }
+    void add_posting_list(uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
+        if (!n) throw std::invalid_argument("List must be nonempty");
+        write_posting_list(m_codec, m_lists, (uint32_t)n, docs, freqs);
+        m_endpoints.push_back(m_lists.size());
+    }
+    void add_encoded_list(const uint8_t* data, size_t len) {
+        m_lists.insert(m_lists.end(), data, data + len);
+        m_endpoints.push_back(m_lists.size());
+    }
+    uint64_t lists() const { return m_endpoints.size() - 1; }
+    // image = 5 B params | u64 m_size | u64 m_num_docs | bit_vector{u64 bits; u64 nwords; words} | u64 nbytes; bytes
+    void freeze(bytes_t& out) const {
+        const uint64_t size = m_endpoints.size() - 1;
+        bitvec_builder bvb;
+        if (size) ef_write(bvb, m_endpoints.begin(), m_lists.size(), size, m_params);
+        out.push_back(m_params.ef_log_sampling0);
+        out.push_back(m_params.ef_log_sampling1);
+        out.push_back(m_params.rb_log_rank1_sampling);
+        out.push_back(m_params.rb_log_sampling1);
+        out.push_back(m_params.log_partition_size);
+        put_pod<uint64_t>(out, size);
+        put_pod<uint64_t>(out, m_num_docs);
+        put_pod<uint64_t>(out, bvb.size());
+        put_pod<uint64_t>(out, bvb.words().size());
+        const uint8_t* w = (const uint8_t*)bvb.words().data();
+        out.insert(out.end(), w, w + 8 * bvb.words().size());
+        put_pod<uint64_t>(out, m_lists.size());
+        out.insert(out.end(), m_lists.begin(), m_lists.end());
+    }
+
+private:
+    int m_codec;
+    uint64_t m_num_docs;
+    global_parameters m_params;
+    std::vector<uint64_t> m_endpoints;
+    bytes_t m_lists;
+};
+
+// Parsed (zero-copy) view of a frozen block_freq_index image.
+struct block_index_view {
+    global_parameters params;
+    uint64_t size = 0, num_docs = 0;
+    bitview endpoints_bv;
+    const uint8_t* lists = nullptr;
+    uint64_t lists_bytes = 0;
+    std::vector<uint64_t> list_offsets; // size+1 entries (flattened m_endpoints)
+
+    void parse(const void* image, size_t bytes) {
+        reader r(image, bytes);
+        params.ef_log_sampling0 = r.pod<uint8_t>();
+        params.ef_log_sampling1 = r.pod<uint8_t>();
+        params.rb_log_rank1_sampling = r.pod<uint8_t>();
+        params.rb_log_sampling1 = r.pod<uint8_t>();
+        params.log_partition_size = r.pod<uint8_t>();
+        size = r.pod<uint64_t>();
+        num_docs = r.pod<uint64_t>();
+        endpoints_bv.nbits = r.pod<uint64_t>();
+        uint64_t nwords = r.pod<uint64_t>();
+        if (nwords != ceil_div(endpoints_bv.nbits, (uint64_t)64)) throw std::runtime_error("bad endpoints bit vector");
+        endpoints_bv.nbytes = 8 * nwords;
+        endpoints_bv.bytes = r.take(8 * nwords);
+        lists_bytes = r.pod<uint64_t>();
+        lists = r.take(lists_bytes);
+        if (num_docs > 0xFFFFFFFFull) throw std::runtime_error("num_docs exceeds 32 bits");
+        if (size) ef_decode_all(endpoints_bv, 0, lists_bytes, size, params, list_offsets);
+        list_offsets.push_back(lists_bytes);
+        for (uint64_t i = 0; i + 1 < list_offsets.size(); ++i)
+            if (list_offsets[i] >= list_offsets[i + 1]) throw std::runtime_error("list endpoints not increasing");
+    }
+};
+
+// ------------------------------------------------------------ BM25 + wand_data
+// reference bm25.hpp:7-25 -- float32 throughout, no contraction.
+struct bm25 {
+    static float doc_term_weight(uint64_t freq, float norm_len) {
+        const float b = 0.5f, k1 = 1.2f;
+        float f = (float)freq;
+        return f / (f + k1 * (1.0f - b + b * norm_len));
+    }
+    static float query_term_weight(uint64_t freq, uint64_t df, uint64_t num_docs) {
+        const float k1 = 1.2f;
+        float f = (float)freq;
+        float fdf = (float)df;
+        float idf = std::log((float(num_docs) - fdf + 0.5f) / (fdf + 0.5f));
+        static const float epsilon_score = 1.0E-6f;
+        return f * std::max(epsilon_score, idf) * (1.0f + k1);
+    }
+};
+
+// wand image = u64 N | float norm_lens[N] | u64 V | float max_term_weight[V]
+inline void compute_norm_lens(const uint32_t* sizes, uint64_t num_docs, std::vector<float>& norm_lens) {
+    norm_lens.resize(num_docs);
+    double sum = 0;
+    for (uint64_t i = 0; i < num_docs; ++i) {
+        float len = (float)sizes[i];
+        norm_lens[i] = len;
+        sum += len;
+    }
+    float avg = float(sum / double(num_docs));
+    for (uint64_t i = 0; i < num_docs; ++i) norm_lens[i] /= avg;
+}
+inline float list_max_weight(const float* norm_lens, uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
+    float mx = 0;
+    for (uint64_t i = 0; i < n; ++i) mx = std::max(mx, bm25::doc_term_weight(freqs[i], norm_lens[docs[i]]));
+    return mx;
+}
+inline void wand_freeze(std::vector<float> const& norm_lens, std::vector<float> const& max_w, bytes_t& out) {
+    put_pod<uint64_t>(out, norm_lens.size());
+    const uint8_t* p = (const uint8_t*)norm_lens.data();
+    out.insert(out.end(), p, p + 4 * norm_lens.size());
+    put_pod<uint64_t>(out, max_w.size());
+    p = (const uint8_t*)max_w.data();
+    out.insert(out.end(), p, p + 4 * max_w.size());
+}
+struct wand_view {
+    uint64_t num_docs = 0, num_terms = 0;
+    const uint8_t* norm_lens = nullptr;       // float[num_docs], unaligned
+    const uint8_t* max_term_weight = nullptr; // float[num_terms], unaligned
+    void parse(const void* image, size_t bytes) {
+        reader r(image, bytes);
+        num_docs = r.pod<uint64_t>();
+        norm_lens = r.take(4 * num_docs);
+        num_terms = r.pod<uint64_t>();
+        max_term_weight = r.take(4 * num_terms);
+    }
+};
+
+} // namespace ds2i_host

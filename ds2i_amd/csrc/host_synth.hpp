@@ -1,0 +1,128 @@
+// Deterministic synthetic collection + query generator (SURVEY.md §8(d) "Concrete
+// synthetic inputs"). Host-side product utility: bench.py, tests and the CLI build
+// their indexes from it. Every list is generated from (seed, term) alone, so the
+// collection never has to be materialised (GOV2-scale = ~1 B postings) and the test
+// oracle can regenerate any list independently.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace ds2i_host {
+
+struct synth_params {
+    uint64_t seed;
+    uint32_t num_docs;
+    uint32_t num_terms;
+    double zipf_exp;       // list length of rank r = max(min_len, top_df_frac*N * r^-zipf_exp)
+    double top_df_frac;
+    uint32_t min_len;
+    uint32_t clustered_every; // every k-th list alternates 8x / (1/8)x density segments; 0 = never
+};
+
+struct xoshiro256ss {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t& x) {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit xoshiro256ss(uint64_t seed) { for (auto& v : s) v = splitmix(seed); }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    // uniform in (0,1]
+    double unit() { return double((next() >> 11) + 1) * (1.0 / 9007199254740992.0); }
+};
+
+inline uint64_t synth_target_len(synth_params const& p, uint32_t term) {
+    double v = p.top_df_frac * double(p.num_docs) * std::pow(double(term) + 1.0, -p.zipf_exp);
+    uint64_t n = v < 1.0 ? 1 : (uint64_t)v;
+    n = std::max<uint64_t>(n, p.min_len);
+    return std::min<uint64_t>(n, p.num_docs);
+}
+
+// Generates list `term`; returns its length (>=1). docs strictly increasing in [0,N).
+inline uint64_t synth_list(synth_params const& p, uint32_t term, std::vector<uint32_t>& docs,
+                           std::vector<uint32_t>& freqs) {
+    docs.clear();
+    freqs.clear();
+    const uint64_t N = p.num_docs;
+    const uint64_t target = synth_target_len(p, term);
+    xoshiro256ss rng(p.seed ^ (0xD6E8FEB86659FD93ull * (uint64_t(term) + 1)));
+    const double q0 = double(target) / double(N);
+    const bool clustered = p.clustered_every && (term % p.clustered_every) == p.clustered_every - 1;
+    docs.reserve(target + target / 8 + 16);
+    freqs.reserve(target + target / 8 + 16);
+    uint64_t pos = 0; // next candidate docid
+    bool dense = (rng.next() & 1) != 0;
+    while (pos < N) {
+        uint64_t seg_end = N;
+        double q = q0;
+        if (clustered) {
+            uint64_t seg = uint64_t(1) << (12 + (rng.next() % 5));
+            seg_end = std::min<uint64_t>(N, pos + seg);
+            q = dense ? std::min(0.95, q0 * 8.0) : q0 / 8.0;
+            dense = !dense;
+        }
+        if (q >= 1.0) q = 0.999999;
+        const double inv = 1.0 / std::log1p(-q);
+        while (true) {
+            uint64_t skip = (uint64_t)(std::log(rng.unit()) * inv); // geometric(q) - 1
+            if (skip >= seg_end - pos) { pos = seg_end; break; }
+            pos += skip;
+            docs.push_back((uint32_t)pos);
+            uint32_t r = (uint32_t)rng.next() | 0x80000000u;
+            freqs.push_back(1u + (uint32_t)__builtin_ctz(r));
+            ++pos;
+            if (pos >= seg_end) break;
+        }
+    }
+    if (docs.empty()) {
+        docs.push_back((uint32_t)(rng.next() % N));
+        freqs.push_back(1);
+    }
+    return docs.size();
+}
+
+inline void synth_doc_sizes(synth_params const& p, std::vector<uint32_t>& sizes) {
+    sizes.resize(p.num_docs);
+    xoshiro256ss rng(p.seed ^ 0x5125CAFEull);
+    for (uint32_t d = 0; d < p.num_docs; ++d) {
+        double e = -std::log(rng.unit());
+        uint64_t s = 1 + (uint64_t)(e * 1769.0);
+        sizes[d] = (uint32_t)std::min<uint64_t>(s, 61081);
+    }
+}
+
+// Query log shaped like test/test_data/queries: length histogram of the real file,
+// term rank log-uniform in [1,V], 1% of queries repeat a term.
+inline void synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, std::vector<uint32_t>& terms,
+                          std::vector<uint32_t>& offsets) {
+    static const uint32_t hist[11] = {45, 168, 124, 74, 41, 22, 13, 9, 2, 1, 1}; // lengths 1..11, /500
+    xoshiro256ss rng(seed);
+    terms.clear();
+    offsets.assign(1, 0);
+    for (uint32_t q = 0; q < nq; ++q) {
+        uint32_t x = (uint32_t)(rng.next() % 500), len = 1, acc = 0;
+        for (uint32_t l = 0; l < 11; ++l) { acc += hist[l]; if (x < acc) { len = l + 1; break; } }
+        size_t begin = terms.size();
+        for (uint32_t i = 0; i < len; ++i) {
+            double u = rng.unit();
+            double r = std::pow(double(num_terms), 1.0 - u); // in [1,V)
+            uint32_t t = (uint32_t)r;
+            if (t < 1) t = 1;
+            if (t > num_terms) t = num_terms;
+            terms.push_back(t - 1);
+        }
+        if (len > 1 && (rng.next() % 100) == 0) terms.back() = terms[begin];
+        offsets.push_back((uint32_t)terms.size());
+    }
+}
+
+} // namespace ds2i_host

@@ -1,0 +1,519 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the ds2i batched query path.
+// One wavefront per query, persistent waves pulling query tickets; every memory
+// operation is wave-cooperative, control flow is wave-uniform. No MFMA (integer work).
+//
+//   k_conjunctive   and_query / ranked_and_query   reference queries.hpp:35-86, 322-401
+//                   block-synchronous intersection: each round intersects the window
+//                   [lo, min_i block_max_i] of all lists' current blocks at once (up to
+//                   128 candidates, two per lane) instead of one candidate per step.
+//   k_daat          or / ranked_or / wand / maxscore (+ reference-order and / ranked_and)
+//                   reference queries.hpp:88-131, 404-476, 200-319, 478-591
+//   k_decode_list   full decode of one list (Index::operator[] + enumeration)
+//   k_selftest      primitives (scan, ballot) used by the GPU unit tests
+#include <hip/hip_runtime.h>
+
+#include "device_enum.hpp"
+
+using namespace ds2i_dev;
+
+namespace {
+
+template <int TMAX>
+struct Lds {
+    uint32_t docs[TMAX][128];
+    uint32_t freqs[TMAX][128];
+    uint32_t meta[TMAX][M_WORDS];
+    uint32_t exc[EXC_DW];
+    uint32_t st[STAGE_DW];
+    uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring)
+    uint32_t ord[TMAX];     // daat: ordered_enums
+    float ub[TMAX];         // maxscore upper_bounds
+};
+
+template <int TMAX>
+DS2I_DEV Ctx make_ctx(Lds<TMAX>& L, const BatchArgs& a) {
+    Ctx c;
+    c.docs = &L.docs[0][0];
+    c.freqs = &L.freqs[0][0];
+    c.meta = &L.meta[0][0];
+    c.exc = L.exc;
+    c.win.st = L.st;
+    c.win.gbase = a.arena;
+    c.win.nbytes = 0;
+    c.arena = a.arena;
+    c.codec = a.codec;
+    c.num_docs = a.num_docs;
+    c.init_stats();
+    return c;
+}
+
+DS2I_DEV uint32_t next_ticket(unsigned int* ticket) {
+    uint32_t t = 0;
+    if (lane_id() == 0) t = atomicAdd(ticket, 1u);
+    return bcast(t, 0);
+}
+
+DS2I_DEV void store_topk(const BatchArgs& a, uint32_t q, const TopK& tk) {
+    const uint32_t lane = lane_id();
+    if (lane < a.k) a.out_topk[(size_t)q * a.k + lane] = tk.v;
+    if (lane == 0) a.out_topk_len[q] = tk.n;
+}
+
+// ------------------------------------------------------------------ conjunctive
+// Candidate membership of c (held by this lane, valid iff `want`) in the sorted LDS block d[128].
+DS2I_DEV bool member_bsearch(const uint32_t* d, uint32_t c, bool want, uint32_t& pos) {
+    uint32_t idx = 0;
+    if (want) {
+#pragma unroll
+        for (uint32_t step = 64; step; step >>= 1)
+            if (d[idx + step - 1] < c) idx += step;
+    }
+    pos = idx;
+    return want && d[idx] == c;
+}
+
+template <bool RANKED, bool WITH_FREQS, int TMAX>
+__global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
+    __shared__ Lds<TMAX> L;
+    const uint32_t lane = lane_id();
+    Ctx cx = make_ctx(L, a);
+    for (;;) {
+        const uint32_t tkt = next_ticket(a.ticket);
+        if (tkt >= a.nslice) break;
+        const uint32_t q = a.order[tkt];
+        const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
+        unsigned long long count = 0, fsum = 0;
+        TopK tk;
+        tk.init(a.k);
+        if (nt == 0 || nt > (uint32_t)TMAX) { // empty query -> 0 results (queries.hpp:41,335)
+            if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
+            if (RANKED) store_topk(a, q, tk);
+            continue;
+        }
+        for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
+        const unsigned long long mbase = a.out_matches ? a.match_off[q] : 0;
+        const unsigned long long mcap = a.out_matches ? a.match_off[q + 1] - mbase : 0;
+        const uint32_t last0 = uniform(ld32(cx.ptr(0, M_MAXS_LO) + 4ull * (cx.m(0, M_NB) - 1)));
+        uint32_t lo = 0;
+        bool finished = false;
+        while (!finished) {
+            ++cx.s_rounds;
+            // list 0 supplies the candidates of this round
+            if (lo > cx.m(0, M_BMAX)) {
+                if (lo > last0) break;
+                uint32_t cur = cx.m(0, M_CUR);
+                uint32_t blk = cx.find_block(0, cur + 1, lo);
+                cx.s_bm_examined += blk - cur;
+                cx.s_bytes += 4ull * (blk - cur);
+                cx.decode_docs(0, blk);
+            }
+            uint32_t hi = cx.m(0, M_BMAX);
+            const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
+            bool al0 = c0 >= lo && c0 != 0xFFFFFFFFu, al1 = c1 >= lo && c1 != 0xFFFFFFFFu;
+            for (uint32_t i = 1; i < nt; ++i) {
+                uint64_t b0 = ballot(al0), b1 = ballot(al1);
+                if (!(b0 | b1)) break;
+                uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
+                if (amin > cx.m(i, M_BMAX)) {
+                    uint32_t cur = cx.m(i, M_CUR);
+                    uint32_t blk = cx.find_block(i, cur + 1, amin);
+                    if (blk >= cx.m(i, M_NB)) { // list i has nothing >= amin: no further match exists
+                        cx.s_bm_examined += 1;
+                        cx.s_bytes += 4;
+                        al0 = al1 = false;
+                        finished = true;
+                        break;
+                    }
+                    cx.s_bm_examined += blk - cur;
+                    cx.s_bytes += 4ull * (blk - cur);
+                    cx.decode_docs(i, blk);
+                }
+                uint32_t bm = cx.m(i, M_BMAX);
+                hi = bm < hi ? bm : hi;
+                bool w0 = al0 && c0 <= hi, w1 = al1 && c1 <= hi;
+                const uint32_t* d = L.docs[i];
+                uint64_t wb0 = ballot(w0), wb1 = ballot(w1);
+                uint32_t nw = (uint32_t)(__builtin_popcountll(wb0) + __builtin_popcountll(wb1));
+                uint32_t p0 = 0, p1 = 0;
+                if (nw > 24) {
+                    al0 = member_bsearch(d, c0, w0, p0);
+                    al1 = member_bsearch(d, c1, w1, p1);
+                } else {
+                    // few candidates: broadcast each, two equality ballots over the block
+                    const uint32_t d0 = d[lane], d1 = d[lane + 64];
+                    uint64_t r0 = 0, r1 = 0;
+                    for (int half = 0; half < 2; ++half) {
+                        uint64_t todo = half ? wb1 : wb0;
+                        while (todo) {
+                            uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            uint32_t c = bcast(half ? c1 : c0, src);
+                            uint64_t e0 = ballot(d0 == c), e1 = ballot(d1 == c);
+                            if (e0 | e1) {
+                                uint32_t pp = e0 ? (uint32_t)__builtin_ctzll(e0) : 64u + (uint32_t)__builtin_ctzll(e1);
+                                if (half) { r1 |= 1ull << src; if (lane == src) p1 = pp; }
+                                else { r0 |= 1ull << src; if (lane == src) p0 = pp; }
+                            }
+                        }
+                    }
+                    al0 = (r0 >> lane) & 1;
+                    al1 = (r1 >> lane) & 1;
+                }
+                if (RANKED || WITH_FREQS) {
+                    if (al0) L.pos[i][lane] = (uint8_t)p0;
+                    if (al1) L.pos[i][lane + 64] = (uint8_t)p1;
+                }
+            }
+            // candidates that survived every list and lie inside the window are matches
+            al0 = al0 && c0 <= hi;
+            al1 = al1 && c1 <= hi;
+            const uint64_t s0 = ballot(al0), s1 = ballot(al1);
+            const uint32_t ns = (uint32_t)(__builtin_popcountll(s0) + __builtin_popcountll(s1));
+            if (ns) {
+                if (a.out_matches) {
+                    const uint64_t lt = (1ull << lane) - 1;
+                    unsigned long long i0 = count + __builtin_popcountll(s0 & lt);
+                    unsigned long long i1 = count + __builtin_popcountll(s0) + __builtin_popcountll(s1 & lt);
+                    if (al0 && i0 < mcap) a.out_matches[mbase + i0] = c0;
+                    if (al1 && i1 < mcap) a.out_matches[mbase + i1] = c1;
+                }
+                count += ns;
+                if (RANKED || WITH_FREQS) {
+                    wave_sync(); // L.pos writes visible
+                    float nl0 = 0.f, nl1 = 0.f, sc0 = 0.f, sc1 = 0.f;
+                    if (RANKED) {
+                        if (al0) nl0 = a.norm_lens[c0];
+                        if (al1) nl1 = a.norm_lens[c1];
+                        cx.s_bytes += 4ull * ns;
+                        cx.s_scored += ns;
+                    }
+                    uint32_t fs = 0;
+                    for (uint32_t i = 0; i < nt; ++i) {
+                        if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
+                        const uint32_t* f = L.freqs[i];
+                        uint32_t f0 = 0, f1 = 0;
+                        if (al0) f0 = f[i ? L.pos[i][lane] : lane];
+                        if (al1) f1 = f[i ? L.pos[i][lane + 64] : lane + 64];
+                        if (RANKED) {
+                            float qw = __uint_as_float(cx.m(i, M_QW));
+                            if (al0) sc0 += qw * doc_term_weight(f0, nl0);
+                            if (al1) sc1 += qw * doc_term_weight(f1, nl1);
+                        } else {
+                            fs += f0 + f1;
+                        }
+                    }
+                    if (WITH_FREQS && !RANKED) {
+                        for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                        fsum += fs;
+                    }
+                    if (RANKED) {
+                        // only scores that can enter the heap are inserted (serial, rare once warm)
+                        for (int half = 0; half < 2; ++half) {
+                            const bool al = half ? al1 : al0;
+                            const float sc = half ? sc1 : sc0;
+                            uint64_t todo = ballot(al && tk.would_enter(sc));
+                            while (todo) {
+                                uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                                todo &= todo - 1;
+                                tk.insert(__uint_as_float(bcast(__float_as_uint(sc), src)));
+                            }
+                        }
+                    }
+                }
+            }
+            if (hi == 0xFFFFFFFFu) break;
+            lo = hi + 1;
+        }
+        if (lane == 0) {
+            a.out_count[q] = RANKED ? tk.n : count;
+            if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+        }
+        if (RANKED) store_topk(a, q, tk);
+    }
+    cx.flush_stats(a.stats);
+}
+
+// ------------------------------------------------------------------ document-at-a-time
+template <int TMAX>
+DS2I_DEV float score_of(Ctx& cx, uint32_t s, float norm_len) {
+    return __uint_as_float(cx.m(s, M_QW)) * doc_term_weight(cx.freq(s), norm_len);
+}
+
+// stable insertion sort of ord[0..n) by key(slot) (== libstdc++ std::sort for n <= 16)
+template <int TMAX, class Key>
+DS2I_DEV void sort_ord(Lds<TMAX>& L, uint32_t n, Key key) {
+    if (lane_id() == 0) {
+        for (uint32_t i = 1; i < n; ++i) {
+            uint32_t v = L.ord[i];
+            auto kv = key(v);
+            uint32_t j = i;
+            while (j > 0 && kv < key(L.ord[j - 1])) { L.ord[j] = L.ord[j - 1]; --j; }
+            L.ord[j] = v;
+        }
+    }
+    wave_sync();
+}
+
+template <int OP, int TMAX>
+__global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
+    __shared__ Lds<TMAX> L;
+    const uint32_t lane = lane_id();
+    Ctx cx = make_ctx(L, a);
+    const uint32_t N = a.num_docs;
+    constexpr bool RANKED = OP >= OP_RANKED_AND;
+    for (;;) {
+        const uint32_t tkt = next_ticket(a.ticket);
+        if (tkt >= a.nslice) break;
+        const uint32_t q = a.order[tkt];
+        const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
+        unsigned long long count = 0, fsum = 0;
+        TopK tk;
+        tk.init(a.k);
+        if (nt == 0 || nt > (uint32_t)TMAX) {
+            if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
+            if (RANKED) store_topk(a, q, tk);
+            continue;
+        }
+        for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
+        auto norm_len = [&](uint32_t d) {
+            cx.s_bytes += 4;
+            ++cx.s_scored;
+            return __uint_as_float(uniform(__float_as_uint(a.norm_lens[d])));
+        };
+
+        if (OP == OP_AND || OP == OP_AND_FREQ || OP == OP_RANKED_AND) {
+            // reference traversal, one candidate at a time (queries.hpp:58-84 / 362-387)
+            const unsigned long long mbase = a.out_matches ? a.match_off[q] : 0;
+            const unsigned long long mcap = a.out_matches ? a.match_off[q + 1] - mbase : 0;
+            uint32_t cand = cx.docid(0);
+            uint32_t i = 1;
+            while (cand < N) {
+                for (; i < nt; ++i) {
+                    cx.next_geq(i, cand);
+                    uint32_t d = cx.docid(i);
+                    if (d != cand) { cand = d; i = 0; break; }
+                }
+                if (i == nt) {
+                    if (OP == OP_RANKED_AND) {
+                        float nl = norm_len(cand), score = 0.f;
+                        for (i = 0; i < nt; ++i) score += score_of<TMAX>(cx, i, nl);
+                        tk.insert(score);
+                    } else {
+                        if (a.out_matches && lane == 0 && count < mcap) a.out_matches[mbase + count] = cand;
+                        ++count;
+                        if (OP == OP_AND_FREQ) for (i = 0; i < nt; ++i) fsum += cx.freq(i);
+                    }
+                    cx.next(0);
+                    cand = cx.docid(0);
+                    i = 1;
+                }
+            }
+        } else if (OP == OP_OR || OP == OP_OR_FREQ || OP == OP_RANKED_OR) {
+            // queries.hpp:105-127 / 438-462
+            uint32_t cur = N;
+            for (uint32_t i = 0; i < nt; ++i) { uint32_t d = cx.docid(i); cur = d < cur ? d : cur; }
+            while (cur < N) {
+                float score = 0.f, nl = 0.f;
+                if (OP == OP_RANKED_OR) nl = norm_len(cur);
+                uint32_t nxt = N;
+                for (uint32_t i = 0; i < nt; ++i) {
+                    if (cx.docid(i) == cur) {
+                        if (OP == OP_RANKED_OR) score += score_of<TMAX>(cx, i, nl);
+                        if (OP == OP_OR_FREQ) fsum += cx.freq(i);
+                        cx.next(i);
+                    }
+                    uint32_t d = cx.docid(i);
+                    nxt = d < nxt ? d : nxt;
+                }
+                if (OP == OP_RANKED_OR) tk.insert(score); else ++count;
+                cur = nxt;
+            }
+        } else if (OP == OP_WAND) {
+            // queries.hpp:236-305
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord[i] = i;
+            wave_sync();
+            auto by_docid = [&](uint32_t s) { return L.meta[s][M_DOCID]; };
+            sort_ord(L, nt, by_docid);
+            for (;;) {
+                float upper = 0.f;
+                uint32_t pivot = 0;
+                bool found = false;
+                for (pivot = 0; pivot < nt; ++pivot) {
+                    uint32_t s = uniform(L.ord[pivot]);
+                    if (cx.docid(s) == N) break;
+                    upper += __uint_as_float(cx.m(s, M_MAXW));
+                    if (tk.would_enter(upper)) { found = true; break; }
+                }
+                if (!found) break;
+                const uint32_t pivot_id = cx.docid(uniform(L.ord[pivot]));
+                if (pivot_id == cx.docid(uniform(L.ord[0]))) {
+                    float score = 0.f, nl = norm_len(pivot_id);
+                    for (uint32_t j = 0; j < nt; ++j) {
+                        uint32_t s = uniform(L.ord[j]);
+                        if (cx.docid(s) != pivot_id) break;
+                        score += score_of<TMAX>(cx, s, nl);
+                        cx.next(s);
+                    }
+                    tk.insert(score);
+                    sort_ord(L, nt, by_docid);
+                } else {
+                    uint32_t nl_ = pivot;
+                    while (cx.docid(uniform(L.ord[nl_])) == pivot_id) --nl_;
+                    cx.next_geq(uniform(L.ord[nl_]), pivot_id);
+                    if (lane == 0) {
+                        for (uint32_t j = nl_ + 1; j < nt; ++j) {
+                            uint32_t x = L.ord[j], y = L.ord[j - 1];
+                            if (L.meta[x][M_DOCID] < L.meta[y][M_DOCID]) { L.ord[j] = y; L.ord[j - 1] = x; }
+                            else break;
+                        }
+                    }
+                    wave_sync();
+                }
+            }
+        } else { // OP_MAXSCORE, queries.hpp:514-577
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord[i] = i;
+            wave_sync();
+            auto by_maxw = [&](uint32_t s) { return __uint_as_float(L.meta[s][M_MAXW]); };
+            sort_ord(L, nt, by_maxw);
+            if (lane == 0) {
+                float acc = 0.f;
+                for (uint32_t i = 0; i < nt; ++i) {
+                    float mw = __uint_as_float(L.meta[L.ord[i]][M_MAXW]);
+                    acc = i ? acc + mw : mw;
+                    L.ub[i] = acc;
+                }
+            }
+            wave_sync();
+            uint32_t non_ess = 0, cur = N;
+            for (uint32_t i = 0; i < nt; ++i) { uint32_t d = cx.docid(i); cur = d < cur ? d : cur; }
+            while (non_ess < nt && cur < N) {
+                float score = 0.f, nl = norm_len(cur);
+                uint32_t nxt = N;
+                for (uint32_t i = non_ess; i < nt; ++i) {
+                    uint32_t s = uniform(L.ord[i]);
+                    if (cx.docid(s) == cur) {
+                        score += score_of<TMAX>(cx, s, nl);
+                        cx.next(s);
+                    }
+                    uint32_t d = cx.docid(s);
+                    nxt = d < nxt ? d : nxt;
+                }
+                for (uint32_t i = non_ess; i-- > 0;) {
+                    float ub = __uint_as_float(uniform(__float_as_uint(L.ub[i])));
+                    if (!tk.would_enter(score + ub)) break;
+                    uint32_t s = uniform(L.ord[i]);
+                    cx.next_geq(s, cur);
+                    if (cx.docid(s) == cur) score += score_of<TMAX>(cx, s, nl);
+                }
+                if (tk.insert(score)) {
+                    while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub[non_ess])))))
+                        ++non_ess;
+                }
+                cur = nxt;
+            }
+        }
+        if (lane == 0) {
+            a.out_count[q] = RANKED ? tk.n : count;
+            if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+        }
+        if (RANKED) store_topk(a, q, tk);
+    }
+    cx.flush_stats(a.stats);
+}
+
+// ------------------------------------------------------------------ list decode
+// One wave per 128-posting block of ONE list; writes absolute doc-ids and freqs.
+__global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
+    __shared__ Lds<1> L;
+    BatchArgs ba{};
+    ba.arena = a.arena;
+    ba.codec = a.codec;
+    ba.num_docs = a.num_docs;
+    Ctx cx = make_ctx(L, ba);
+    const uint32_t lane = lane_id();
+    const uint32_t n = a.term.n, nb = (n + 127u) >> 7;
+    const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
+    const uint64_t maxs = a.term.list_off + vl;
+    if (lane == 0) {
+        L.meta[0][M_MAXS_LO] = (uint32_t)maxs;
+        L.meta[0][M_MAXS_HI] = (uint32_t)(maxs >> 32);
+        L.meta[0][M_N] = n;
+        L.meta[0][M_NB] = nb;
+        L.meta[0][M_END_LO] = (uint32_t)a.term.list_end;
+        L.meta[0][M_END_HI] = (uint32_t)(a.term.list_end >> 32);
+    }
+    wave_sync();
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        cx.decode_docs(0, b);
+        cx.decode_freqs(0);
+        const uint32_t sz = cx.m(0, M_SIZE);
+        for (uint32_t i = lane; i < sz; i += 64) {
+            a.out_docs[(size_t)b * 128 + i] = L.docs[0][i];
+            a.out_freqs[(size_t)b * 128 + i] = L.freqs[0][i];
+        }
+        wave_sync();
+    }
+    cx.flush_stats(a.stats);
+}
+
+// ------------------------------------------------------------------ primitive self-test
+__global__ void __launch_bounds__(64) k_selftest(const uint32_t* in, uint32_t* out) {
+    const uint32_t lane = lane_id();
+    uint32_t x = in[blockIdx.x * 64 + lane];
+    out[blockIdx.x * 64 + lane] = wave_incl_scan(x);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ launchers (called from capi.cpp)
+namespace ds2i_launch {
+
+struct Batch {
+    BatchArgs a;
+};
+
+template <int TMAX>
+static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
+    dim3 g(grid), b(64);
+    switch (op) {
+    case OP_AND: hipLaunchKernelGGL((k_conjunctive<false, false, TMAX>), g, b, 0, s, a); break;
+    case OP_AND_FREQ: hipLaunchKernelGGL((k_conjunctive<false, true, TMAX>), g, b, 0, s, a); break;
+    case OP_RANKED_AND: hipLaunchKernelGGL((k_conjunctive<true, true, TMAX>), g, b, 0, s, a); break;
+    case OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
+    case OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
+    case OP_WAND: hipLaunchKernelGGL((k_daat<OP_WAND, TMAX>), g, b, 0, s, a); break;
+    case OP_MAXSCORE: hipLaunchKernelGGL((k_daat<OP_MAXSCORE, TMAX>), g, b, 0, s, a); break;
+    case OP_RANKED_OR: hipLaunchKernelGGL((k_daat<OP_RANKED_OR, TMAX>), g, b, 0, s, a); break;
+    // reference-order (one candidate per step) conjunctive traversal: op | OP_REFERENCE_ORDER
+    case 0x100 | OP_AND: hipLaunchKernelGGL((k_daat<OP_AND, TMAX>), g, b, 0, s, a); break;
+    case 0x100 | OP_AND_FREQ: hipLaunchKernelGGL((k_daat<OP_AND_FREQ, TMAX>), g, b, 0, s, a); break;
+    case 0x100 | OP_RANKED_AND: hipLaunchKernelGGL((k_daat<OP_RANKED_AND, TMAX>), g, b, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace ds2i_launch
+
+extern "C" {
+
+// tmax_class: 0 -> TMAX 4, 1 -> TMAX 16
+hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s) {
+    const BatchArgs& a = *(const BatchArgs*)args;
+    return tmax_class == 0 ? ds2i_launch::launch_t<4>(op, a, grid, s) : ds2i_launch::launch_t<16>(op, a, grid, s);
+}
+
+hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s) {
+    const DecodeArgs& a = *(const DecodeArgs*)args;
+    hipLaunchKernelGGL(k_decode_list, dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(64), 0, s, in, out);
+    return hipGetLastError();
+}
+
+size_t ds2i_sizeof_batch_args() { return sizeof(BatchArgs); }
+size_t ds2i_sizeof_decode_args() { return sizeof(DecodeArgs); }
+}

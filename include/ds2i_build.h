@@ -1,0 +1,69 @@
+/* ds2i_build.h -- host-side (CPU) index construction entry points of libds2i_hip.so.
+ *
+ * These replace the build-side tools the benchmark loop needs because the reference cannot be
+ * compiled here (create_freq_index.cpp:45-110, create_wand_data.cpp:8-29,
+ * block_freq_index::builder block_freq_index.hpp:18-70). They produce the reference's on-disk
+ * images (block_freq_index / wand_data) that ds2i_hip_index_open consumes. Nothing here is on
+ * the timed query path and nothing here touches the GPU.
+ */
+#ifndef DS2I_BUILD_H
+#define DS2I_BUILD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ds2i_builder ds2i_builder;
+typedef struct ds2i_blob ds2i_blob; /* owned byte buffer returned by the builders */
+
+/* Synthetic Zipf collection; every list is a pure function of (seed, term). */
+typedef struct ds2i_synth_params {
+    uint64_t seed;
+    uint32_t num_docs;
+    uint32_t num_terms;
+    double zipf_exp;          /* list length(rank r) = max(min_len, top_df_frac*N*r^-zipf_exp) */
+    double top_df_frac;
+    uint32_t min_len;
+    uint32_t clustered_every; /* every k-th list alternates dense/sparse segments; 0 = never */
+} ds2i_synth_params;
+
+const uint8_t* ds2i_blob_data(const ds2i_blob* b);
+size_t ds2i_blob_size(const ds2i_blob* b);
+void ds2i_blob_free(ds2i_blob* b);
+
+/* block_freq_index<Codec>::builder (block_freq_index.hpp:18-70); codec = enum ds2i_hip_index_kind */
+int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out);
+int ds2i_builder_add_posting_list(ds2i_builder* b, uint64_t n, const uint32_t* docs, const uint32_t* freqs);
+int ds2i_builder_freeze(ds2i_builder* b, ds2i_blob** image); /* succinct::mapper::freeze image */
+void ds2i_builder_free(ds2i_builder* b);
+
+/* wand_data<bm25> (wand_data.hpp:20-52): sizes = doc lengths; lists are streamed in term order */
+typedef struct ds2i_wand_builder ds2i_wand_builder;
+int ds2i_wand_create(const uint32_t* doc_sizes, uint64_t num_docs, ds2i_wand_builder** out);
+int ds2i_wand_add_list(ds2i_wand_builder* w, uint64_t n, const uint32_t* docs, const uint32_t* freqs);
+int ds2i_wand_freeze(ds2i_wand_builder* w, ds2i_blob** image);
+void ds2i_wand_free(ds2i_wand_builder* w);
+
+/* single block encoders (test hooks for the codec round trips of test_block_codecs.cpp:9-46).
+ * sum_of_values == 0xFFFFFFFF means "unknown" like the reference. Returns a blob. */
+int ds2i_encode_block(int codec, const uint32_t* values, uint32_t sum_of_values, uint32_t n, ds2i_blob** out);
+int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out);
+int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const uint32_t* freqs, ds2i_blob** out);
+
+/* synthetic collection */
+uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term);
+int ds2i_synth_list(const ds2i_synth_params* p, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,
+                    uint64_t* n);
+int ds2i_synth_doc_sizes(const ds2i_synth_params* p, uint32_t* sizes);
+/* query log: terms gets at most 11*nq entries, offsets nq+1 */
+int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t* terms, uint32_t* offsets);
+/* generate + encode the whole collection with `threads` host threads: index image + wand image */
+int ds2i_synth_build(const ds2i_synth_params* p, int codec, int threads, ds2i_blob** index_image,
+                     ds2i_blob** wand_image, uint64_t* total_postings);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+/* ds2i_hip.h -- C ABI of libds2i_hip.so: the MI355X-native batched query path for ds2i indexes.
+ *
+ * ds2i has no FFI; its extension points are two C++ template concepts:
+ *   Index concept     size(), num_docs(), operator[](term) -> document_enumerator
+ *                     (reference block_freq_index.hpp:72-94, block_posting_list.hpp:84-186)
+ *   Query-op concept  uint64_t operator()(Index const&, term_id_vec) [+ topk()]
+ *                     (reference queries.hpp:35-591, driven by queries.cpp:13-62)
+ * This header is what a binding for those two concepts would call. The index image and the
+ * wand image are the reference's own on-disk files, unchanged (block_freq_index.hpp:124-134,
+ * wand_data.hpp:71-78). Everything is plain C: no exceptions cross the boundary; every
+ * function returns 0 on success or a negative DS2I_E* code, ds2i_hip_last_error() explains.
+ * A handle is bound to one device and is not re-entrant; distinct handles may be used
+ * concurrently from distinct host threads (index immutable, like profile_queries.cpp:25-37).
+ */
+#ifndef DS2I_HIP_H
+#define DS2I_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* index kinds == reference index_types.hpp:35-39 (DS2I_BLOCK_INDEX_TYPES) */
+enum ds2i_hip_index_kind {
+    DS2I_BLOCK_OPTPFOR = 0,
+    DS2I_BLOCK_VARINT = 1,
+    DS2I_BLOCK_INTERPOLATIVE = 2,
+    DS2I_BLOCK_QMX = 3,
+    DS2I_BLOCK_MIXED = 4
+};
+
+/* query operators == the strings queries.cpp:104-117 dispatches on (+ ranked_or, queries.hpp:404) */
+enum ds2i_hip_op {
+    DS2I_OP_AND = 0,        /* and_query<false>   queries.hpp:35-86   */
+    DS2I_OP_AND_FREQ = 1,   /* and_query<true>                        */
+    DS2I_OP_OR = 2,         /* or_query<false>    queries.hpp:88-131  */
+    DS2I_OP_OR_FREQ = 3,    /* or_query<true>                         */
+    DS2I_OP_RANKED_AND = 4, /* ranked_and_query   queries.hpp:322-401 */
+    DS2I_OP_WAND = 5,       /* wand_query         queries.hpp:200-319 */
+    DS2I_OP_MAXSCORE = 6,   /* maxscore_query     queries.hpp:478-591 */
+    DS2I_OP_RANKED_OR = 7,  /* ranked_or_query    queries.hpp:404-476 */
+    /* OR this flag into and / and_freq / ranked_and to run the reference's one-candidate-per-step
+       traversal on the GPU instead of the block-synchronous kernel (same results; used to
+       cross-check and to count the reference traversal's algorithmic bytes on the device). */
+    DS2I_OP_REFERENCE_ORDER = 0x100
+};
+
+enum ds2i_hip_error {
+    DS2I_OK = 0,
+    DS2I_EINVAL = -1,   /* bad argument (null pointer, unknown kind/op, k out of range) */
+    DS2I_EFORMAT = -2,  /* index / wand image failed validation */
+    DS2I_ETERM = -3,    /* term id >= index size (UB + assert in the reference, block_freq_index.hpp:87) */
+    DS2I_EDEVICE = -4,  /* HIP runtime error or no usable device */
+    DS2I_ENOWAND = -5,  /* ranked operator without wand data (queries.cpp:108-116 logs "Unsupported") */
+    DS2I_ETOOLONG = -6, /* query has more than DS2I_HIP_MAX_TERMS distinct terms */
+    DS2I_ENOMEM = -7
+};
+
+#define DS2I_HIP_MAX_TERMS 16 /* distinct terms per query held in LDS by one wavefront */
+#define DS2I_HIP_MAX_K 64     /* top-k kept one score per lane */
+
+typedef struct ds2i_hip_index ds2i_hip_index;
+typedef struct ds2i_hip_batch ds2i_hip_batch;
+
+/* Device-side counters of one batch run; the byte pricing is SURVEY.md §8(d)'s A_skip. */
+typedef struct ds2i_hip_stats {
+    double kernel_ms;             /* hipEvent time of the kernels of the last run */
+    uint64_t docs_blocks_decoded; /* block_profiler counter [2b]   (block_posting_list.hpp:316-318) */
+    uint64_t freqs_blocks_decoded;/* block_profiler counter [2b+1] (block_posting_list.hpp:328-330) */
+    uint64_t block_max_examined;
+    uint64_t algorithmic_bytes;
+    uint64_t postings_scored;
+    uint64_t rounds;              /* block-synchronous rounds (conjunctive kernel) */
+} ds2i_hip_stats;
+
+int ds2i_hip_device_count(void);
+const char* ds2i_hip_last_error(void);
+
+/* Copies the index (and optional wand data) to the device's HBM. The images are not referenced
+ * after the call returns. Replaces succinct::mapper::map of queries.cpp:76-77,90-95. */
+int ds2i_hip_index_open(int device, int index_kind, const void* index_image, size_t index_bytes,
+                        const void* wand_image, size_t wand_bytes, ds2i_hip_index** out);
+void ds2i_hip_index_close(ds2i_hip_index* idx);
+
+/* Index concept: size() = number of posting lists, num_docs() (block_freq_index.hpp:72-80) */
+uint64_t ds2i_hip_index_size(const ds2i_hip_index* idx);
+uint64_t ds2i_hip_index_num_docs(const ds2i_hip_index* idx);
+uint64_t ds2i_hip_index_device_bytes(const ds2i_hip_index* idx);
+/* document_enumerator::size() of index[term] (block_posting_list.hpp:178-181) */
+int ds2i_hip_list_size(const ds2i_hip_index* idx, uint32_t term, uint64_t* n);
+/* index[term] followed by a full enumeration docid()/freq()/next(): decodes every block of the
+ * list on the GPU. docs/freqs hold `capacity` entries; *n receives the list length. */
+int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,
+                         uint64_t* n);
+
+/* One-shot batched query operator: for each query q (terms[query_offsets[q] .. query_offsets[q+1]))
+ *   out_count[q]    the operator's return value (matches for and/or, top-k size for ranked ops)
+ *   out_topk        nq*k floats, each query's scores descending, padded with -inf (may be NULL for and/or)
+ *   out_topk_len    nq (may be NULL)
+ * Host terms -> HBM, kernels, results -> host. stats may be NULL. */
+int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                         const uint32_t* query_offsets, uint32_t nq, uint64_t* out_count, float* out_topk,
+                         uint32_t* out_topk_len, ds2i_hip_stats* stats);
+
+/* Split form: prepare() does query normalisation (query_freqs / remove_duplicate_terms,
+ * queries.hpp:29-33,136-150), BM25 query weights, list-length ordering and uploads everything;
+ * run() only launches kernels on data already resident in HBM (this is what bench.py times);
+ * fetch() copies results back. want_matches != 0 additionally collects the doc-id lists of `and`. */
+int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                           const uint32_t* query_offsets, uint32_t nq, int want_matches, ds2i_hip_batch** out);
+int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats);
+/* per kernel class of the last run (class 0: <=4 distinct terms, class 1: 5..16 -- two template
+ * instantiations with different LDS footprints, launched concurrently on two streams) */
+int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
+int ds2i_hip_batch_fetch(ds2i_hip_batch* b, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len,
+                         uint64_t* out_freq_sum);
+/* doc-id lists of `and` (want_matches): match_offsets has nq+1 entries; matches has match_offsets[nq] */
+int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total);
+int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches);
+void ds2i_hip_batch_free(ds2i_hip_batch* b);
+
+/* GPU unit-test hook: wave64 inclusive prefix sum over rows of 64 values */
+int ds2i_hip_selftest_scan(int device, const uint32_t* in, uint32_t* out, uint32_t rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
