@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of ranked_and over a synthetic block_optpfor index on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run with one rank per GPU. A "step" = one pass of the hot path (ranked_and, k=10)
+over one 4096-query batch per GPU, with the index, the prepared query terms and the output buffers
+already resident in HBM. Rank 0 prints ONE JSON line.
+
+  value        whole-job queries/s = (queries all ranks processed) / max-over-ranks wall time
+  roofline     dominant kernel (k_conjunctive<ranked>, <=4-term class): algorithmic bytes (the reference
+               traversal's A_skip, SURVEY.md §8(d), counted by the instrumented oracle) / that kernel's
+               mean hipEvent duration, against the 8 TB/s HBM peak
+  cpu_baseline the oracle (CPU restatement of the reference path, oracle/) driven like op_perftest
+               (queries.cpp:13-62) on ONE host core over a bounded sample of the same batch -- the only
+               place this file touches oracle/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: synthetic 1M-doc Zipf collection, batch = 4096 queries
+    "c2": dict(num_docs=1_000_000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128, clustered_every=4,
+               seed=0xD5210002, label="synthetic 1M-doc Zipf (configs[1]), block_optpfor, ranked_and, batch=4096"),
+    # BASELINE.json metric ("GOV2-scale"): 25M docs, ~1.0 B postings (SURVEY.md §8(d) C3/C4 shape)
+    "gov2": dict(num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
+                 seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config), block_optpfor, ranked_and, batch=4096"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2"])
+    ap.add_argument("--op", default="ranked_and")
+    ap.add_argument("--codec", default="block_optpfor")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=None, help="rocprofv3 --pmc derived HBM bytes per launch (profiles/*.json)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import ds2i_amd as d
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(0)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the query path has no CPU fallback)")
+    d.lib()  # fail loudly if the HIP extension is missing
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- workload
+    wl = args.workload
+    threads = max(1, (os.cpu_count() or 8))
+    if wl == "auto":
+        # probe the host's index-build rate; GOV2-scale (~1 B postings) must build in ~2 minutes
+        if rank == 0:
+            pp = d.SynthParams(seed=1, num_docs=2_000_000, num_terms=2048, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
+                               clustered_every=4)
+            t0 = time.time()
+            _, _, n = d.synth_build(pp, args.codec, threads)
+            rate = n / (time.time() - t0)
+            wl = "gov2" if 1.0e9 / rate < 150 else "c2"
+            log("index build rate %.1f Mpostings/s on %d threads -> workload %s" % (rate / 1e6, threads, wl))
+        if dist is not None:
+            t = torch.tensor([1 if wl == "gov2" else 0], device="cuda")
+            dist.broadcast(t, 0)
+            wl = "gov2" if int(t.item()) else "c2"
+    W = WORKLOADS[wl]
+    p = d.SynthParams(seed=W["seed"], num_docs=W["num_docs"], num_terms=W["num_terms"], zipf_exp=W["zipf_exp"],
+                      top_df_frac=W["top_df_frac"], min_len=W["min_len"], clustered_every=W["clustered_every"])
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    tag = "ds2i_bench_%s_%s_%d" % (wl, args.codec, os.getppid() if world > 1 else os.getpid())
+    f_idx, f_wand = os.path.join(shm, tag + ".idx"), os.path.join(shm, tag + ".wand")
+    postings = 0
+    if rank == 0:
+        t0 = time.time()
+        img, wand, postings = d.synth_build(p, args.codec, threads)
+        log("built %s index: %d postings, %.1f MB, %.1fs" % (wl, postings, len(img) / 1e6, time.time() - t0))
+        if world > 1:
+            open(f_idx, "wb").write(img)
+            open(f_wand, "wb").write(wand)
+    if dist is not None:
+        dist.barrier()
+        if rank != 0:
+            img, wand = open(f_idx, "rb").read(), open(f_wand, "rb").read()
+        dist.barrier()
+        if rank == 0:
+            os.remove(f_idx)
+            os.remove(f_wand)
+    # each rank: full index replica in its GPU's HBM, its own 4096-query batch (weak scaling, no collective)
+    queries = d.synth_queries(0x51E21 + rank, p.num_terms, args.batch)
+    idx = d.Index(args.codec, img, wand, device=local_rank)
+    batch = d.Batch(idx, args.op, queries, k=10)
+
+    # ---------------------------------------------------------------- timed region
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms = [0.0, 0.0]
+    for _ in range(args.steps):
+        st = batch.run()
+        for c in (0, 1):
+            kern_ms[c] += batch.class_stats(c)[0].kernel_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    count, topk, tlen, _ = batch.fetch()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_q = args.batch * world * args.steps
+    qps = total_q / elapsed
+    cls_stats = [batch.class_stats(c) for c in (0, 1)]
+    dom = 0 if cls_stats[0][0].algorithmic_bytes >= cls_stats[1][0].algorithmic_bytes else 1
+    dom_ms = kern_ms[dom] / args.steps
+    out = {
+        "metric": "queries/sec (%s, %s)" % (args.op, args.codec), "value": qps, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "mean_us_per_query": 1e6 * elapsed / (args.batch * args.steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+        "config": {"workload": W["label"], "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
+                   "batch_per_gpu": args.batch, "k": 10, "parallelism": "query-batch sharding x%d, index replicated" % world},
+    }
+
+    # ---------------------------------------------------------------- cpu baseline + algorithmic bytes (oracle; rank 0 only)
+    a_skip_dom = None
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        import oracle as o
+        try:
+            opath = o.build(native=True, out=os.path.join(shm, tag + "_oracle.so"))  # -O3 -march=native on this host
+        except Exception as e:  # no compiler on the box: use the prebuilt generic library
+            log("native oracle build failed (%s); using prebuilt liboracle.so" % e)
+            opath = None
+        oidx = o.Index(args.codec, img, wand, libpath=opath)
+        nterms = [len(set(q)) for q in queries]
+        cls_q = [[q for q, n in zip(queries, nterms) if (n <= 4) == (c == 0)] for c in (0, 1)]
+        t0 = time.time()
+        prof = [oidx.query_batch(args.op, cq, k=10, profile=True)[4] if cq else None for cq in cls_q]
+        log("oracle profile pass (reference traversal A_skip): %.1fs" % (time.time() - t0))
+        a_skip_dom = prof[dom]["algorithmic_bytes"] if prof[dom] else 0
+        out["a_skip_bytes_per_step"] = sum(pr["algorithmic_bytes"] for pr in prof if pr)
+        # parity spot check in the same run (count + top-k within 1e-5) on the sample below
+        probe = queries[:64]
+        t0 = time.time()
+        oidx.query_batch(args.op, probe, k=10)
+        per_q = (time.time() - t0) / len(probe)
+        nsample = int(max(64, min(len(queries), 15.0 / (3 * per_q))))
+        sample = queries[:nsample]
+        oc, otopk, otlen, _, _ = oidx.query_batch(args.op, sample, k=10)
+        assert np.array_equal(count[:nsample], oc), "GPU/oracle count mismatch"
+        fin = np.isfinite(otopk)
+        np.testing.assert_allclose(topk[:nsample][fin], otopk[fin], rtol=1e-5)
+        pt = oidx.perftest(args.op, sample, k=10, runs=2)
+        cpu = {"value": 1e6 / pt["avg"], "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": "first %d of the %d-query batch, op_perftest: 1 untimed + 2 timed passes, %.1fs timed; "
+                         "mean %.1f us q50 %.1f q90 %.1f q95 %.1f" % (nsample, len(queries), pt["seconds"], pt["avg"],
+                                                                   pt["q50"], pt["q90"], pt["q95"]),
+               "host_cpus": os.cpu_count()}
+        out["speedup_vs_cpu_1core"] = qps / cpu["value"]
+        if opath and os.path.exists(opath):
+            os.remove(opath)
+    if a_skip_dom is None:  # N>1 or baseline skipped: price the device's own traversal with the same pricing
+        a_skip_dom = cls_stats[dom][0].algorithmic_bytes
+        src = "device-counted (block-synchronous traversal, same pricing)"
+    else:
+        src = "oracle-counted reference traversal (A_skip)"
+    achieved = a_skip_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    if args.traffic_json and os.path.exists(args.traffic_json):
+        traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "kernel": "k_conjunctive<ranked,%s>" % ("TMAX=4" if dom == 0 else "TMAX=16"),
+                       "kernel_ms": dom_ms, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
+                       "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
+                       "queries_in_kernel": cls_stats[dom][1]}
+    out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

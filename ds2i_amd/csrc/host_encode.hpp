@@ -413,18 +413,21 @@ inline void mixed_encode_type(mixed_type t, int pfor_b, const uint32_t* in, uint
     }
 }
 
-// Deterministic per-block policy standing in for optimal_hybrid_index.cpp (out of
-// scope): smallest encoding wins, ties -> varint (the fastest decoder).
+// Deterministic per-block policy standing in for optimal_hybrid_index.cpp (out of scope,
+// SURVEY.md §2): a fixed space/time trade-off -- varint (fastest decoder) when it costs at most
+// 25% more bytes than pfor, interpolative only when it is more than 1.5x smaller than that choice.
 inline void mixed_encode(const uint32_t* in, uint32_t sum, size_t n, bytes_t& out) {
     if (n < BLOCK) { mixed_encode_type(MIXED_INTERP, -1, in, sum, n, out); return; }
     bytes_t a, b, c;
     varint_g8iu_encode(in, sum, n, a);
     optpfor_encode(in, sum, n, b);
-    interpolative_encode(in, sum, n, c);
-    mixed_type t = MIXED_VARINT;
-    size_t best = a.size();
-    if (b.size() < best) { t = MIXED_PFOR; best = b.size(); }
-    if (c.size() + c.size() / 2 < best) { t = MIXED_INTERP; } // interpolative only when >1.5x smaller (slow decode)
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += in[i];
+    const bool interp_ok = total < 0xFFFFFFFFull; // interpolative codes u32 prefix sums
+    if (interp_ok) interpolative_encode(in, sum, n, c);
+    mixed_type t = (4 * a.size() <= 5 * b.size()) ? MIXED_VARINT : MIXED_PFOR;
+    size_t best = t == MIXED_VARINT ? a.size() : b.size();
+    if (interp_ok && 3 * c.size() < 2 * best) t = MIXED_INTERP;
     const bytes_t& src = t == MIXED_VARINT ? a : t == MIXED_PFOR ? b : c;
     out.push_back((uint8_t)t);
     out.insert(out.end(), src.begin(), src.end());

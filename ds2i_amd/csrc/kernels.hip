@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             continue;
         }
         for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
+        if (OP == OP_WAND || OP == OP_MAXSCORE) cx.s_bytes += 4ull * nt; // max_term_weight[term]
         auto norm_len = [&](uint32_t d) {
             cx.s_bytes += 4;
             ++cx.s_scored;

@@ -164,7 +164,9 @@ static const uint8_t* optpfor_decode_block(const uint8_t* in8, uint32_t* out) {
     if (b > 32 || ew > 2 * BLOCK) throw std::runtime_error("optpfor: corrupt block header");
     std::memcpy(words, in8, 4 * total);
     const uint32_t* in = words + 1;
-    uint32_t exc[2 * BLOCK + 28 * 2 + 64];
+    if (ew > 2 * nexc) throw std::runtime_error("optpfor: corrupt exception area");
+    static thread_local std::vector<uint32_t> excbuf(2 * BLOCK * 28 + 64);
+    uint32_t* exc = excbuf.data();
     if (ew) simple16_decode(in, ew, exc);
     in += ew;
     for (uint32_t g = 0; g < 4; ++g) unpackers::fns[b](in + g * b, out + 32 * g);
@@ -659,7 +661,7 @@ static uint64_t or_query(query_ctx& c, term_id_vec terms, bool with_freqs) {
 
 struct scored_enum { document_enumerator docs_enum; float q_weight; float max_weight; };
 
-static std::vector<scored_enum> make_scored(query_ctx& c, term_id_vec const& terms) {
+static std::vector<scored_enum> make_scored(query_ctx& c, term_id_vec const& terms, bool need_max_weight) {
     auto qf = query_freqs(terms);
     std::vector<scored_enum> enums;
     enums.reserve(qf.size());
@@ -667,8 +669,11 @@ static std::vector<scored_enum> make_scored(query_ctx& c, term_id_vec const& ter
     for (auto term : qf) {
         auto list = (*c.index)[term.first];
         float q_weight = bm25::query_term_weight(term.second, list.size(), num_docs);
-        float max_weight = q_weight * c.wdata->max_term_weight(term.first);
-        if (c.index->prof) c.index->prof->algorithmic_bytes += 4;
+        float max_weight = 0.f; // only wand / maxscore read m_max_term_weight (queries.hpp:232, 510)
+        if (need_max_weight) {
+            max_weight = q_weight * c.wdata->max_term_weight(term.first);
+            if (c.index->prof) c.index->prof->algorithmic_bytes += 4;
+        }
         enums.push_back(scored_enum{std::move(list), q_weight, max_weight});
     }
     return enums;
@@ -681,7 +686,7 @@ static inline float norm_len(query_ctx& c, uint64_t d) {
 static uint64_t ranked_and_query(query_ctx& c, term_id_vec terms) {
     c.topk.clear();
     if (terms.empty()) return 0;
-    auto enums = make_scored(c, terms);
+    auto enums = make_scored(c, terms, false);
     std::sort(enums.begin(), enums.end(), [](scored_enum const& l, scored_enum const& r) { return l.docs_enum.size() < r.docs_enum.size(); });
     uint64_t candidate = enums[0].docs_enum.docid();
     size_t i = 1;
@@ -706,7 +711,7 @@ static uint64_t ranked_and_query(query_ctx& c, term_id_vec terms) {
 static uint64_t ranked_or_query(query_ctx& c, term_id_vec terms) {
     c.topk.clear();
     if (terms.empty()) return 0;
-    auto enums = make_scored(c, terms);
+    auto enums = make_scored(c, terms, false);
     uint64_t cur_doc = std::min_element(enums.begin(), enums.end(), [](scored_enum const& l, scored_enum const& r) { return l.docs_enum.docid() < r.docs_enum.docid(); })->docs_enum.docid();
     while (cur_doc < c.index->num_docs()) {
         float score = 0, nl = norm_len(c, cur_doc);
@@ -729,7 +734,7 @@ static uint64_t wand_query(query_ctx& c, term_id_vec const& terms) {
     c.topk.clear();
     if (terms.empty()) return 0;
     uint64_t num_docs = c.index->num_docs();
-    auto enums = make_scored(c, terms);
+    auto enums = make_scored(c, terms, true);
     std::vector<scored_enum*> ordered;
     ordered.reserve(enums.size());
     for (auto& en : enums) ordered.push_back(&en);
@@ -774,7 +779,7 @@ static uint64_t wand_query(query_ctx& c, term_id_vec const& terms) {
 static uint64_t maxscore_query(query_ctx& c, term_id_vec const& terms) {
     c.topk.clear();
     if (terms.empty()) return 0;
-    auto enums = make_scored(c, terms);
+    auto enums = make_scored(c, terms, true);
     std::vector<scored_enum*> ordered;
     ordered.reserve(enums.size());
     for (auto& en : enums) ordered.push_back(&en);

@@ -1,0 +1,102 @@
+"""Shared test helpers: tiny seeded collections and a codec-independent brute-force oracle (numpy)."""
+import numpy as np
+
+import ds2i_amd as d
+
+K1, B = np.float32(1.2), np.float32(0.5)
+
+
+def small_params(num_docs=20000, num_terms=300, seed=0xD5210001, min_len=1, top=0.5, clustered_every=4):
+    return d.SynthParams(seed=seed, num_docs=num_docs, num_terms=num_terms, zipf_exp=0.75, top_df_frac=top,
+                         min_len=min_len, clustered_every=clustered_every)
+
+
+class Collection:
+    """A materialised synthetic collection: lists, doc sizes, norm_lens (float32 like wand_data.hpp:24-36)."""
+
+    def __init__(self, p):
+        self.p = p
+        self.num_docs = int(p.num_docs)
+        self.lists = [d.synth_list(p, t) for t in range(p.num_terms)]
+        self.sizes = d.synth_doc_sizes(p)
+        lens = self.sizes.astype(np.float32)
+        avg = np.float32(lens.astype(np.float64).sum() / float(self.num_docs))
+        self.norm_lens = (lens / avg).astype(np.float32)
+
+    def index_image(self, codec):
+        return d.build_index(codec, self.num_docs, self.lists)
+
+    def wand_image(self):
+        return d.build_wand(self.sizes, self.lists)
+
+
+def doc_term_weight(freq, norm_len):
+    f = freq.astype(np.float32)
+    return (f / (f + K1 * ((np.float32(1.0) - B) + B * norm_len))).astype(np.float32)
+
+
+def query_term_weight(qtf, df, num_docs):
+    f, fdf = np.float32(qtf), np.float32(df)
+    idf = np.float32(np.log(np.float32((np.float32(num_docs) - fdf + np.float32(0.5)) / (fdf + np.float32(0.5)))))
+    return np.float32(f * max(np.float32(1.0e-6), idf) * (np.float32(1.0) + K1))
+
+
+def brute_and(coll, terms):
+    ts = sorted(set(terms))
+    if not ts:
+        return np.zeros(0, dtype=np.uint32)
+    out = coll.lists[ts[0]][0]
+    for t in ts[1:]:
+        out = np.intersect1d(out, coll.lists[t][0], assume_unique=True)
+    return out.astype(np.uint32)
+
+
+def brute_or(coll, terms):
+    ts = sorted(set(terms))
+    if not ts:
+        return np.zeros(0, dtype=np.uint32)
+    return np.unique(np.concatenate([coll.lists[t][0] for t in ts])).astype(np.uint32)
+
+
+def _term_freqs(terms):
+    ts = sorted(terms)
+    out = []
+    for t in ts:
+        if out and out[-1][0] == t:
+            out[-1][1] += 1
+        else:
+            out.append([t, 1])
+    return out
+
+
+def brute_ranked(coll, terms, k, conjunctive, order="size"):
+    """top-k BM25 scores (descending) of the AND / OR result set. Scores are float32 sums in the
+    reference's enumerator order: size-sorted for ranked_and (queries.hpp:357-360), term order for ranked_or."""
+    tf = _term_freqs(terms)
+    if not tf:
+        return np.zeros(0, dtype=np.float32)
+    N = coll.num_docs
+    ents = []
+    for t, qtf in tf:
+        docs, freqs = coll.lists[t]
+        ents.append((len(docs), t, query_term_weight(qtf, len(docs), N)))
+    if order == "size":
+        ents.sort(key=lambda e: e[0])  # python sort is stable, like insertion sort on <=16 elements
+    docset = brute_and(coll, [t for t, _ in tf]) if conjunctive else brute_or(coll, [t for t, _ in tf])
+    if len(docset) == 0:
+        return np.zeros(0, dtype=np.float32)
+    nl = coll.norm_lens[docset]
+    score = np.zeros(len(docset), dtype=np.float32)
+    for _, t, qw in ents:
+        docs, freqs = coll.lists[t]
+        pos = np.searchsorted(docs, docset)
+        pos_c = np.minimum(pos, len(docs) - 1)
+        hit = docs[pos_c] == docset
+        w = (qw * doc_term_weight(freqs[pos_c], nl)).astype(np.float32)
+        score = np.where(hit, (score + w).astype(np.float32), score)
+    top = np.sort(score)[::-1][:k]
+    return top.astype(np.float32)
+
+
+def queries_for(coll, nq=200, seed=0x51E21):
+    return d.synth_queries(seed, coll.p.num_terms, nq)

@@ -1,0 +1,53 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares."""
+import os
+import re
+
+import pytest
+
+import ds2i_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for h in ("ds2i_hip.h", "ds2i_build.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(ds2i_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_exports_every_declared_symbol(built_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    missing = [s for s in syms if not hasattr(built_lib, s)]
+    assert not missing, missing
+
+
+def test_error_reporting_without_gpu(built_lib):
+    # argument validation happens before any device work, so it is checkable on a CPU box
+    import ctypes as C
+    h = C.c_void_p()
+    rc = built_lib.ds2i_hip_index_open(0, 99, b"x", 1, None, 0, C.byref(h))
+    assert rc == -1 and b"unknown index kind" in built_lib.ds2i_hip_last_error()
+    with pytest.raises(ds2i_amd.Ds2iError):
+        ds2i_amd.build_index("block_optpfor", 10, [([], [])])
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    """The product must fail loudly, not fall back to the oracle, if the HIP extension is absent."""
+    import ds2i_amd.api as api
+    monkeypatch.setattr(api, "_lib", None)
+    monkeypatch.setattr(api, "_HERE", str(tmp_path))
+    with pytest.raises(ImportError):
+        api.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ds2i_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in txt and "liboracle" not in txt and '"oracle/' not in txt, f

@@ -1,0 +1,182 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bit-exact for doc-id lists, counts and decoded postings; BM25 top-k within 1e-5 relative (north_star).
+"""
+import numpy as np
+import pytest
+
+import ds2i_amd as d
+import oracle as o
+from helpers import Collection, brute_and, brute_ranked, queries_for, small_params
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+CODECS = list(d.CODECS)
+ALL_OPS = ["and", "and_freq", "or", "or_freq", "ranked_and", "wand", "maxscore", "ranked_or"]
+
+
+@pytest.fixture(scope="module")
+def coll(built_lib):
+    return Collection(small_params(num_docs=20000, num_terms=300))
+
+
+@pytest.fixture(scope="module")
+def queries(coll):
+    return queries_for(coll, 300) + [[], [5], [5, 5], [7, 3, 7, 3], [0, 1, 2], [0], [299, 298, 297, 296, 295, 294]]
+
+
+@pytest.fixture(scope="module")
+def images(coll):
+    return {c: coll.index_image(c) for c in CODECS}, coll.wand_image()
+
+
+def test_wave_scan_primitive(built_lib):
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 1 << 20, size=(64, 64), dtype=np.uint64).astype(np.uint32)
+    out = np.zeros_like(x)
+    rc = built_lib.ds2i_hip_selftest_scan(0, x.ctypes.data, out.ctypes.data, 64)
+    assert rc == 0, built_lib.ds2i_hip_last_error()
+    assert np.array_equal(out, np.cumsum(x, axis=1, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("codec", CODECS)
+def test_decode_every_list(coll, images, codec):
+    idx = d.Index(codec, images[0][codec])
+    assert idx.size() == len(coll.lists) and idx.num_docs() == coll.num_docs
+    for t, (docs, freqs) in enumerate(coll.lists):
+        assert idx.list_size(t) == len(docs)
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs), (codec, t)
+        assert np.array_equal(ff, freqs), (codec, t)
+
+
+def _check_against_oracle(gidx, oidx, op, queries, k=10, reference_order=False):
+    b = d.Batch(gidx, op, queries, k=k, want_matches=op in ("and", "and_freq"), reference_order=reference_order)
+    st = b.run()
+    count, topk, tlen, fsum = b.fetch()
+    ocount, otopk, otlen, ofsum, _ = oidx.query_batch(op, queries, k=k)
+    assert np.array_equal(count, ocount), op
+    if op in ("and_freq", "or_freq"):
+        assert np.array_equal(fsum, ofsum), op
+    if op in ("ranked_and", "wand", "maxscore", "ranked_or"):
+        assert np.array_equal(tlen, otlen), op
+        for i in range(len(queries)):
+            np.testing.assert_allclose(topk[i, :tlen[i]], otopk[i, :otlen[i]], rtol=RTOL, err_msg=str((op, queries[i])))
+            assert np.all(np.isneginf(topk[i, tlen[i]:]))
+    if op in ("and", "and_freq"):
+        got = b.fetch_matches(count)
+        for i, q in enumerate(queries):
+            exp = oidx.query("and", q, want_matches=True)["matches"]
+            assert np.array_equal(got[i], exp), (op, q)
+    b.close()
+    return st
+
+
+@pytest.mark.parametrize("codec", CODECS)
+@pytest.mark.parametrize("op", ALL_OPS)
+def test_query_ops_match_oracle(coll, queries, images, codec, op):
+    gidx = d.Index(codec, images[0][codec], images[1])
+    oidx = o.Index(codec, images[0][codec], images[1])
+    _check_against_oracle(gidx, oidx, op, queries)
+
+
+@pytest.mark.parametrize("op", ["and", "and_freq", "ranked_and"])
+def test_reference_order_kernel_and_algorithmic_bytes(coll, queries, images, op):
+    """The one-candidate-per-step GPU traversal decodes exactly the blocks the reference decodes."""
+    codec = "block_optpfor"
+    gidx = d.Index(codec, images[0][codec], images[1])
+    oidx = o.Index(codec, images[0][codec], images[1])
+    st = _check_against_oracle(gidx, oidx, op, queries, reference_order=True)
+    _, _, _, _, prof = oidx.query_batch(op, queries, profile=True)
+    assert st.docs_blocks_decoded == prof["docs_blocks"]
+    assert st.freqs_blocks_decoded == prof["freqs_blocks"]
+    assert st.block_max_examined == prof["block_max_examined"]
+    assert st.algorithmic_bytes == prof["algorithmic_bytes"]
+    # block-synchronous kernel: a superset of those blocks, never fewer docs blocks
+    b = d.Batch(gidx, op, queries)
+    st2 = b.run()
+    assert st2.docs_blocks_decoded >= prof["docs_blocks"] * 0.99
+    assert st2.docs_blocks_decoded <= prof["docs_blocks"] * 1.5 + 16
+
+
+def test_topk_other_k(coll, queries, images):
+    codec = "block_optpfor"
+    gidx = d.Index(codec, images[0][codec], images[1])
+    oidx = o.Index(codec, images[0][codec], images[1])
+    for k in (1, 3, 64):
+        for op in ("ranked_and", "ranked_or", "wand"):
+            _check_against_oracle(gidx, oidx, op, queries[:80], k=k)
+
+
+def test_brute_force_agreement(coll, queries, images):
+    """Codec-independent check: the GPU results equal sorted-array intersection + BM25 in numpy."""
+    gidx = d.Index("block_varint", images[0]["block_varint"], images[1])
+    count, _, _, _ = gidx.query_batch("and", queries)
+    rcount, topk, tlen, _ = gidx.query_batch("ranked_and", queries)
+    for i, q in enumerate(queries):
+        assert count[i] == len(brute_and(coll, q))
+        exp = brute_ranked(coll, q, 10, True)
+        assert rcount[i] == len(exp)
+        np.testing.assert_allclose(topk[i, :tlen[i]], exp, rtol=RTOL)
+
+
+def test_error_behaviour(coll, images):
+    gidx = d.Index("block_optpfor", images[0]["block_optpfor"])  # no wand data
+    with pytest.raises(d.Ds2iError) as e:
+        gidx.query_batch("and", [[coll.p.num_terms]])
+    assert e.value.code == -3  # DS2I_ETERM: the reference only asserts (block_freq_index.hpp:87)
+    with pytest.raises(d.Ds2iError) as e:
+        gidx.query_batch("ranked_and", [[1, 2]])
+    assert e.value.code == -5  # ranked op without wand data (queries.cpp:108-116)
+    with pytest.raises(d.Ds2iError) as e:
+        gidx.query_batch("and", [list(range(17))])
+    assert e.value.code == -6
+    with pytest.raises(d.Ds2iError):
+        d.Index("block_optpfor", b"\x00" * 10)
+    count, _, _, _ = gidx.query_batch("and", [])
+    assert len(count) == 0
+
+
+def test_query_op_concept(coll, images):
+    """queries.cpp-style use: op(index, terms) -> uint64, ranked ops expose topk()."""
+    gidx = d.Index("block_qmx", images[0]["block_qmx"], images[1])
+    q = [3, 40]
+    assert d.and_query()(gidx, q) == len(brute_and(coll, q))
+    op = d.ranked_and_query(None, 10)
+    n = op(gidx, q)
+    exp = brute_ranked(coll, q, 10, True)
+    assert n == len(exp)
+    np.testing.assert_allclose(op.topk(), exp, rtol=RTOL)
+
+
+def test_full_size_c2_properties(built_lib):
+    """BASELINE configs[1]: 1M docs Zipf, block_optpfor, 4096-query batch. Parity on every query against the
+    oracle (it finishes in seconds) plus size-independent properties."""
+    p = d.SynthParams(seed=0xD5210002, num_docs=1000000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128,
+                      clustered_every=4)
+    img, wand, postings = d.synth_build(p, "block_optpfor")
+    assert postings > 20_000_000
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
+    gidx = d.Index("block_optpfor", img, wand)
+    oidx = o.Index("block_optpfor", img, wand)
+    acount, _, _, _ = gidx.query_batch("and", queries)
+    rcount, topk, tlen, st = gidx.query_batch("ranked_and", queries)
+    oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", queries)
+    oac, _, _, _, _ = oidx.query_batch("and", queries)
+    assert np.array_equal(acount, oac)
+    assert np.array_equal(rcount, oc) and np.array_equal(tlen, otlen)
+    assert np.array_equal(rcount, np.minimum(acount, 10))          # ranked_and keeps min(k, |AND|) scores
+    assert np.all(np.diff(topk, axis=1)[np.isfinite(topk[:, 1:])] <= 0)  # descending
+    finite = np.isfinite(otopk)
+    np.testing.assert_allclose(topk[finite], otopk[finite], rtol=RTOL)
+    # idempotence: a second run of the same batch gives identical bits
+    rcount2, topk2, _, _ = gidx.query_batch("ranked_and", queries)
+    assert np.array_equal(rcount, rcount2) and np.array_equal(topk, topk2)
+    # wand == maxscore == ranked_or (the reference's own ranked test, test_ranked_queries.cpp:40-60)
+    sub = queries[:512]
+    _, t_or, l_or, _ = gidx.query_batch("ranked_or", sub)
+    for op in ("wand", "maxscore"):
+        _, t2, l2, _ = gidx.query_batch(op, sub)
+        assert np.array_equal(l_or, l2)
+        f = np.isfinite(t_or)
+        np.testing.assert_allclose(t2[f], t_or[f], rtol=RTOL)
