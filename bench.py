@@ -162,7 +162,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         import oracle as o
         try:
-            opath = o.build(native=True, out=os.path.join(shm, tag + "_oracle.so"))  # -O3 -march=native on this host
+            import tempfile
+            opath = o.build(native=True, out=os.path.join(tempfile.gettempdir(), tag + "_oracle.so"))  # -O3 -march=native here
         except Exception as e:  # no compiler on the box: use the prebuilt generic library
             log("native oracle build failed (%s); using prebuilt liboracle.so" % e)
             opath = None

@@ -118,7 +118,8 @@ def _ptr(a):
 def _take_blob(handle):
     L = lib()
     n = L.ds2i_blob_size(handle)
-    out = C.string_at(L.ds2i_blob_data(handle), n) if n else b""
+    # (c_char * n).raw handles images > 2 GiB (string_at takes a C int size)
+    out = (C.c_char * n).from_address(L.ds2i_blob_data(handle)).raw if n else b""
     L.ds2i_blob_free(handle)
     return out
 

@@ -22,12 +22,22 @@ struct Stats {
 enum { OP_AND = 0, OP_AND_FREQ = 1, OP_OR = 2, OP_OR_FREQ = 3, OP_RANKED_AND = 4, OP_WAND = 5, OP_MAXSCORE = 6,
        OP_RANKED_OR = 7, OP_REFERENCE_ORDER = 0x100 };
 
+// One schedulable piece of a query: conjunctive queries are split by ranges of blocks of their
+// shortest list (doc-id ranges), every other operator has exactly one unit per query.
+struct Unit {
+    uint32_t q;         // query id
+    uint32_t blk_begin; // first block of list 0 this unit owns
+    uint32_t blk_end;   // one past the last block
+    uint32_t nparts;    // number of units of query q (1 -> the unit writes the final outputs itself)
+};
+
 struct BatchArgs {
     const uint8_t* arena;
     const float* norm_lens;
     const QTerm* qterms;      // terms of all queries, already in enumerator order
     const uint32_t* q_off;    // nq+1 offsets into qterms
-    const uint32_t* order;    // nslice query ids, scheduling order (costliest first)
+    const Unit* units;        // all units, grouped by query
+    const uint32_t* order;    // nslice unit ids, scheduling order (costliest first)
     uint32_t nslice;
     uint32_t num_docs;
     uint32_t k;
@@ -39,7 +49,28 @@ struct BatchArgs {
     unsigned long long* out_freq_sum; // nq (and_freq / or_freq checksum of touched freqs) or null
     uint32_t* out_matches;    // optional doc-id lists (and) or null
     const unsigned long long* match_off; // nq+1 capacity offsets
+    // per-unit partial results of split queries (merged by k_merge)
+    unsigned long long* unit_count;
+    float* unit_topk;         // nunits*k
+    uint32_t* unit_topk_len;
+    unsigned long long* unit_freq_sum;
     Stats* stats;
+};
+
+struct MergeArgs {
+    const uint32_t* split_queries; // ids of queries with nparts > 1
+    uint32_t nsplit;
+    const uint32_t* q_unit_off;    // nq+1: units of query q are [q_unit_off[q], q_unit_off[q+1])
+    uint32_t k;
+    int ranked;
+    const unsigned long long* unit_count;
+    const float* unit_topk;
+    const uint32_t* unit_topk_len;
+    const unsigned long long* unit_freq_sum;
+    unsigned long long* out_count;
+    float* out_topk;
+    uint32_t* out_topk_len;
+    unsigned long long* out_freq_sum;
 };
 
 struct DecodeArgs {

@@ -18,12 +18,15 @@
 
 using ds2i_dev::BatchArgs;
 using ds2i_dev::DecodeArgs;
+using ds2i_dev::MergeArgs;
+using ds2i_dev::Unit;
 using ds2i_dev::QTerm;
 using ds2i_dev::Stats;
 
 extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s);
 }
 
@@ -69,7 +72,18 @@ struct ds2i_hip_batch {
     int op = 0;
     uint32_t k = 0, nq = 0;
     bool want_matches = false;
-    uint32_t ncls[2] = {0, 0};
+    uint32_t ncls[2] = {0, 0}; // units per kernel class
+    uint32_t nqcls[2] = {0, 0}; // queries per kernel class
+    uint32_t nunits = 0, nsplit = 0;
+    std::vector<Unit> units;
+    std::vector<uint32_t> q_unit_off;
+    Unit* d_units = nullptr;
+    uint32_t* d_q_unit_off = nullptr;
+    uint32_t* d_split = nullptr;
+    unsigned long long* d_unit_count = nullptr;
+    float* d_unit_topk = nullptr;
+    uint32_t* d_unit_topk_len = nullptr;
+    unsigned long long* d_unit_freq_sum = nullptr;
     QTerm* d_qterms = nullptr;
     uint32_t* d_qoff = nullptr;
     uint32_t* d_order[2] = {nullptr, nullptr};
@@ -289,10 +303,13 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
 
     std::vector<QTerm> qterms;
     std::vector<uint32_t> qoff(nq + 1, 0);
-    std::vector<std::pair<double, uint32_t>> cls[2];
+    std::vector<double> qcost(nq, 0.0);   // estimated block decodes of the whole query
+    std::vector<uint32_t> qnb0(nq, 0);    // blocks of the shortest list (conjunctive)
     b->match_off.assign(nq + 1, 0);
     std::vector<uint32_t> t;
     std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
+    const bool split_ok = conj && !(op & DS2I_OP_REFERENCE_ORDER);
+    double total_cost[2] = {0, 0};
     for (uint32_t q = 0; q < nq; ++q) {
         if (query_offsets[q + 1] < query_offsets[q])
             return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
@@ -325,17 +342,54 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             std::stable_sort(qterms.begin() + begin, qterms.end(),
                              [](QTerm const& l, QTerm const& r) { return l.n < r.n; });
             if (!tf.empty()) {
-                double n0 = qterms[begin].n;
-                for (size_t i = begin; i < qterms.size(); ++i) cost += std::min<double>(qterms[i].n, 128.0 * n0);
-                b->match_off[q + 1] = (unsigned long long)qterms[begin].n;
+                const double n0 = qterms[begin].n;
+                qnb0[q] = (qterms[begin].n + 127u) / 128u;
+                cost = qnb0[q] * (ranked ? 2.0 : 1.0);
+                for (size_t i = begin + 1; i < qterms.size(); ++i) cost += std::min<double>((qterms[i].n + 127u) / 128u, n0);
+                b->match_off[q + 1] = 128ull * qnb0[q];
             }
         } else {
-            for (size_t i = begin; i < qterms.size(); ++i) cost += qterms[i].n;
+            for (size_t i = begin; i < qterms.size(); ++i) cost += (qterms[i].n + 127u) / 128u * (ranked ? 2.0 : 1.0);
         }
         qoff[q + 1] = (uint32_t)qterms.size();
-        cls[tf.size() <= 4 ? 0 : 1].emplace_back(cost, q);
+        qcost[q] = cost;
+        total_cost[tf.size() <= 4 ? 0 : 1] += cost;
     }
     for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
+
+    // ---- work units: long conjunctive queries are split by block ranges of their shortest list so
+    // that one giant query does not pin a single wavefront (SURVEY.md §7 "Load imbalance")
+    std::vector<std::pair<double, uint32_t>> cls[2];
+    b->q_unit_off.assign(nq + 1, 0);
+    std::vector<uint32_t> split_queries;
+    const double resident[2] = {idx->num_cus * 20.0, idx->num_cus * 7.0};
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t nt = qoff[q + 1] - qoff[q];
+        const int c = nt <= 4 ? 0 : 1;
+        uint32_t parts = 1;
+        if (split_ok && nt && qnb0[q] > 1) {
+            const double target = std::max(48.0, total_cost[c] / (4.0 * resident[c]));
+            double want = std::floor(qcost[q] / target);
+            parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
+        }
+        const uint32_t nb0 = std::max(1u, qnb0[q]);
+        const uint32_t per = (nb0 + parts - 1) / parts;
+        parts = (nb0 + per - 1) / per;
+        if (parts > 1) split_queries.push_back(q);
+        if (q < nq) ++b->nqcls[c];
+        for (uint32_t j = 0; j < parts; ++j) {
+            Unit u;
+            u.q = q;
+            u.blk_begin = j * per;
+            u.blk_end = std::min(nb0, (j + 1) * per);
+            u.nparts = parts;
+            cls[c].emplace_back(qcost[q] / parts, (uint32_t)b->units.size());
+            b->units.push_back(u);
+        }
+        b->q_unit_off[q + 1] = (uint32_t)b->units.size();
+    }
+    b->nunits = (uint32_t)b->units.size();
+    b->nsplit = (uint32_t)split_queries.size();
 
     HIP_OK(hipSetDevice(idx->device));
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
@@ -345,6 +399,9 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     };
     HIP_OK(upload((void**)&b->d_qterms, qterms.data(), qterms.size() * sizeof(QTerm)));
     HIP_OK(upload((void**)&b->d_qoff, qoff.data(), qoff.size() * 4));
+    HIP_OK(upload((void**)&b->d_units, b->units.data(), b->units.size() * sizeof(Unit)));
+    HIP_OK(upload((void**)&b->d_q_unit_off, b->q_unit_off.data(), b->q_unit_off.size() * 4));
+    HIP_OK(upload((void**)&b->d_split, split_queries.data(), split_queries.size() * 4));
     for (int c = 0; c < 2; ++c) {
         std::stable_sort(cls[c].begin(), cls[c].end(),
                          [](auto const& l, auto const& r) { return l.first > r.first; }); // costliest first
@@ -353,6 +410,12 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         b->ncls[c] = (uint32_t)order.size();
         HIP_OK(upload((void**)&b->d_order[c], order.data(), order.size() * 4));
     }
+    const size_t nu = b->nunits ? b->nunits : 1;
+    HIP_OK(hipMalloc((void**)&b->d_unit_count, 8 * nu));
+    HIP_OK(hipMalloc((void**)&b->d_unit_topk, 4 * nu * k));
+    HIP_OK(hipMalloc((void**)&b->d_unit_topk_len, 4 * nu));
+    HIP_OK(hipMalloc((void**)&b->d_unit_freq_sum, 8 * nu));
+    HIP_OK(hipMemset(b->d_unit_count, 0, 8 * nu));
     HIP_OK(hipMalloc((void**)&b->d_count, 8 * (size_t)(nq ? nq : 1)));
     HIP_OK(hipMalloc((void**)&b->d_topk, 4 * (size_t)(nq ? nq : 1) * k));
     HIP_OK(hipMalloc((void**)&b->d_topk_len, 4 * (size_t)(nq ? nq : 1)));
@@ -385,6 +448,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.norm_lens = idx->d_norm_lens;
             a.qterms = b->d_qterms;
             a.q_off = b->d_qoff;
+            a.units = b->d_units;
             a.order = b->d_order[c];
             a.nslice = b->ncls[c];
             a.num_docs = (uint32_t)idx->num_docs;
@@ -397,6 +461,10 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.out_freq_sum = b->d_freq_sum;
             a.out_matches = b->want_matches ? b->d_matches : nullptr;
             a.match_off = b->d_match_off;
+            a.unit_count = b->d_unit_count;
+            a.unit_topk = b->d_unit_topk;
+            a.unit_topk_len = b->d_unit_topk_len;
+            a.unit_freq_sum = b->d_unit_freq_sum;
             a.stats = idx->d_stats + c;
             const unsigned per_cu = c ? 7u : 24u; // resident one-wave workgroups per CU (LDS bound)
             unsigned grid = (unsigned)std::min<uint64_t>(b->ncls[c], uint64_t(idx->num_cus) * per_cu);
@@ -405,6 +473,23 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
         HIP_OK(hipEventRecord(idx->ev[2 + 2 * c], s));
     }
     HIP_OK(hipStreamWaitEvent(s0, idx->ev[4], 0));
+    if (b->nsplit) {
+        MergeArgs m{};
+        m.split_queries = b->d_split;
+        m.nsplit = b->nsplit;
+        m.q_unit_off = b->d_q_unit_off;
+        m.k = b->k;
+        m.ranked = (b->op & 0xFF) >= DS2I_OP_RANKED_AND;
+        m.unit_count = b->d_unit_count;
+        m.unit_topk = b->d_unit_topk;
+        m.unit_topk_len = b->d_unit_topk_len;
+        m.unit_freq_sum = b->d_unit_freq_sum;
+        m.out_count = b->d_count;
+        m.out_topk = b->d_topk;
+        m.out_topk_len = b->d_topk_len;
+        m.out_freq_sum = b->d_freq_sum;
+        HIP_OK(ds2i_launch_merge(&m, std::min<unsigned>(b->nsplit, 4096u), s0));
+    }
     HIP_OK(hipEventRecord(idx->ev[5], s0));
     HIP_OK(hipStreamSynchronize(s0));
     float ms = 0.f;
@@ -433,7 +518,7 @@ int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, 
     out->algorithmic_bytes = b->cls_stats[cls].algorithmic_bytes;
     out->postings_scored = b->cls_stats[cls].postings_scored;
     out->rounds = b->cls_stats[cls].rounds;
-    if (nqueries) *nqueries = b->ncls[cls];
+    if (nqueries) *nqueries = b->nqcls[cls];
     return DS2I_OK;
 }
 
@@ -452,18 +537,35 @@ int ds2i_hip_batch_fetch(ds2i_hip_batch* b, uint64_t* out_count, float* out_topk
 
 int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total) {
     if (!b || !total) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_match_total: null argument");
-    *total = b->want_matches ? b->match_off[b->nq] : 0;
+    *total = b->want_matches ? b->match_off[b->nq] : 0; // capacity: 128 per block of each query's shortest list
     return DS2I_OK;
 }
 
-// matches of query q occupy [match_offsets[q], match_offsets[q] + out_count[q]) (capacity = shortest list)
+// On return matches of query q occupy [match_offsets[q], match_offsets[q] + out_count[q]); the device
+// buffer holds one segment per work unit (at 128*blk_begin), compacted here on the host.
 int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches) {
     if (!b || !match_offsets || !matches) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch_matches: null argument");
     if (!b->want_matches) return ds2i_set_error(DS2I_EINVAL, "batch was prepared without want_matches");
     HIP_OK(hipSetDevice(b->idx->device));
     for (size_t i = 0; i <= b->nq; ++i) match_offsets[i] = b->match_off[i];
-    if (b->match_off[b->nq])
-        HIP_OK(hipMemcpy(matches, b->d_matches, 4 * (size_t)b->match_off[b->nq], hipMemcpyDeviceToHost));
+    const size_t total = (size_t)b->match_off[b->nq];
+    if (!total) return DS2I_OK;
+    HIP_OK(hipMemcpy(matches, b->d_matches, 4 * total, hipMemcpyDeviceToHost));
+    if (b->nsplit) {
+        std::vector<unsigned long long> ucount(b->nunits);
+        HIP_OK(hipMemcpy(ucount.data(), b->d_unit_count, 8 * (size_t)b->nunits, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < b->nq; ++q) {
+            const uint32_t u0 = b->q_unit_off[q], u1 = b->q_unit_off[q + 1];
+            if (u1 - u0 < 2) continue;
+            uint32_t* base = matches + b->match_off[q];
+            size_t w = 0;
+            for (uint32_t u = u0; u < u1; ++u) {
+                const uint32_t* seg = base + 128ull * b->units[u].blk_begin;
+                std::memmove(base + w, seg, 4 * (size_t)ucount[u]);
+                w += (size_t)ucount[u];
+            }
+        }
+    }
     return DS2I_OK;
 }
 

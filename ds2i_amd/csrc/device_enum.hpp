@@ -125,8 +125,9 @@ struct Ctx {
         s_bytes += consumed;
     }
 
-    // ---- ctor (block_posting_list.hpp:86-103)
-    DS2I_DEV void open(uint32_t s, const QTerm& t) {
+    // ---- ctor (block_posting_list.hpp:86-103). bind() only records the list geometry; open()
+    // additionally decodes block 0 like the reference constructor does.
+    DS2I_DEV void bind(uint32_t s, const QTerm& t) {
         const uint32_t n = t.n;
         const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
         const uint64_t maxs = t.list_off + vl;
@@ -140,29 +141,57 @@ struct Ctx {
             mm[M_MAXW] = __float_as_uint(t.max_weight);
             mm[M_END_LO] = (uint32_t)t.list_end;
             mm[M_END_HI] = (uint32_t)(t.list_end >> 32);
+            mm[M_CUR] = 0xFFFFFFFFu; // no block decoded yet
+            mm[M_BMAX] = 0;
+            mm[M_FDEC] = 0;
         }
         wave_sync();
-        s_bytes += vl + 8 + 4; // vbyte(n) + list offset + block_max[0]
+        s_bytes += vl + 8; // vbyte(n) + list offset
+    }
+    DS2I_DEV void open(uint32_t s, const QTerm& t) {
+        bind(s, t);
+        s_bytes += 4; // block_max[0]
         ++s_bm_examined;
         decode_docs(s, 0);
     }
 
-    // first block >= from whose block_max >= lb, or nb if none. 64 entries per probe.
+    // first block >= from whose block_max >= lb, or nb if none. The reference scans block_max
+    // linearly (block_posting_list.hpp:134-137); here one wave probes 64 entries at a time: first the
+    // 64 entries right after the current block (short skips), then a 64-ary search over the rest.
     DS2I_DEV uint32_t find_block(uint32_t s, uint32_t from, uint32_t lb) {
         const uint8_t* maxs = ptr(s, M_MAXS_LO);
         const uint32_t nb = m(s, M_NB);
-        uint32_t blk = from;
-        while (blk < nb) {
-            uint32_t idx = blk + lane_id();
+        const uint32_t lane = lane_id();
+        if (from >= nb) return nb;
+        {
+            uint32_t idx = from + lane;
             uint32_t v = (idx < nb) ? ld32(maxs + 4ull * idx) : 0xFFFFFFFFu;
             uint64_t hit = ballot(v >= lb);
             if (hit) {
-                blk += (uint32_t)__builtin_ctzll(hit);
-                break;
+                uint32_t blk = from + (uint32_t)__builtin_ctzll(hit);
+                return blk < nb ? blk : nb;
             }
-            blk += 64;
         }
-        return blk < nb ? blk : nb;
+        uint32_t lo = from + 64, hi = nb; // answer in [lo, hi) or none
+        if (lo >= hi) return nb;
+        while (hi - lo > 64) {
+            const uint32_t stride = (hi - lo + 63) / 64;
+            uint32_t idx = lo + (lane + 1) * stride - 1;
+            if (idx >= hi) idx = hi - 1;
+            uint32_t v = ld32(maxs + 4ull * idx);
+            uint64_t hit = ballot(v >= lb);
+            if (!hit) return nb; // even block hi-1 (probed by the last lanes) is below lb
+            uint32_t f = (uint32_t)__builtin_ctzll(hit);
+            uint32_t nhi = lo + (f + 1) * stride;
+            hi = nhi < hi ? nhi : hi;
+            lo = lo + f * stride;
+        }
+        uint32_t idx = lo + lane;
+        uint32_t v = (idx < hi) ? ld32(maxs + 4ull * idx) : 0xFFFFFFFFu;
+        uint64_t hit = ballot(v >= lb);
+        if (!hit) return nb;
+        uint32_t blk = lo + (uint32_t)__builtin_ctzll(hit);
+        return blk < hi ? blk : nb;
     }
 
     // ---- next_geq (block_posting_list.hpp:124-146)

@@ -53,10 +53,10 @@ DS2I_DEV uint32_t next_ticket(unsigned int* ticket) {
     return bcast(t, 0);
 }
 
-DS2I_DEV void store_topk(const BatchArgs& a, uint32_t q, const TopK& tk) {
+DS2I_DEV void store_topk(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopK& tk) {
     const uint32_t lane = lane_id();
-    if (lane < a.k) a.out_topk[(size_t)q * a.k + lane] = tk.v;
-    if (lane == 0) a.out_topk_len[q] = tk.n;
+    if (lane < k) topk[(size_t)slot * k + lane] = tk.v;
+    if (lane == 0) topk_len[slot] = tk.n;
 }
 
 // ------------------------------------------------------------------ conjunctive
@@ -80,29 +80,36 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
     for (;;) {
         const uint32_t tkt = next_ticket(a.ticket);
         if (tkt >= a.nslice) break;
-        const uint32_t q = a.order[tkt];
+        const uint32_t uid = a.order[tkt];
+        const Unit u = a.units[uid];
+        const uint32_t q = u.q;
+        const bool whole = u.nparts == 1;
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         unsigned long long count = 0, fsum = 0;
         TopK tk;
         tk.init(a.k);
         if (nt == 0 || nt > (uint32_t)TMAX) { // empty query -> 0 results (queries.hpp:41,335)
             if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
-            if (RANKED) store_topk(a, q, tk);
+            if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
             continue;
         }
-        for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
-        const unsigned long long mbase = a.out_matches ? a.match_off[q] : 0;
-        const unsigned long long mcap = a.out_matches ? a.match_off[q + 1] - mbase : 0;
-        const uint32_t last0 = uniform(ld32(cx.ptr(0, M_MAXS_LO) + 4ull * (cx.m(0, M_NB) - 1)));
+        // list 0 (shortest) drives; the unit owns its blocks [blk_begin, blk_end). The other lists are
+        // bound lazily: their first block is located by the first candidate (no block-0 decode).
+        for (uint32_t i = 0; i < nt; ++i) cx.bind(i, a.qterms[t0 + i]);
+        const unsigned long long mbase = a.out_matches ? a.match_off[q] + 128ull * u.blk_begin : 0;
+        const unsigned long long mcap = a.out_matches ? 128ull * (u.blk_end - u.blk_begin) : 0;
+        cx.s_bytes += 4;
+        ++cx.s_bm_examined;
+        cx.decode_docs(0, u.blk_begin);
         uint32_t lo = 0;
         bool finished = false;
         while (!finished) {
             ++cx.s_rounds;
             // list 0 supplies the candidates of this round
             if (lo > cx.m(0, M_BMAX)) {
-                if (lo > last0) break;
                 uint32_t cur = cx.m(0, M_CUR);
                 uint32_t blk = cx.find_block(0, cur + 1, lo);
+                if (blk >= u.blk_end) break;
                 cx.s_bm_examined += blk - cur;
                 cx.s_bytes += 4ull * (blk - cur);
                 cx.decode_docs(0, blk);
@@ -114,7 +121,7 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                 uint64_t b0 = ballot(al0), b1 = ballot(al1);
                 if (!(b0 | b1)) break;
                 uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
-                if (amin > cx.m(i, M_BMAX)) {
+                if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
                     uint32_t cur = cx.m(i, M_CUR);
                     uint32_t blk = cx.find_block(i, cur + 1, amin);
                     if (blk >= cx.m(i, M_NB)) { // list i has nothing >= amin: no further match exists
@@ -224,13 +231,56 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
             if (hi == 0xFFFFFFFFu) break;
             lo = hi + 1;
         }
-        if (lane == 0) {
-            a.out_count[q] = RANKED ? tk.n : count;
-            if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+        if (whole) {
+            if (lane == 0) {
+                a.out_count[q] = RANKED ? tk.n : count;
+                if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+            }
+            if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+        } else {
+            if (lane == 0) {
+                a.unit_count[uid] = RANKED ? tk.n : count;
+                a.unit_freq_sum[uid] = fsum;
+            }
+            if (RANKED) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
-        if (RANKED) store_topk(a, q, tk);
     }
     cx.flush_stats(a.stats);
+}
+
+// Merges the partial results of split queries: counts add up, the top-k of a union is the top-k of
+// the parts' top-ks (scores are per-document, so the merged multiset equals the sequential one).
+__global__ void __launch_bounds__(64) k_merge(MergeArgs a) {
+    const uint32_t lane = lane_id();
+    for (uint32_t w = blockIdx.x; w < a.nsplit; w += gridDim.x) {
+        const uint32_t q = a.split_queries[w];
+        const uint32_t u0 = a.q_unit_off[q], u1 = a.q_unit_off[q + 1];
+        unsigned long long count = 0, fsum = 0;
+        for (uint32_t u = u0 + lane; u < u1; u += 64) { count += a.unit_count[u]; fsum += a.unit_freq_sum[u]; }
+        for (int o = 32; o; o >>= 1) {
+            count += __shfl_xor(count, o);
+            fsum += __shfl_xor(fsum, o);
+        }
+        TopK tk;
+        tk.init(a.k);
+        if (a.ranked) {
+            for (uint32_t u = u0; u < u1; ++u) {
+                const uint32_t len = a.unit_topk_len[u];
+                float v = lane < len ? a.unit_topk[(size_t)u * a.k + lane] : -__builtin_inff();
+                uint64_t todo = ballot(lane < len && tk.would_enter(v));
+                while (todo) {
+                    uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    tk.insert(__uint_as_float(bcast(__float_as_uint(v), src)));
+                }
+            }
+            store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+        }
+        if (lane == 0) {
+            a.out_count[q] = a.ranked ? tk.n : count;
+            if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ document-at-a-time
@@ -264,14 +314,14 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     for (;;) {
         const uint32_t tkt = next_ticket(a.ticket);
         if (tkt >= a.nslice) break;
-        const uint32_t q = a.order[tkt];
+        const uint32_t q = a.units[a.order[tkt]].q; // one unit per query for these operators
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         unsigned long long count = 0, fsum = 0;
         TopK tk;
         tk.init(a.k);
         if (nt == 0 || nt > (uint32_t)TMAX) {
             if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
-            if (RANKED) store_topk(a, q, tk);
+            if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
             continue;
         }
         for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
@@ -417,7 +467,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             a.out_count[q] = RANKED ? tk.n : count;
             if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
         }
-        if (RANKED) store_topk(a, q, tk);
+        if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
     }
     cx.flush_stats(a.stats);
 }
@@ -502,6 +552,12 @@ extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
     return tmax_class == 0 ? ds2i_launch::launch_t<4>(op, a, grid, s) : ds2i_launch::launch_t<16>(op, a, grid, s);
+}
+
+hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s) {
+    const MergeArgs& a = *(const MergeArgs*)args;
+    hipLaunchKernelGGL(k_merge, dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s) {

@@ -119,6 +119,14 @@ def decode_vbyte(data):
     return v.value, n
 
 
+def _padded(data, pad):
+    """one zero-padded copy of an image (the decoders' benign over-reads must stay in bounds)"""
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.zeros(len(src) + pad, dtype=np.uint8)
+    out[:len(src)] = src
+    return out
+
+
 def _flatten(queries):
     offs = np.zeros(len(queries) + 1, dtype=np.uint32)
     for i, q in enumerate(queries):
@@ -137,8 +145,8 @@ class Index:
     def __init__(self, kind, index_image, wand_image=None, libpath=None):
         self._L = lib(libpath)
         # keep padded copies alive: the oracle aliases the images like the reference's mmap
-        self._img = np.frombuffer(bytes(index_image) + b"\0" * 64, dtype=np.uint8)
-        self._wand = np.frombuffer(bytes(wand_image) + b"\0" * 8, dtype=np.uint8) if wand_image is not None else None
+        self._img = _padded(index_image, 64)
+        self._wand = _padded(wand_image, 8) if wand_image is not None else None
         self._h = self._L.oracle_index_open(_codec(kind), _p(self._img), len(index_image),
                                             _p(self._wand) if self._wand is not None else None,
                                             len(wand_image) if wand_image is not None else 0)
