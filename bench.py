@@ -31,6 +31,7 @@ WORKLOADS = {
     "gov2": dict(num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
                  seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config), block_optpfor, ranked_and, batch=4096"),
 }
+NCLS = 4  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -124,10 +125,10 @@ def main():
         batch.run()
     barrier()
     t0 = time.perf_counter()
-    kern_ms = [0.0, 0.0]
+    kern_ms = [0.0] * NCLS
     for _ in range(args.steps):
         st = batch.run()
-        for c in (0, 1):
+        for c in range(NCLS):
             kern_ms[c] += batch.class_stats(c)[0].kernel_ms
     barrier()
     elapsed = time.perf_counter() - t0
@@ -144,8 +145,13 @@ def main():
 
     total_q = args.batch * world * args.steps
     qps = total_q / elapsed
-    cls_stats = [batch.class_stats(c) for c in (0, 1)]
-    dom = 0 if cls_stats[0][0].algorithmic_bytes >= cls_stats[1][0].algorithmic_bytes else 1
+    cls_stats = [batch.class_stats(c) for c in range(NCLS)]
+    dom = max(range(NCLS), key=lambda c: cls_stats[c][0].algorithmic_bytes)
+    for c in range(NCLS):
+        log("class %d: %d queries, kernel %.3f ms/step, %s" % (c, cls_stats[c][1], kern_ms[c] / args.steps, cls_stats[c][0].as_dict()))
+        pc = batch.phase_cycles(c)
+        if pc["total"]:
+            log("   phase cycles (diagnostic build): " + ", ".join("%s %.1f%%" % (k, 100.0 * v / pc["total"]) for k, v in pc.items()))
     dom_ms = kern_ms[dom] / args.steps
     out = {
         "metric": "queries/sec (%s, %s)" % (args.op, args.codec), "value": qps, "unit": "queries/s",
@@ -169,7 +175,8 @@ def main():
             opath = None
         oidx = o.Index(args.codec, img, wand, libpath=opath)
         nterms = [len(set(q)) for q in queries]
-        cls_q = [[q for q, n in zip(queries, nterms) if (n <= 4) == (c == 0)] for c in (0, 1)]
+        cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3
+        cls_q = [[q for q, n in zip(queries, nterms) if cls_of(n) == c] for c in range(NCLS)]
         t0 = time.time()
         prof = [oidx.query_batch(args.op, cq, k=10, profile=True)[4] if cq else None for cq in cls_q]
         log("oracle profile pass (reference traversal A_skip): %.1fs" % (time.time() - t0))
@@ -206,7 +213,7 @@ def main():
         traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                       "kernel": "k_conjunctive<ranked,%s>" % ("TMAX=4" if dom == 0 else "TMAX=16"),
+                       "kernel": "k_conjunctive<ranked,TMAX=%d>" % (2, 4, 8, 16)[dom],
                        "kernel_ms": dom_ms, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
                        "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
                        "queries_in_kernel": cls_stats[dom][1]}

@@ -66,6 +66,7 @@ def lib():
         L.ds2i_hip_batch_prepare.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
         L.ds2i_hip_batch_run.argtypes = [vp, C.POINTER(Stats)]
         L.ds2i_hip_batch_class_stats.argtypes = [vp, C.c_int, C.POINTER(Stats), u32p]
+        L.ds2i_hip_batch_phase_cycles.argtypes = [vp, C.c_int, vp, C.c_int]
         L.ds2i_hip_batch_fetch.argtypes = [vp, vp, vp, vp, vp]
         L.ds2i_hip_batch_match_total.argtypes = [vp, u64p]
         L.ds2i_hip_batch_fetch_matches.argtypes = [vp, vp, vp]
@@ -249,6 +250,11 @@ class Batch:
         st, n = Stats(), C.c_uint32()
         _check(lib().ds2i_hip_batch_class_stats(self._h, cls, C.byref(st), C.byref(n)))
         return st, n.value
+
+    def phase_cycles(self, cls):
+        out = np.zeros(7, dtype=np.uint64)
+        _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), 7))
+        return dict(zip(("total", "docs", "freqs", "find", "member", "score", "topk"), out.tolist()))
 
     def fetch(self):
         nq = max(self.nq, 1)

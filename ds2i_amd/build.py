@@ -33,6 +33,8 @@ def _headers():
 
 def build(verbose=False, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("DS2I_EXTRA_CFLAGS", "").split()  # e.g. -DDS2I_PHASE_TIMING (diagnostic build)
+    force = force or bool(extra)
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
@@ -42,7 +44,7 @@ def build(verbose=False, force=False):
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):
-            cmd = [hipcc, "--offload-arch=" + ARCH] + COMMON + ["-c", sp, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH] + COMMON + extra + ["-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd[1:1] = ["-x", "hip"]
             if verbose:

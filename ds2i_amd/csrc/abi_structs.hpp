@@ -15,8 +15,10 @@ struct QTerm {
     uint32_t term;
 };
 
+enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_COUNT };
 struct Stats {
     unsigned long long docs_blocks, freqs_blocks, block_max_examined, algorithmic_bytes, postings_scored, rounds;
+    unsigned long long phase_cycles[PH_COUNT]; // summed over waves; only filled with -DDS2I_PHASE_TIMING
 };
 
 enum { OP_AND = 0, OP_AND_FREQ = 1, OP_OR = 2, OP_OR_FREQ = 3, OP_RANKED_AND = 4, OP_WAND = 5, OP_MAXSCORE = 6,

@@ -50,6 +50,9 @@ const char* ds2i_get_error() { return g_last_error.c_str(); }
     } while (0)
 
 // ------------------------------------------------------------------ handles
+// kernel classes by number of distinct query terms: <=2, <=4, <=8, <=16 (LDS per wave grows with it)
+static const int NCLS = 4;
+static inline int class_of(size_t nterms) { return nterms <= 2 ? 0 : nterms <= 4 ? 1 : nterms <= 8 ? 2 : 3; }
 struct ds2i_hip_index {
     int device = 0, kind = 0, num_cus = 256;
     uint64_t size = 0, num_docs = 0;
@@ -61,10 +64,10 @@ struct ds2i_hip_index {
     std::vector<uint64_t> list_end;
     std::vector<uint32_t> list_n;
     std::vector<float> max_term_weight;
-    hipStream_t stream[2] = {nullptr, nullptr};
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    Stats* d_stats = nullptr;     // [2]
-    unsigned int* d_ticket = nullptr; // [2]
+    hipStream_t stream[NCLS] = {};
+    hipEvent_t ev[2 + 2 * NCLS] = {};
+    Stats* d_stats = nullptr;     // [NCLS]
+    unsigned int* d_ticket = nullptr; // [NCLS]
 };
 
 struct ds2i_hip_batch {
@@ -72,8 +75,8 @@ struct ds2i_hip_batch {
     int op = 0;
     uint32_t k = 0, nq = 0;
     bool want_matches = false;
-    uint32_t ncls[2] = {0, 0}; // units per kernel class
-    uint32_t nqcls[2] = {0, 0}; // queries per kernel class
+    uint32_t ncls[NCLS] = {}; // units per kernel class
+    uint32_t nqcls[NCLS] = {}; // queries per kernel class
     uint32_t nunits = 0, nsplit = 0;
     std::vector<Unit> units;
     std::vector<uint32_t> q_unit_off;
@@ -86,7 +89,7 @@ struct ds2i_hip_batch {
     unsigned long long* d_unit_freq_sum = nullptr;
     QTerm* d_qterms = nullptr;
     uint32_t* d_qoff = nullptr;
-    uint32_t* d_order[2] = {nullptr, nullptr};
+    uint32_t* d_order[NCLS] = {};
     unsigned long long* d_count = nullptr;
     float* d_topk = nullptr;
     uint32_t* d_topk_len = nullptr;
@@ -94,8 +97,8 @@ struct ds2i_hip_batch {
     uint32_t* d_matches = nullptr;
     unsigned long long* d_match_off = nullptr;
     std::vector<unsigned long long> match_off;
-    float cls_ms[2] = {0, 0};
-    Stats cls_stats[2] = {};
+    float cls_ms[NCLS] = {};
+    Stats cls_stats[NCLS] = {};
 };
 
 namespace {
@@ -206,8 +209,8 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
         HIP_OK(hipMalloc((void**)&x->d_norm_lens, 4 * (wv.num_docs + 1)));
         HIP_OK(hipMemcpy(x->d_norm_lens, wv.norm_lens, 4 * wv.num_docs, hipMemcpyHostToDevice));
     }
-    HIP_OK(hipMalloc((void**)&x->d_stats, 2 * sizeof(Stats)));
-    HIP_OK(hipMalloc((void**)&x->d_ticket, 2 * sizeof(unsigned int)));
+    HIP_OK(hipMalloc((void**)&x->d_stats, NCLS * sizeof(Stats)));
+    HIP_OK(hipMalloc((void**)&x->d_ticket, NCLS * sizeof(unsigned int)));
     for (auto& s : x->stream) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     for (auto& e : x->ev) HIP_OK(hipEventCreate(&e));
     *out = x.release();
@@ -267,8 +270,7 @@ void ds2i_hip_batch_free(ds2i_hip_batch* b) {
     (void)hipSetDevice(b->idx->device);
     (void)hipFree(b->d_qterms);
     (void)hipFree(b->d_qoff);
-    (void)hipFree(b->d_order[0]);
-    (void)hipFree(b->d_order[1]);
+    for (auto& o : b->d_order) (void)hipFree(o);
     (void)hipFree(b->d_count);
     (void)hipFree(b->d_topk);
     (void)hipFree(b->d_topk_len);
@@ -309,7 +311,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     std::vector<uint32_t> t;
     std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
     const bool split_ok = conj && !(op & DS2I_OP_REFERENCE_ORDER);
-    double total_cost[2] = {0, 0};
+    double total_cost[NCLS] = {};
     for (uint32_t q = 0; q < nq; ++q) {
         if (query_offsets[q + 1] < query_offsets[q])
             return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
@@ -353,22 +355,24 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         }
         qoff[q + 1] = (uint32_t)qterms.size();
         qcost[q] = cost;
-        total_cost[tf.size() <= 4 ? 0 : 1] += cost;
+        total_cost[class_of(tf.size())] += cost;
     }
     for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
 
     // ---- work units: long conjunctive queries are split by block ranges of their shortest list so
     // that one giant query does not pin a single wavefront (SURVEY.md §7 "Load imbalance")
-    std::vector<std::pair<double, uint32_t>> cls[2];
+    std::vector<std::pair<double, uint32_t>> cls[NCLS];
     b->q_unit_off.assign(nq + 1, 0);
     std::vector<uint32_t> split_queries;
-    const double resident[2] = {idx->num_cus * 20.0, idx->num_cus * 7.0};
+    double all_cost = 0;
+    for (double c : total_cost) all_cost += c;
+    const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
-        const int c = nt <= 4 ? 0 : 1;
+        const int c = class_of(nt);
         uint32_t parts = 1;
         if (split_ok && nt && qnb0[q] > 1) {
-            const double target = std::max(48.0, total_cost[c] / (4.0 * resident[c]));
+            const double target = std::max(48.0, all_cost / (16.0 * resident));
             double want = std::floor(qcost[q] / target);
             parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
         }
@@ -402,7 +406,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     HIP_OK(upload((void**)&b->d_units, b->units.data(), b->units.size() * sizeof(Unit)));
     HIP_OK(upload((void**)&b->d_q_unit_off, b->q_unit_off.data(), b->q_unit_off.size() * 4));
     HIP_OK(upload((void**)&b->d_split, split_queries.data(), split_queries.size() * 4));
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NCLS; ++c) {
         std::stable_sort(cls[c].begin(), cls[c].end(),
                          [](auto const& l, auto const& r) { return l.first > r.first; }); // costliest first
         std::vector<uint32_t> order(cls[c].size());
@@ -433,14 +437,14 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_run: null batch");
     ds2i_hip_index* idx = b->idx;
     HIP_OK(hipSetDevice(idx->device));
-    hipStream_t s0 = idx->stream[0], s1 = idx->stream[1];
-    HIP_OK(hipMemsetAsync(idx->d_ticket, 0, 2 * sizeof(unsigned int), s0));
-    HIP_OK(hipMemsetAsync(idx->d_stats, 0, 2 * sizeof(Stats), s0));
-    // ev[0] start (s0) ; class 0 kernel on s0 between ev[1],ev[2] ; class 1 kernel on s1 between ev[3],ev[4] ; ev[5] end
+    hipStream_t s0 = idx->stream[0];
+    HIP_OK(hipMemsetAsync(idx->d_stats, 0, NCLS * sizeof(Stats), s0));
+    // ev[0] start (s0); class c kernel on stream c between ev[1+2c], ev[2+2c]; ev[1+2*NCLS] end (s0).
+    // Heavier LDS classes are enqueued first so their few workgroups are not starved by class 0.
     HIP_OK(hipEventRecord(idx->ev[0], s0));
-    HIP_OK(hipStreamWaitEvent(s1, idx->ev[0], 0));
-    for (int c = 0; c < 2; ++c) {
-        hipStream_t s = c ? s1 : s0;
+    for (int c = NCLS - 1; c >= 0; --c) {
+        hipStream_t s = idx->stream[c];
+        if (c) HIP_OK(hipStreamWaitEvent(s, idx->ev[0], 0));
         HIP_OK(hipEventRecord(idx->ev[1 + 2 * c], s));
         if (b->ncls[c]) {
             BatchArgs a{};
@@ -466,13 +470,11 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.unit_topk_len = b->d_unit_topk_len;
             a.unit_freq_sum = b->d_unit_freq_sum;
             a.stats = idx->d_stats + c;
-            const unsigned per_cu = c ? 7u : 24u; // resident one-wave workgroups per CU (LDS bound)
-            unsigned grid = (unsigned)std::min<uint64_t>(b->ncls[c], uint64_t(idx->num_cus) * per_cu);
-            HIP_OK(ds2i_launch_batch(b->op, c, &a, grid, s));
+            HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }
         HIP_OK(hipEventRecord(idx->ev[2 + 2 * c], s));
     }
-    HIP_OK(hipStreamWaitEvent(s0, idx->ev[4], 0));
+    for (int c = 1; c < NCLS; ++c) HIP_OK(hipStreamWaitEvent(s0, idx->ev[2 + 2 * c], 0));
     if (b->nsplit) {
         MergeArgs m{};
         m.split_queries = b->d_split;
@@ -490,27 +492,31 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
         m.out_freq_sum = b->d_freq_sum;
         HIP_OK(ds2i_launch_merge(&m, std::min<unsigned>(b->nsplit, 4096u), s0));
     }
-    HIP_OK(hipEventRecord(idx->ev[5], s0));
+    HIP_OK(hipEventRecord(idx->ev[1 + 2 * NCLS], s0));
     HIP_OK(hipStreamSynchronize(s0));
     float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[5]));
-    for (int c = 0; c < 2; ++c) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], idx->ev[1 + 2 * c], idx->ev[2 + 2 * c]));
-    HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, 2 * sizeof(Stats), hipMemcpyDeviceToHost));
+    HIP_OK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1 + 2 * NCLS]));
+    for (int c = 0; c < NCLS; ++c) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], idx->ev[1 + 2 * c], idx->ev[2 + 2 * c]));
+    HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     if (stats) {
         stats->kernel_ms = ms;
-        stats->docs_blocks_decoded = b->cls_stats[0].docs_blocks + b->cls_stats[1].docs_blocks;
-        stats->freqs_blocks_decoded = b->cls_stats[0].freqs_blocks + b->cls_stats[1].freqs_blocks;
-        stats->block_max_examined = b->cls_stats[0].block_max_examined + b->cls_stats[1].block_max_examined;
-        stats->algorithmic_bytes = b->cls_stats[0].algorithmic_bytes + b->cls_stats[1].algorithmic_bytes;
-        stats->postings_scored = b->cls_stats[0].postings_scored + b->cls_stats[1].postings_scored;
-        stats->rounds = b->cls_stats[0].rounds + b->cls_stats[1].rounds;
+        stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;
+        stats->algorithmic_bytes = stats->postings_scored = stats->rounds = 0;
+        for (int c = 0; c < NCLS; ++c) {
+            stats->docs_blocks_decoded += b->cls_stats[c].docs_blocks;
+            stats->freqs_blocks_decoded += b->cls_stats[c].freqs_blocks;
+            stats->block_max_examined += b->cls_stats[c].block_max_examined;
+            stats->algorithmic_bytes += b->cls_stats[c].algorithmic_bytes;
+            stats->postings_scored += b->cls_stats[c].postings_scored;
+            stats->rounds += b->cls_stats[c].rounds;
+        }
     }
     return DS2I_OK;
 }
 
 // per kernel-class timing / bytes of the last run (class 0: <=4 distinct terms, class 1: 5..16)
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries) {
-    if (!b || !out || cls < 0 || cls > 1) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_class_stats: bad argument");
+    if (!b || !out || cls < 0 || cls >= NCLS) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_class_stats: bad argument");
     out->kernel_ms = b->cls_ms[cls];
     out->docs_blocks_decoded = b->cls_stats[cls].docs_blocks;
     out->freqs_blocks_decoded = b->cls_stats[cls].freqs_blocks;
@@ -519,6 +525,13 @@ int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, 
     out->postings_scored = b->cls_stats[cls].postings_scored;
     out->rounds = b->cls_stats[cls].rounds;
     if (nqueries) *nqueries = b->nqcls[cls];
+    return DS2I_OK;
+}
+
+// diagnostic: phase cycle sums of class `cls` (all zero unless built with -DDS2I_PHASE_TIMING)
+int ds2i_hip_batch_phase_cycles(ds2i_hip_batch* b, int cls, uint64_t* out, int n) {
+    if (!b || !out || cls < 0 || cls >= NCLS) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_phase_cycles: bad argument");
+    for (int i = 0; i < n && i < ds2i_dev::PH_COUNT; ++i) out[i] = b->cls_stats[cls].phase_cycles[i];
     return DS2I_OK;
 }
 

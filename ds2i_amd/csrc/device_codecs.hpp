@@ -24,7 +24,7 @@ namespace ds2i_dev {
 
 enum { CODEC_OPTPFOR = 0, CODEC_VARINT = 1, CODEC_INTERPOLATIVE = 2, CODEC_QMX = 3, CODEC_MIXED = 4 };
 
-static constexpr uint32_t STAGE_DW = 160; // staging window, dwords (640 B)
+static constexpr uint32_t STAGE_DW = 128; // staging window, dwords (512 B); larger blocks fall back to global reads
 static constexpr uint32_t EXC_DW = 256;   // Simple16 exception scratch / generic out scratch
 
 DS2I_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -157,9 +157,9 @@ struct BitReader {
 
 // Decodes n (<=128) values into out[] (LDS, index order) as PREFIX SUMS P_i
 // (P_{n-1} = sum). Returns bytes consumed. The bit stream is inherently serial
-// (interpolative_coding.hpp:124-146), so lane 0 runs it alone; `stk` is >= 8 dwords of LDS
-// used as the explicit pre-order stack (packed offset<<8 | count). Bounds of a segment
-// [o,o+c) are read back from out[]: low = P_{o-1} (0 at o==0), high = P_{o+c}.
+// (interpolative_coding.hpp:124-146), so lane 0 runs it alone. `stk` (>= 24 dwords of LDS) is the
+// explicit pre-order stack of pending right children (packed offset<<8|count, low, high); bounds
+// stay in registers while walking down a left spine, so LDS is touched once per spine, not per value.
 DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p, uint32_t sum, uint32_t n,
                                               uint32_t* out, uint32_t* stk) {
     uint32_t consumed = 0;
@@ -172,20 +172,29 @@ DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p,
         if (n > 1) {
             BitReader br{&w, p, 0, 0, 0};
             int sp = 0;
-            stk[sp++] = n - 1; // offset 0, count n-1
-            while (sp > 0) {
-                uint32_t e = stk[--sp];
-                uint32_t o = e >> 8, c = e & 0xFFu;
+            uint32_t o = 0, c = n - 1, low = 0, high = sum;
+            for (;;) {
                 while (c > 0) {
                     uint32_t h = c >> 1;
-                    uint32_t low = o ? out[o - 1] : 0u;
-                    uint32_t high = out[o + c];
                     uint32_t val = low + br.read_int(high - low + 1);
                     out[o + h] = val;
                     uint32_t rc = c - h - 1;
-                    if (rc) stk[sp++] = ((o + h + 1) << 8) | rc;
+                    if (rc) {
+                        stk[3 * sp] = ((o + h + 1) << 8) | rc;
+                        stk[3 * sp + 1] = val;
+                        stk[3 * sp + 2] = high;
+                        ++sp;
+                    }
                     c = h;
+                    high = val;
                 }
+                if (!sp) break;
+                --sp;
+                uint32_t e = stk[3 * sp];
+                low = stk[3 * sp + 1];
+                high = stk[3 * sp + 2];
+                o = e >> 8;
+                c = e & 0xFFu;
             }
             consumed += (br.pos + 7) >> 3;
         }
@@ -194,64 +203,75 @@ DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p,
     return bcast(consumed, 0);
 }
 
-// ---- Simple16 layouts (selector -> per-value widths), packed 5 bits per entry is
-// overkill; use run descriptors: up to 3 runs of (count,width).
-__device__ static const uint8_t S16_RUNS[16][6] = {
-    {28, 1, 0, 0, 0, 0}, {7, 2, 14, 1, 0, 0}, {7, 1, 7, 2, 7, 1}, {14, 1, 7, 2, 0, 0},
-    {14, 2, 0, 0, 0, 0}, {1, 4, 8, 3, 0, 0},  {1, 3, 4, 4, 3, 3}, {7, 4, 0, 0, 0, 0},
-    {4, 5, 2, 4, 0, 0},  {2, 4, 4, 5, 0, 0},  {3, 6, 2, 5, 0, 0}, {2, 5, 3, 6, 0, 0},
-    {4, 7, 0, 0, 0, 0},  {1, 10, 2, 9, 0, 0}, {2, 14, 0, 0, 0, 0}, {1, 28, 0, 0, 0, 0}};
-__device__ static const uint8_t S16_COUNT[16] = {28, 21, 21, 21, 14, 9, 8, 7, 6, 6, 5, 5, 4, 3, 2, 1};
+// Simple16 layout descriptors: three (count,width) runs packed 5 bits each: c0 | w0<<5 | c1<<10 | ...
+#define S16D(c0, w0, c1, w1, c2, w2) ((c0) | ((w0) << 5) | ((c1) << 10) | ((w1) << 15) | ((c2) << 20) | ((w2) << 25))
+__device__ static const uint32_t S16_DESC[16] = {
+    S16D(28, 1, 0, 0, 0, 0), S16D(7, 2, 14, 1, 0, 0), S16D(7, 1, 7, 2, 7, 1), S16D(14, 1, 7, 2, 0, 0),
+    S16D(14, 2, 0, 0, 0, 0), S16D(1, 4, 8, 3, 0, 0),  S16D(1, 3, 4, 4, 3, 3), S16D(7, 4, 0, 0, 0, 0),
+    S16D(4, 5, 2, 4, 0, 0),  S16D(2, 4, 4, 5, 0, 0),  S16D(3, 6, 2, 5, 0, 0), S16D(2, 5, 3, 6, 0, 0),
+    S16D(4, 7, 0, 0, 0, 0),  S16D(1, 10, 2, 9, 0, 0), S16D(2, 14, 0, 0, 0, 0), S16D(1, 28, 0, 0, 0, 0)};
+
+// value k (0-based) of a Simple16 word with (wave-uniform) descriptor d: values fill the 28 payload
+// bits from the high end (FastPFor unpack order).
+DS2I_DEV uint32_t s16_value(uint32_t word, uint32_t d, uint32_t k) {
+    const uint32_t c0 = d & 31, w0 = (d >> 5) & 31, c1 = (d >> 10) & 31, w1 = (d >> 15) & 31, w2 = d >> 25;
+    uint32_t wdt, endbit;
+    if (k < c0) { wdt = w0; endbit = (k + 1) * w0; }
+    else if (k < c0 + c1) { wdt = w1; endbit = c0 * w0 + (k + 1 - c0) * w1; }
+    else { wdt = w2; endbit = c0 * w0 + c1 * w1 + (k + 1 - c0 - c1) * w2; }
+    return (word >> (28u - endbit)) & ((1u << wdt) - 1u);
+}
 
 // ---- OptPFor full block (128 values). Returns bytes consumed; values in v0/v1 (layout A).
-// scratch `exc` (EXC_DW dwords) and `out` (128 dwords) are LDS.
+// `exc` (EXC_DW dwords) and `out` (128 dwords) are LDS scratch.
+// Fast path: the block is dword aligned and lies inside the staging window (always the case for a
+// block_optpfor index, whose lists are re-based at upload so that every full block is aligned):
+// direct LDS dword indexing and v_alignbit extraction. Exceptions: one wave-uniform pass over the
+// Simple16 words, one lane per VALUE of a word; positions by wave prefix sum.
 DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* exc, uint32_t* out, uint32_t& v0,
                                  uint32_t& v1) {
     const uint32_t lane = lane_id();
     const uint32_t hdr = uniform(w.rd32(p));
     const uint32_t b = hdr >> 26;
-    const uint32_t nexc = (hdr >> 16) & 0x3FFu;
+    uint32_t nexc = (hdr >> 16) & 0x3FFu;
     const uint32_t ew = hdr & 0xFFFFu;
-    const uint8_t* data = p + 4 + 4 * ew;
     if (b >= 32) {
+        const uint8_t* data = p + 4;
         v0 = w.rd32(data + 4 * lane);
         v1 = w.rd32(data + 4 * (lane + 64));
         return 4 * (1 + 128);
     }
+    if (nexc > 128) nexc = 128; // corrupt header: stay inside the scratch arrays
+    const uint32_t total = 4 * (1 + ew + 4 * b);
+    const bool fast = (((uintptr_t)p & 3) == 0) && w.covers(p, total + 4);
+    const uint32_t* blk = w.st + ((uint32_t)(p - w.gbase) >> 2); // only dereferenced when fast
     if (b == 0) {
         v0 = v1 = 0;
     } else {
         const uint32_t mask = (1u << b) - 1u;
-        uint32_t bit0 = lane * b, bit1 = (lane + 64) * b;
-        uint64_t x0 = w.rd64(data + 4 * (bit0 >> 5));
-        uint64_t x1 = w.rd64(data + 4 * (bit1 >> 5));
-        v0 = (uint32_t)(x0 >> (bit0 & 31)) & mask;
-        v1 = (uint32_t)(x1 >> (bit1 & 31)) & mask;
+        const uint32_t bit0 = lane * b, bit1 = bit0 + 64 * b;
+        if (fast) {
+            const uint32_t* data = blk + 1 + ew;
+            const uint32_t i0 = bit0 >> 5, i1 = bit1 >> 5;
+            v0 = __builtin_amdgcn_alignbit(data[i0 + 1], data[i0], bit0 & 31) & mask;
+            v1 = __builtin_amdgcn_alignbit(data[i1 + 1], data[i1], bit1 & 31) & mask;
+        } else {
+            const uint8_t* data = p + 4 + 4 * ew;
+            uint64_t x0 = w.rd64(data + 4 * (bit0 >> 5));
+            uint64_t x1 = w.rd64(data + 4 * (bit1 >> 5));
+            v0 = (uint32_t)(x0 >> (bit0 & 31)) & mask;
+            v1 = (uint32_t)(x1 >> (bit1 & 31)) & mask;
+        }
     }
     if (nexc) {
-        // expand Simple16 words: lane j handles word j (+64 per round)
-        uint32_t total = 0;
         const uint32_t need = 2 * nexc;
-        for (uint32_t base = 0; base < ew && total < need; base += 64) {
-            uint32_t j = base + lane;
-            uint32_t word = (j < ew) ? w.rd32(p + 4 + 4 * j) : 0;
-            uint32_t sel = word >> 28;
-            uint32_t cnt = (j < ew) ? S16_COUNT[sel] : 0;
-            uint32_t incl = wave_incl_scan(cnt);
-            uint32_t off = total + incl - cnt;
-            if (j < ew) {
-                uint32_t pos = 28, k = 0;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    uint32_t rc = S16_RUNS[sel][2 * r], rw = S16_RUNS[sel][2 * r + 1];
-                    for (uint32_t c = 0; c < rc; ++c, ++k) {
-                        pos -= rw;
-                        uint32_t val = (word >> pos) & ((1u << rw) - 1u);
-                        if (off + k < EXC_DW) exc[off + k] = val;
-                    }
-                }
-            }
-            total += bcast(incl, 63);
+        uint32_t off = 0;
+        for (uint32_t j = 0; j < ew && off < need; ++j) {
+            const uint32_t word = uniform(fast ? blk[1 + j] : w.rd32(p + 4 + 4 * j));
+            const uint32_t d = S16_DESC[word >> 28];
+            const uint32_t cnt = (d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31);
+            if (lane < cnt && off + lane < EXC_DW) exc[off + lane] = s16_value(word, d, lane);
+            off += cnt;
         }
         out[lane] = v0;
         out[lane + 64] = v1;
@@ -259,10 +279,10 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
         // positions are delta coded: lpos_e = sum_{j<=e}(exc[j]+1) - 1
         uint32_t carry = 0;
         for (uint32_t base = 0; base < nexc; base += 64) {
-            uint32_t e = base + lane;
-            uint32_t d = (e < nexc) ? exc[e] + 1 : 0;
-            uint32_t incl = wave_incl_scan(d);
-            uint32_t lpos = carry + incl - 1;
+            const uint32_t e = base + lane;
+            const uint32_t dlt = (e < nexc) ? exc[e] + 1 : 0;
+            const uint32_t incl = wave_incl_scan(dlt);
+            const uint32_t lpos = carry + incl - 1;
             if (e < nexc && lpos < 128) out[lpos] |= (exc[e + nexc] + 1) << b;
             carry += bcast(incl, 63);
         }
@@ -271,7 +291,7 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
         v1 = out[lane + 64];
         wave_sync();
     }
-    return 4 * (1 + ew + 4 * b);
+    return total;
 }
 
 // ---- VarInt-G8IU full block. Values are scattered to out[] (LDS) then re-read.
@@ -365,10 +385,13 @@ DS2I_DEV uint32_t qmx_decode(Window& w, const uint8_t* p, uint32_t* out, uint32_
 // ---- generic block decode: n values (gap-1 / freq-1) -> v0,v1 (layout A; lanes >= n get 0).
 // `out` = 128-dword LDS scratch (may be the destination buffer itself), `exc` = EXC_DW dwords.
 // Returns bytes consumed.
-DS2I_DEV uint32_t decode_block(int codec, Window& w, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out,
+// CODEC_T >= 0 fixes the codec at compile time (dead code of the other decoders disappears).
+template <int CODEC_T>
+DS2I_DEV uint32_t decode_block(int codec_rt, Window& w, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out,
                                uint32_t* exc, uint32_t& v0, uint32_t& v1) {
     const uint32_t lane = lane_id();
     uint32_t consumed = 0;
+    const int codec = CODEC_T >= 0 ? CODEC_T : codec_rt;
     int c = codec;
     if (n == 128 && codec == CODEC_MIXED) {
         uint32_t t = uniform(w.rd8(p));

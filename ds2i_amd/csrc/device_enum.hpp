@@ -19,7 +19,16 @@ namespace ds2i_dev {
 enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
        M_QW, M_MAXW, M_END_LO, M_END_HI, M_WORDS };
 
-struct Ctx {
+#ifdef DS2I_PHASE_TIMING
+#define PT_BEGIN(cx) const unsigned long long pt_t0_ = __builtin_readcyclecounter()
+#define PT_END(cx, ph) (cx).s_phase[ph] += __builtin_readcyclecounter() - pt_t0_
+#else
+#define PT_BEGIN(cx) do {} while (0)
+#define PT_END(cx, ph) do {} while (0)
+#endif
+
+template <int CODEC_T>
+struct CtxT {
     uint32_t* docs;  // [TMAX][128]
     uint32_t* freqs; // [TMAX][128]
     uint32_t* meta;  // [TMAX][M_WORDS]
@@ -31,6 +40,7 @@ struct Ctx {
     // per-wave statistics (wave-uniform)
     uint32_t s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
     unsigned long long s_bytes;
+    unsigned long long s_phase[PH_COUNT];
 
     DS2I_DEV uint32_t* D(uint32_t s) const { return docs + 128 * s; }
     DS2I_DEV uint32_t* F(uint32_t s) const { return freqs + 128 * s; }
@@ -45,6 +55,7 @@ struct Ctx {
     DS2I_DEV void init_stats() {
         s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
         s_bytes = 0;
+        for (int i = 0; i < PH_COUNT; ++i) s_phase[i] = 0;
     }
     DS2I_DEV void flush_stats(Stats* st) {
         if (st && lane_id() == 0) {
@@ -54,11 +65,15 @@ struct Ctx {
             atomicAdd(&st->algorithmic_bytes, s_bytes);
             atomicAdd(&st->postings_scored, (unsigned long long)s_scored);
             atomicAdd(&st->rounds, (unsigned long long)s_rounds);
+#ifdef DS2I_PHASE_TIMING
+            for (int i = 0; i < PH_COUNT; ++i) atomicAdd(&st->phase_cycles[i], s_phase[i]);
+#endif
         }
     }
 
     // ---- decode_docs_block (block_posting_list.hpp:292-319)
     DS2I_DEV void decode_docs(uint32_t s, uint32_t b) {
+        PT_BEGIN(*this);
         const uint32_t lane = lane_id();
         const uint8_t* maxs = ptr(s, M_MAXS_LO);
         const uint32_t n = m(s, M_N), nb = m(s, M_NB);
@@ -79,7 +94,7 @@ struct Ctx {
         win.load(p, hint);
         uint32_t v0, v1;
         uint32_t* dst = D(s);
-        uint32_t consumed = decode_block(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
+        uint32_t consumed = decode_block<CODEC_T>(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
         uint32_t g0 = (lane < sz) ? v0 + 1u : 0u;
         uint32_t g1 = (lane + 64 < sz) ? v1 + 1u : 0u;
         uint32_t i0 = wave_incl_scan(g0);
@@ -103,10 +118,12 @@ struct Ctx {
         wave_sync();
         ++s_docs_blocks;
         s_bytes += 4 + consumed; // endpoint + docs part
+        PT_END(*this, PH_DOCS);
     }
 
     // ---- decode_freqs_block (block_posting_list.hpp:321-331)
     DS2I_DEV void decode_freqs(uint32_t s) {
+        PT_BEGIN(*this);
         const uint32_t lane = lane_id();
         const uint8_t* p = ptr(s, M_FREQ_LO);
         const uint32_t sz = m(s, M_SIZE);
@@ -116,13 +133,14 @@ struct Ctx {
         }
         uint32_t v0, v1;
         uint32_t* dst = F(s);
-        uint32_t consumed = decode_block(codec, win, p, 0xFFFFFFFFu, sz, dst, exc, v0, v1);
+        uint32_t consumed = decode_block<CODEC_T>(codec, win, p, 0xFFFFFFFFu, sz, dst, exc, v0, v1);
         dst[lane] = v0 + 1u;
         dst[lane + 64] = v1 + 1u;
         setm(s, M_FDEC, 1);
         wave_sync();
         ++s_freqs_blocks;
         s_bytes += consumed;
+        PT_END(*this, PH_FREQS);
     }
 
     // ---- ctor (block_posting_list.hpp:86-103). bind() only records the list geometry; open()
@@ -206,8 +224,8 @@ struct Ctx {
                 wave_sync();
                 return;
             }
-            s_bm_examined += blk - cur;
-            s_bytes += 4ull * (blk - cur);
+            s_bm_examined += (cur == 0xFFFFFFFFu) ? 1u : blk - cur;
+            s_bytes += 4ull * ((cur == 0xFFFFFFFFu) ? 1u : blk - cur);
             decode_docs(s, blk);
         }
         const uint32_t lane = lane_id();
@@ -260,6 +278,8 @@ struct Ctx {
         return uniform(F(s)[m(s, M_POS)]);
     }
 };
+
+typedef CtxT<-1> Ctx;
 
 // bm25::doc_term_weight (bm25.hpp:11-15). Compiled with -ffp-contract=off so the
 // float32 operation order matches the reference exactly.

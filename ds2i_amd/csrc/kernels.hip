@@ -25,14 +25,15 @@ struct Lds {
     uint32_t meta[TMAX][M_WORDS];
     uint32_t exc[EXC_DW];
     uint32_t st[STAGE_DW];
-    uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring)
-    uint32_t ord[TMAX];     // daat: ordered_enums
-    float ub[TMAX];         // maxscore upper_bounds
+    uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring; row 0 unused
+                            // by the conjunctive kernel and reused as ord/ub by the daat kernel)
+    DS2I_DEV uint32_t* ord() { return (uint32_t*)&pos[0][0]; }       // daat: ordered_enums [TMAX<=16]
+    DS2I_DEV float* ub() { return (float*)&pos[0][64]; }             // maxscore upper_bounds [TMAX<=16]
 };
 
-template <int TMAX>
-DS2I_DEV Ctx make_ctx(Lds<TMAX>& L, const BatchArgs& a) {
-    Ctx c;
+template <int CODEC_T, int TMAX>
+DS2I_DEV CtxT<CODEC_T> make_ctx(Lds<TMAX>& L, const BatchArgs& a) {
+    CtxT<CODEC_T> c;
     c.docs = &L.docs[0][0];
     c.freqs = &L.freqs[0][0];
     c.meta = &L.meta[0][0];
@@ -72,16 +73,19 @@ DS2I_DEV bool member_bsearch(const uint32_t* d, uint32_t c, bool want, uint32_t&
     return want && d[idx] == c;
 }
 
-template <bool RANKED, bool WITH_FREQS, int TMAX>
+template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T>
 __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
     __shared__ Lds<TMAX> L;
     const uint32_t lane = lane_id();
-    Ctx cx = make_ctx(L, a);
-    for (;;) {
-        const uint32_t tkt = next_ticket(a.ticket);
-        if (tkt >= a.nslice) break;
+    CtxT<CODEC_T> cx = make_ctx<CODEC_T>(L, a);
+    // one work unit per (single-wave) workgroup, costliest units first: the hardware dispatcher
+    // interleaves the workgroups of the concurrently running LDS classes as resources free up
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
         const Unit u = a.units[uid];
+#ifdef DS2I_PHASE_TIMING
+        const unsigned long long unit_t0 = __builtin_readcyclecounter();
+#endif
         const uint32_t q = u.q;
         const bool whole = u.nparts == 1;
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
@@ -108,7 +112,8 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
             // list 0 supplies the candidates of this round
             if (lo > cx.m(0, M_BMAX)) {
                 uint32_t cur = cx.m(0, M_CUR);
-                uint32_t blk = cx.find_block(0, cur + 1, lo);
+                uint32_t blk;
+                { PT_BEGIN(cx); blk = cx.find_block(0, cur + 1, lo); PT_END(cx, PH_FIND); }
                 if (blk >= u.blk_end) break;
                 cx.s_bm_examined += blk - cur;
                 cx.s_bytes += 4ull * (blk - cur);
@@ -123,7 +128,8 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                 uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
                 if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
                     uint32_t cur = cx.m(i, M_CUR);
-                    uint32_t blk = cx.find_block(i, cur + 1, amin);
+                    uint32_t blk;
+                    { PT_BEGIN(cx); blk = cx.find_block(i, cur + 1, amin); PT_END(cx, PH_FIND); }
                     if (blk >= cx.m(i, M_NB)) { // list i has nothing >= amin: no further match exists
                         cx.s_bm_examined += 1;
                         cx.s_bytes += 4;
@@ -131,10 +137,12 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                         finished = true;
                         break;
                     }
-                    cx.s_bm_examined += blk - cur;
-                    cx.s_bytes += 4ull * (blk - cur);
+                    // a lazily bound list is positioned by one 64-ary search, not a scan from block 0
+                    cx.s_bm_examined += (cur == 0xFFFFFFFFu) ? 1u : blk - cur;
+                    cx.s_bytes += 4ull * ((cur == 0xFFFFFFFFu) ? 1u : blk - cur);
                     cx.decode_docs(i, blk);
                 }
+                PT_BEGIN(cx);
                 uint32_t bm = cx.m(i, M_BMAX);
                 hi = bm < hi ? bm : hi;
                 bool w0 = al0 && c0 <= hi, w1 = al1 && c1 <= hi;
@@ -170,6 +178,7 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                     if (al0) L.pos[i][lane] = (uint8_t)p0;
                     if (al1) L.pos[i][lane + 64] = (uint8_t)p1;
                 }
+                PT_END(cx, PH_MEMBER);
             }
             // candidates that survived every list and lie inside the window are matches
             al0 = al0 && c0 <= hi;
@@ -187,6 +196,10 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                 count += ns;
                 if (RANKED || WITH_FREQS) {
                     wave_sync(); // L.pos writes visible
+#ifdef DS2I_PHASE_TIMING
+                    const unsigned long long sc_t0 = __builtin_readcyclecounter();
+                    const unsigned long long fr_before = cx.s_phase[PH_FREQS];
+#endif
                     float nl0 = 0.f, nl1 = 0.f, sc0 = 0.f, sc1 = 0.f;
                     if (RANKED) {
                         if (al0) nl0 = a.norm_lens[c0];
@@ -213,6 +226,10 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                         for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
                         fsum += fs;
                     }
+#ifdef DS2I_PHASE_TIMING
+                    const unsigned long long tk_t0 = __builtin_readcyclecounter();
+                    cx.s_phase[PH_SCORE] += tk_t0 - sc_t0 - (cx.s_phase[PH_FREQS] - fr_before);
+#endif
                     if (RANKED) {
                         // only scores that can enter the heap are inserted (serial, rare once warm)
                         for (int half = 0; half < 2; ++half) {
@@ -226,11 +243,17 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                             }
                         }
                     }
+#ifdef DS2I_PHASE_TIMING
+                    cx.s_phase[PH_TOPK] += __builtin_readcyclecounter() - tk_t0;
+#endif
                 }
             }
             if (hi == 0xFFFFFFFFu) break;
             lo = hi + 1;
         }
+#ifdef DS2I_PHASE_TIMING
+        cx.s_phase[PH_TOTAL] += __builtin_readcyclecounter() - unit_t0;
+#endif
         if (whole) {
             if (lane == 0) {
                 a.out_count[q] = RANKED ? tk.n : count;
@@ -284,8 +307,8 @@ __global__ void __launch_bounds__(64) k_merge(MergeArgs a) {
 }
 
 // ------------------------------------------------------------------ document-at-a-time
-template <int TMAX>
-DS2I_DEV float score_of(Ctx& cx, uint32_t s, float norm_len) {
+template <int TMAX, class CX>
+DS2I_DEV float score_of(CX& cx, uint32_t s, float norm_len) {
     return __uint_as_float(cx.m(s, M_QW)) * doc_term_weight(cx.freq(s), norm_len);
 }
 
@@ -294,11 +317,11 @@ template <int TMAX, class Key>
 DS2I_DEV void sort_ord(Lds<TMAX>& L, uint32_t n, Key key) {
     if (lane_id() == 0) {
         for (uint32_t i = 1; i < n; ++i) {
-            uint32_t v = L.ord[i];
+            uint32_t v = L.ord()[i];
             auto kv = key(v);
             uint32_t j = i;
-            while (j > 0 && kv < key(L.ord[j - 1])) { L.ord[j] = L.ord[j - 1]; --j; }
-            L.ord[j] = v;
+            while (j > 0 && kv < key(L.ord()[j - 1])) { L.ord()[j] = L.ord()[j - 1]; --j; }
+            L.ord()[j] = v;
         }
     }
     wave_sync();
@@ -308,12 +331,10 @@ template <int OP, int TMAX>
 __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     __shared__ Lds<TMAX> L;
     const uint32_t lane = lane_id();
-    Ctx cx = make_ctx(L, a);
+    Ctx cx = make_ctx<-1>(L, a);
     const uint32_t N = a.num_docs;
     constexpr bool RANKED = OP >= OP_RANKED_AND;
-    for (;;) {
-        const uint32_t tkt = next_ticket(a.ticket);
-        if (tkt >= a.nslice) break;
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t q = a.units[a.order[tkt]].q; // one unit per query for these operators
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         unsigned long long count = 0, fsum = 0;
@@ -381,7 +402,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             }
         } else if (OP == OP_WAND) {
             // queries.hpp:236-305
-            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord[i] = i;
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord()[i] = i;
             wave_sync();
             auto by_docid = [&](uint32_t s) { return L.meta[s][M_DOCID]; };
             sort_ord(L, nt, by_docid);
@@ -390,17 +411,17 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 uint32_t pivot = 0;
                 bool found = false;
                 for (pivot = 0; pivot < nt; ++pivot) {
-                    uint32_t s = uniform(L.ord[pivot]);
+                    uint32_t s = uniform(L.ord()[pivot]);
                     if (cx.docid(s) == N) break;
                     upper += __uint_as_float(cx.m(s, M_MAXW));
                     if (tk.would_enter(upper)) { found = true; break; }
                 }
                 if (!found) break;
-                const uint32_t pivot_id = cx.docid(uniform(L.ord[pivot]));
-                if (pivot_id == cx.docid(uniform(L.ord[0]))) {
+                const uint32_t pivot_id = cx.docid(uniform(L.ord()[pivot]));
+                if (pivot_id == cx.docid(uniform(L.ord()[0]))) {
                     float score = 0.f, nl = norm_len(pivot_id);
                     for (uint32_t j = 0; j < nt; ++j) {
-                        uint32_t s = uniform(L.ord[j]);
+                        uint32_t s = uniform(L.ord()[j]);
                         if (cx.docid(s) != pivot_id) break;
                         score += score_of<TMAX>(cx, s, nl);
                         cx.next(s);
@@ -409,12 +430,12 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                     sort_ord(L, nt, by_docid);
                 } else {
                     uint32_t nl_ = pivot;
-                    while (cx.docid(uniform(L.ord[nl_])) == pivot_id) --nl_;
-                    cx.next_geq(uniform(L.ord[nl_]), pivot_id);
+                    while (cx.docid(uniform(L.ord()[nl_])) == pivot_id) --nl_;
+                    cx.next_geq(uniform(L.ord()[nl_]), pivot_id);
                     if (lane == 0) {
                         for (uint32_t j = nl_ + 1; j < nt; ++j) {
-                            uint32_t x = L.ord[j], y = L.ord[j - 1];
-                            if (L.meta[x][M_DOCID] < L.meta[y][M_DOCID]) { L.ord[j] = y; L.ord[j - 1] = x; }
+                            uint32_t x = L.ord()[j], y = L.ord()[j - 1];
+                            if (L.meta[x][M_DOCID] < L.meta[y][M_DOCID]) { L.ord()[j] = y; L.ord()[j - 1] = x; }
                             else break;
                         }
                     }
@@ -422,16 +443,16 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 }
             }
         } else { // OP_MAXSCORE, queries.hpp:514-577
-            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord[i] = i;
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord()[i] = i;
             wave_sync();
             auto by_maxw = [&](uint32_t s) { return __uint_as_float(L.meta[s][M_MAXW]); };
             sort_ord(L, nt, by_maxw);
             if (lane == 0) {
                 float acc = 0.f;
                 for (uint32_t i = 0; i < nt; ++i) {
-                    float mw = __uint_as_float(L.meta[L.ord[i]][M_MAXW]);
+                    float mw = __uint_as_float(L.meta[L.ord()[i]][M_MAXW]);
                     acc = i ? acc + mw : mw;
-                    L.ub[i] = acc;
+                    L.ub()[i] = acc;
                 }
             }
             wave_sync();
@@ -441,7 +462,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 float score = 0.f, nl = norm_len(cur);
                 uint32_t nxt = N;
                 for (uint32_t i = non_ess; i < nt; ++i) {
-                    uint32_t s = uniform(L.ord[i]);
+                    uint32_t s = uniform(L.ord()[i]);
                     if (cx.docid(s) == cur) {
                         score += score_of<TMAX>(cx, s, nl);
                         cx.next(s);
@@ -450,14 +471,14 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                     nxt = d < nxt ? d : nxt;
                 }
                 for (uint32_t i = non_ess; i-- > 0;) {
-                    float ub = __uint_as_float(uniform(__float_as_uint(L.ub[i])));
+                    float ub = __uint_as_float(uniform(__float_as_uint(L.ub()[i])));
                     if (!tk.would_enter(score + ub)) break;
-                    uint32_t s = uniform(L.ord[i]);
+                    uint32_t s = uniform(L.ord()[i]);
                     cx.next_geq(s, cur);
                     if (cx.docid(s) == cur) score += score_of<TMAX>(cx, s, nl);
                 }
                 if (tk.insert(score)) {
-                    while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub[non_ess])))))
+                    while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub()[non_ess])))))
                         ++non_ess;
                 }
                 cur = nxt;
@@ -480,7 +501,7 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
     ba.arena = a.arena;
     ba.codec = a.codec;
     ba.num_docs = a.num_docs;
-    Ctx cx = make_ctx(L, ba);
+    Ctx cx = make_ctx<-1>(L, ba);
     const uint32_t lane = lane_id();
     const uint32_t n = a.term.n, nb = (n + 127u) >> 7;
     const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
@@ -527,9 +548,20 @@ template <int TMAX>
 static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
     dim3 g(grid), b(64);
     switch (op) {
-    case OP_AND: hipLaunchKernelGGL((k_conjunctive<false, false, TMAX>), g, b, 0, s, a); break;
-    case OP_AND_FREQ: hipLaunchKernelGGL((k_conjunctive<false, true, TMAX>), g, b, 0, s, a); break;
-    case OP_RANKED_AND: hipLaunchKernelGGL((k_conjunctive<true, true, TMAX>), g, b, 0, s, a); break;
+    // the conjunctive kernels are specialised for block_optpfor (the benchmark codec); every other
+    // codec goes through the runtime-dispatch instantiation (CODEC_T = -1)
+    case OP_AND:
+        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, -1>), g, b, 0, s, a);
+        break;
+    case OP_AND_FREQ:
+        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, -1>), g, b, 0, s, a);
+        break;
+    case OP_RANKED_AND:
+        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);
+        break;
     case OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
     case OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
     case OP_WAND: hipLaunchKernelGGL((k_daat<OP_WAND, TMAX>), g, b, 0, s, a); break;
@@ -548,10 +580,15 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
 
 extern "C" {
 
-// tmax_class: 0 -> TMAX 4, 1 -> TMAX 16
+// tmax_class: 0 -> TMAX 2, 1 -> TMAX 4, 2 -> TMAX 8, 3 -> TMAX 16 (LDS footprint per wave grows with TMAX)
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
-    return tmax_class == 0 ? ds2i_launch::launch_t<4>(op, a, grid, s) : ds2i_launch::launch_t<16>(op, a, grid, s);
+    switch (tmax_class) {
+    case 0: return ds2i_launch::launch_t<2>(op, a, grid, s);
+    case 1: return ds2i_launch::launch_t<4>(op, a, grid, s);
+    case 2: return ds2i_launch::launch_t<8>(op, a, grid, s);
+    default: return ds2i_launch::launch_t<16>(op, a, grid, s);
+    }
 }
 
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s) {

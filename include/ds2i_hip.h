@@ -110,9 +110,12 @@ int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t
 int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
                            const uint32_t* query_offsets, uint32_t nq, int want_matches, ds2i_hip_batch** out);
 int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats);
-/* per kernel class of the last run (class 0: <=4 distinct terms, class 1: 5..16 -- two template
- * instantiations with different LDS footprints, launched concurrently on two streams) */
+/* per kernel class of the last run (class 0: <=2 distinct terms, 1: 3..4, 2: 5..8, 3: 9..16 -- four
+ * template instantiations with different LDS footprints, launched concurrently on four streams) */
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
+/* diagnostic build only (-DDS2I_PHASE_TIMING): per-phase shader-cycle sums {total, docs decode, freqs
+ * decode, block search, membership, scoring, top-k} of class cls; zeros otherwise */
+int ds2i_hip_batch_phase_cycles(ds2i_hip_batch* b, int cls, uint64_t* out, int n);
 int ds2i_hip_batch_fetch(ds2i_hip_batch* b, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len,
                          uint64_t* out_freq_sum);
 /* doc-id lists of `and` (want_matches): match_offsets has nq+1 entries; matches has match_offsets[nq] */
