@@ -56,19 +56,11 @@ def main():
     import torch
     import ds2i_amd as d
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(0)
+    from ds2i_amd import sharding as sh
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the query path has no CPU fallback)")
+    rank, local_rank, world, dist = sh.init_distributed("nccl")  # "nccl" is RCCL on ROCm; None when N == 1
+    torch.cuda.set_device(local_rank)
     d.lib()  # fail loudly if the HIP extension is missing
 
     def barrier():
@@ -89,10 +81,7 @@ def main():
             rate = n / (time.time() - t0)
             wl = "gov2" if 1.0e9 / rate < 150 else "c2"
             log("index build rate %.1f Mpostings/s on %d threads -> workload %s" % (rate / 1e6, threads, wl))
-        if dist is not None:
-            t = torch.tensor([1 if wl == "gov2" else 0], device="cuda")
-            dist.broadcast(t, 0)
-            wl = "gov2" if int(t.item()) else "c2"
+        wl = "gov2" if sh.broadcast_int(dist, 1 if wl == "gov2" else 0) else "c2"
     W = WORKLOADS[wl]
     p = d.SynthParams(seed=W["seed"], num_docs=W["num_docs"], num_terms=W["num_terms"], zipf_exp=W["zipf_exp"],
                       top_df_frac=W["top_df_frac"], min_len=W["min_len"], clustered_every=W["clustered_every"])
@@ -100,21 +89,13 @@ def main():
     tag = "ds2i_bench_%s_%s_%d" % (wl, args.codec, os.getppid() if world > 1 else os.getpid())
     f_idx, f_wand = os.path.join(shm, tag + ".idx"), os.path.join(shm, tag + ".wand")
     postings = 0
+    img = wand = None
     if rank == 0:
         t0 = time.time()
         img, wand, postings = d.synth_build(p, args.codec, threads)
         log("built %s index: %d postings, %.1f MB, %.1fs" % (wl, postings, len(img) / 1e6, time.time() - t0))
-        if world > 1:
-            open(f_idx, "wb").write(img)
-            open(f_wand, "wb").write(wand)
-    if dist is not None:
-        dist.barrier()
-        if rank != 0:
-            img, wand = open(f_idx, "rb").read(), open(f_wand, "rb").read()
-        dist.barrier()
-        if rank == 0:
-            os.remove(f_idx)
-            os.remove(f_wand)
+    img = sh.share_bytes(dist, rank, img, f_idx)
+    wand = sh.share_bytes(dist, rank, wand, f_wand)
     # each rank: full index replica in its GPU's HBM, its own 4096-query batch (weak scaling, no collective)
     queries = d.synth_queries(0x51E21 + rank, p.num_terms, args.batch)
     idx = d.Index(args.codec, img, wand, device=local_rank)
@@ -132,10 +113,7 @@ def main():
             kern_ms[c] += batch.class_stats(c)[0].kernel_ms
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sh.max_over_ranks(dist, elapsed)
     count, topk, tlen, _ = batch.fetch()
 
     if rank != 0:

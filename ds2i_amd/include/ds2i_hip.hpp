@@ -1,0 +1,142 @@
+// ds2i_hip.hpp -- header-only C++ adaptor over the C ABI (include/ds2i_hip.h) that presents the two
+// template concepts ds2i's drivers are written against, so queries.cpp-style code can switch to the
+// MI355X path by changing a typedef:
+//
+//   Index concept (block_freq_index.hpp:72-94)          -> ds2i_hip::gpu_index
+//       size(), num_docs(), operator[](term) -> document_enumerator, warmup(term)
+//       document_enumerator (block_posting_list.hpp:84-186): docid(), freq(), next(), next_geq(),
+//       move(), reset(), size(), position(); exhausted <=> docid() == num_docs()
+//   Query-operator concept (queries.hpp:35-591, queries.cpp:13-28) -> ds2i_hip::gpu_query_op<OP>
+//       uint64_t operator()(Index const&, term_id_vec) ; topk() for ranked operators
+//       + the batched form this framework adds: operator()(Index const&, vector<term_id_vec> const&)
+//
+// Errors: the C ABI's negative codes become std::runtime_error (builders in the reference throw
+// std::invalid_argument / std::runtime_error too; its query path only asserts).
+#pragma once
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ds2i_hip.h"
+
+namespace ds2i_hip {
+
+typedef uint32_t term_id_type;
+typedef std::vector<term_id_type> term_id_vec;
+
+inline void check(int rc, const char* what) {
+    if (rc != DS2I_OK) throw std::runtime_error(std::string(what) + ": " + ds2i_hip_last_error());
+}
+
+class gpu_index {
+public:
+    // The whole list is decoded on the GPU once (k_decode_list) and iterated on the host: this keeps
+    // the reference's per-posting enumerator API usable (tools, verification) -- the query operators
+    // below never go through it.
+    class document_enumerator {
+    public:
+        document_enumerator() {}
+        document_enumerator(std::vector<uint32_t>&& docs, std::vector<uint32_t>&& freqs, uint64_t universe)
+            : m_docs(std::move(docs)), m_freqs(std::move(freqs)), m_universe(universe) {}
+        void reset() { m_pos = 0; }
+        void next() { ++m_pos; }
+        void next_geq(uint64_t lower_bound) {
+            while (m_pos < m_docs.size() && m_docs[m_pos] < lower_bound) ++m_pos;
+        }
+        void move(uint64_t pos) { m_pos = pos; }
+        uint64_t docid() const { return m_pos < m_docs.size() ? m_docs[m_pos] : m_universe; }
+        uint64_t freq() const { return m_freqs[m_pos]; }
+        uint64_t position() const { return m_pos; }
+        uint64_t size() const { return m_docs.size(); }
+
+    private:
+        std::vector<uint32_t> m_docs, m_freqs;
+        uint64_t m_universe = 0;
+        uint64_t m_pos = 0;
+    };
+
+    gpu_index() {}
+    // index_kind = enum ds2i_hip_index_kind; the images are the reference's on-disk files (mmap them)
+    gpu_index(int index_kind, const void* image, size_t bytes, const void* wand = nullptr, size_t wand_bytes = 0,
+              int device = 0) {
+        check(ds2i_hip_index_open(device, index_kind, image, bytes, wand, wand_bytes, &m_h), "ds2i_hip_index_open");
+    }
+    gpu_index(gpu_index const&) = delete;
+    gpu_index& operator=(gpu_index const&) = delete;
+    gpu_index(gpu_index&& o) : m_h(o.m_h) { o.m_h = nullptr; }
+    ~gpu_index() { ds2i_hip_index_close(m_h); }
+
+    size_t size() const { return (size_t)ds2i_hip_index_size(m_h); }
+    uint64_t num_docs() const { return ds2i_hip_index_num_docs(m_h); }
+    void warmup(size_t) const {} // resident in HBM; nothing to touch (block_freq_index.hpp:96-114)
+    document_enumerator operator[](size_t term) const {
+        uint64_t n = 0;
+        check(ds2i_hip_list_size(m_h, (uint32_t)term, &n), "ds2i_hip_list_size");
+        std::vector<uint32_t> d(n), f(n);
+        check(ds2i_hip_decode_list(m_h, (uint32_t)term, d.data(), f.data(), n, &n), "ds2i_hip_decode_list");
+        return document_enumerator(std::move(d), std::move(f), num_docs());
+    }
+    ds2i_hip_index* handle() const { return m_h; }
+
+private:
+    ds2i_hip_index* m_h = nullptr;
+};
+
+template <int OP>
+class gpu_query_op {
+public:
+    explicit gpu_query_op(uint64_t k = 10) : m_k((uint32_t)k) {}
+    // reference signature: ranked operators are constructed (wand_data const&, k); the wand data already
+    // lives next to the index in HBM, so it is accepted and ignored
+    template <class WandData> gpu_query_op(WandData const&, uint64_t k) : m_k((uint32_t)k) {}
+
+    // queries.cpp:26-28 -- one query (a batch of one)
+    uint64_t operator()(gpu_index const& index, term_id_vec const& terms) {
+        std::vector<term_id_vec> one(1, terms);
+        return (*this)(index, one)[0];
+    }
+    // the batch boundary: all queries cross the C ABI at once
+    std::vector<uint64_t> const& operator()(gpu_index const& index, std::vector<term_id_vec> const& queries) {
+        const uint32_t nq = (uint32_t)queries.size();
+        std::vector<uint32_t> terms, offs(nq + 1, 0);
+        for (uint32_t q = 0; q < nq; ++q) {
+            terms.insert(terms.end(), queries[q].begin(), queries[q].end());
+            offs[q + 1] = (uint32_t)terms.size();
+        }
+        if (terms.empty()) terms.push_back(0);
+        m_counts.assign(nq, 0);
+        const uint32_t k = ranked() ? m_k : 1;
+        std::vector<float> topk((size_t)nq * k, -std::numeric_limits<float>::infinity());
+        std::vector<uint32_t> len(nq, 0);
+        check(ds2i_hip_query_batch(index.handle(), OP, k, terms.data(), offs.data(), nq, m_counts.data(), topk.data(),
+                                   len.data(), &m_stats),
+              "ds2i_hip_query_batch");
+        m_topk.assign(nq, std::vector<float>());
+        if (ranked())
+            for (uint32_t q = 0; q < nq; ++q) m_topk[q].assign(topk.begin() + (size_t)q * k, topk.begin() + (size_t)q * k + len[q]);
+        return m_counts;
+    }
+    std::vector<float> const& topk() const { return m_topk.back(); }          // last query (reference shape)
+    std::vector<std::vector<float>> const& topk_batch() const { return m_topk; }
+    ds2i_hip_stats const& stats() const { return m_stats; }
+    static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
+
+private:
+    uint32_t m_k;
+    std::vector<uint64_t> m_counts;
+    std::vector<std::vector<float>> m_topk;
+    ds2i_hip_stats m_stats{};
+};
+
+typedef gpu_query_op<DS2I_OP_AND> and_query;
+typedef gpu_query_op<DS2I_OP_AND_FREQ> and_freq_query;
+typedef gpu_query_op<DS2I_OP_OR> or_query;
+typedef gpu_query_op<DS2I_OP_OR_FREQ> or_freq_query;
+typedef gpu_query_op<DS2I_OP_RANKED_AND> ranked_and_query;
+typedef gpu_query_op<DS2I_OP_WAND> wand_query;
+typedef gpu_query_op<DS2I_OP_MAXSCORE> maxscore_query;
+typedef gpu_query_op<DS2I_OP_RANKED_OR> ranked_or_query;
+
+} // namespace ds2i_hip

@@ -180,3 +180,27 @@ def test_full_size_c2_properties(built_lib):
         assert np.array_equal(l_or, l2)
         f = np.isfinite(t_or)
         np.testing.assert_allclose(t2[f], t_or[f], rtol=RTOL)
+
+
+def test_queries_cli_and_cpp_adaptor(coll, queries, images, tmp_path):
+    """ds2i_amd/tools/queries: the reference driver's argv, query-log format and stats_line keys (queries.cpp:42-60)."""
+    import json
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ds2i_amd", "tools", "queries")
+    if not os.path.exists(tool):
+        subprocess.check_call(["make", "-C", os.path.dirname(tool), "-s"])
+    idx_path, wand_path = tmp_path / "idx", tmp_path / "wand"
+    idx_path.write_bytes(images[0]["block_optpfor"])
+    wand_path.write_bytes(images[1])
+    log = "\n".join(" ".join(str(t) for t in q) for q in queries if q) + "\n"
+    r = subprocess.run([tool, "block_optpfor", "and:ranked_and:wand:bogus", str(idx_path), str(wand_path)], input=log,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [l["query"] for l in lines] == ["and", "ranked_and", "wand"]
+    for l in lines:
+        assert l["type"] == "block_optpfor" and l["avg"] > 0 and l["q50"] <= l["q90"] <= l["q95"] and l["qps"] > 0
+    assert "Unsupported query type: bogus" in r.stderr
+    r = subprocess.run([tool, "no_such_index", "and", str(idx_path)], input=log, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "ERROR: Unknown type" in r.stderr  # queries.cpp:149-151
