@@ -26,10 +26,10 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # BASELINE.json configs[1]: synthetic 1M-doc Zipf collection, batch = 4096 queries
     "c2": dict(num_docs=1_000_000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128, clustered_every=4,
-               seed=0xD5210002, label="synthetic 1M-doc Zipf (configs[1]), block_optpfor, ranked_and, batch=4096"),
+               seed=0xD5210002, label="synthetic 1M-doc Zipf (configs[1])"),
     # BASELINE.json metric ("GOV2-scale"): 25M docs, ~1.0 B postings (SURVEY.md §8(d) C3/C4 shape)
     "gov2": dict(num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
-                 seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config), block_optpfor, ranked_and, batch=4096"),
+                 seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config)"),
 }
 NCLS = 4  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -136,7 +136,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "mean_us_per_query": 1e6 * elapsed / (args.batch * args.steps),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
-        "config": {"workload": W["label"], "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
+        "config": {"workload": "%s, %s, %s, batch=%d" % (W["label"], args.codec, args.op, args.batch), "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
                    "batch_per_gpu": args.batch, "k": 10, "parallelism": "query-batch sharding x%d, index replicated" % world},
     }
 
@@ -186,12 +186,14 @@ def main():
     else:
         src = "oracle-counted reference traversal (A_skip)"
     achieved = a_skip_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
-    if args.traffic_json and os.path.exists(args.traffic_json):
-        traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+    traffic = None  # PMC counters cannot be collected inside this process: taken from the committed rocprofv3 passes
+    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % wl)
+    if os.path.exists(tj) and args.op == "ranked_and" and args.codec == "block_optpfor" and dom == 0:
+        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                       "kernel": "k_conjunctive<ranked,TMAX=%d>" % (2, 4, 8, 16)[dom],
+                       "kernel": "%s<%s,TMAX=%d>" % ("k_conjunctive" if args.op in ("and", "and_freq", "ranked_and") else "k_daat",
+                                                     args.op, (2, 4, 8, 16)[dom]),
                        "kernel_ms": dom_ms, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
                        "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
                        "queries_in_kernel": cls_stats[dom][1]}

@@ -72,6 +72,7 @@ def lib():
         L.ds2i_hip_batch_fetch_matches.argtypes = [vp, vp, vp]
         L.ds2i_hip_batch_free.argtypes = [vp]
         L.ds2i_hip_batch_free.restype = None
+        L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
         # build side
         L.ds2i_blob_data.argtypes = [vp]
@@ -317,6 +318,11 @@ class Index:
         got = C.c_uint64()
         _check(lib().ds2i_hip_decode_list(self._h, term, _ptr(d), _ptr(f), n, C.byref(got)))
         return d, f
+
+    def calibration_read(self):
+        n = C.c_uint64()
+        _check(lib().ds2i_hip_calibration_read(self._h, C.byref(n)))
+        return n.value
 
     def query_batch(self, op, queries, k=10):
         terms, offs = _flatten(queries)

@@ -27,6 +27,7 @@ extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_calib_read(const uint32_t* base, unsigned long long ndw, uint32_t* out, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s);
 }
 
@@ -370,25 +371,46 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = class_of(nt);
-        uint32_t parts = 1;
-        if (split_ok && nt && qnb0[q] > 1) {
-            const double target = std::max(48.0, all_cost / (16.0 * resident));
-            double want = std::floor(qcost[q] / target);
-            parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
-        }
-        const uint32_t nb0 = std::max(1u, qnb0[q]);
-        const uint32_t per = (nb0 + parts - 1) / parts;
-        parts = (nb0 + per - 1) / per;
-        if (parts > 1) split_queries.push_back(q);
-        if (q < nq) ++b->nqcls[c];
-        for (uint32_t j = 0; j < parts; ++j) {
-            Unit u;
-            u.q = q;
-            u.blk_begin = j * per;
-            u.blk_end = std::min(nb0, (j + 1) * per);
-            u.nparts = parts;
-            cls[c].emplace_back(qcost[q] / parts, (uint32_t)b->units.size());
-            b->units.push_back(u);
+        const double target = std::max(48.0, all_cost / (16.0 * resident));
+        if (conj) {
+            uint32_t parts = 1;
+            if (split_ok && nt && qnb0[q] > 1) {
+                double want = std::floor(qcost[q] / target);
+                parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
+            }
+            const uint32_t nb0 = std::max(1u, qnb0[q]);
+            const uint32_t per = (nb0 + parts - 1) / parts;
+            parts = (nb0 + per - 1) / per;
+            if (parts > 1) split_queries.push_back(q);
+            ++b->nqcls[c];
+            for (uint32_t j = 0; j < parts; ++j) {
+                Unit u;
+                u.q = q;
+                u.blk_begin = j * per;
+                u.blk_end = std::min(nb0, (j + 1) * per);
+                u.nparts = parts;
+                cls[c].emplace_back(qcost[q] / parts, (uint32_t)b->units.size());
+                b->units.push_back(u);
+            }
+        } else {
+            // or / ranked_or / wand / maxscore: units are equal-width doc-id ranges; every part keeps its own
+            // top-k (its own pruning threshold), the merge is exact
+            const uint32_t N = (uint32_t)idx->num_docs;
+            uint32_t parts = 1;
+            if (nt && N > 1) parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / target)), std::min<double>(N, 1024.0));
+            const uint32_t width = (N + parts - 1) / parts;
+            parts = width ? (N + width - 1) / width : 1;
+            if (parts > 1) split_queries.push_back(q);
+            ++b->nqcls[c];
+            for (uint32_t j = 0; j < parts; ++j) {
+                Unit u;
+                u.q = q;
+                u.blk_begin = j * width;
+                u.blk_end = (uint32_t)std::min<uint64_t>(N, (uint64_t)(j + 1) * width);
+                u.nparts = parts;
+                cls[c].emplace_back(qcost[q] / parts, (uint32_t)b->units.size());
+                b->units.push_back(u);
+            }
         }
         b->q_unit_off[q + 1] = (uint32_t)b->units.size();
     }
@@ -592,6 +614,18 @@ int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t
     if (!rc) rc = ds2i_hip_batch_fetch(b, out_count, out_topk, out_topk_len, nullptr);
     ds2i_hip_batch_free(b);
     return rc;
+}
+
+// profiling aid: one pass over the whole index arena with the decoders' load shape (4 B per lane); the
+// bytes read are returned so that rocprofv3's FETCH_SIZE can be calibrated against a known count
+int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read) {
+    if (!idx || !bytes_read) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_calibration_read: null argument");
+    HIP_OK(hipSetDevice(idx->device));
+    const unsigned long long ndw = idx->arena_bytes / 4;
+    HIP_OK(ds2i_launch_calib_read((const uint32_t*)idx->d_arena, ndw, (uint32_t*)idx->d_ticket, idx->num_cus * 32, idx->stream[0]));
+    HIP_OK(hipStreamSynchronize(idx->stream[0]));
+    *bytes_read = ndw * 4;
+    return DS2I_OK;
 }
 
 int ds2i_hip_selftest_scan(int device, const uint32_t* in, uint32_t* out, uint32_t rows) {

@@ -110,7 +110,7 @@ struct CtxT {
             mm[M_SIZE] = sz;
             mm[M_BMAX] = bmax;
             mm[M_POS] = 0;
-            mm[M_DOCID] = d0;
+            mm[M_DOCID] = d0 < num_docs ? d0 : num_docs; // num_docs doubles as the unit's doc-id limit
             mm[M_FREQ_LO] = (uint32_t)fo;
             mm[M_FREQ_HI] = (uint32_t)(fo >> 32);
             mm[M_FDEC] = 0;
@@ -214,7 +214,7 @@ struct CtxT {
 
     // ---- next_geq (block_posting_list.hpp:124-146)
     DS2I_DEV void next_geq(uint32_t s, uint32_t lb) {
-        if (lb > m(s, M_BMAX)) {
+        if (m(s, M_CUR) == 0xFFFFFFFFu || lb > m(s, M_BMAX)) {
             const uint32_t cur = m(s, M_CUR);
             uint32_t blk = find_block(s, cur + 1, lb);
             if (blk >= m(s, M_NB)) {
@@ -243,7 +243,7 @@ struct CtxT {
         }
         if (lane == 0) {
             meta[s * M_WORDS + M_POS] = idx;
-            meta[s * M_WORDS + M_DOCID] = val;
+            meta[s * M_WORDS + M_DOCID] = val < num_docs ? val : num_docs;
         }
         wave_sync();
     }
@@ -266,7 +266,7 @@ struct CtxT {
             uint32_t v = D(s)[pos];
             if (lane_id() == 0) {
                 meta[s * M_WORDS + M_POS] = pos;
-                meta[s * M_WORDS + M_DOCID] = v;
+                meta[s * M_WORDS + M_DOCID] = v < num_docs ? v : num_docs;
             }
             wave_sync();
         }

@@ -332,10 +332,16 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     __shared__ Lds<TMAX> L;
     const uint32_t lane = lane_id();
     Ctx cx = make_ctx<-1>(L, a);
-    const uint32_t N = a.num_docs;
     constexpr bool RANKED = OP >= OP_RANKED_AND;
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
-        const uint32_t q = a.units[a.order[tkt]].q; // one unit per query for these operators
+        // a unit of these operators is a doc-id range [blk_begin, blk_end) of the query (whole range when
+        // nparts == 1); inside the unit blk_end plays the role of num_docs (the exhaustion sentinel)
+        const uint32_t uid = a.order[tkt];
+        const Unit u = a.units[uid];
+        const uint32_t q = u.q;
+        const bool whole = u.nparts == 1;
+        const uint32_t N = whole ? a.num_docs : u.blk_end;
+        cx.num_docs = N;
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         unsigned long long count = 0, fsum = 0;
         TopK tk;
@@ -345,7 +351,11 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
             continue;
         }
-        for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
+        if (whole) {
+            for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
+        } else {
+            for (uint32_t i = 0; i < nt; ++i) { cx.bind(i, a.qterms[t0 + i]); cx.next_geq(i, u.blk_begin); }
+        }
         if (OP == OP_WAND || OP == OP_MAXSCORE) cx.s_bytes += 4ull * nt; // max_term_weight[term]
         auto norm_len = [&](uint32_t d) {
             cx.s_bytes += 4;
@@ -484,11 +494,19 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 cur = nxt;
             }
         }
-        if (lane == 0) {
-            a.out_count[q] = RANKED ? tk.n : count;
-            if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+        if (whole) {
+            if (lane == 0) {
+                a.out_count[q] = RANKED ? tk.n : count;
+                if (a.out_freq_sum) a.out_freq_sum[q] = fsum;
+            }
+            if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+        } else {
+            if (lane == 0) {
+                a.unit_count[uid] = RANKED ? tk.n : count;
+                a.unit_freq_sum[uid] = fsum;
+            }
+            if (RANKED) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
-        if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
     }
     cx.flush_stats(a.stats);
 }
@@ -533,6 +551,17 @@ __global__ void __launch_bounds__(64) k_selftest(const uint32_t* in, uint32_t* o
     const uint32_t lane = lane_id();
     uint32_t x = in[blockIdx.x * 64 + lane];
     out[blockIdx.x * 64 + lane] = wave_incl_scan(x);
+}
+
+// FETCH_SIZE calibration (MI355X_MICROARCH.md §HBM): streams `ndw` dwords of the arena with the same
+// access shape as Window::load (one dword per lane, 64 consecutive lanes) and folds them into a checksum.
+__global__ void __launch_bounds__(64) k_calib_read(const uint32_t* base, unsigned long long ndw, uint32_t* out) {
+    uint32_t acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 64 + lane_id(); i < ndw;
+         i += (unsigned long long)gridDim.x * 64)
+        acc ^= base[i];
+    for (int o = 32; o; o >>= 1) acc ^= __shfl_xor(acc, o);
+    if (lane_id() == 0 && acc == 0x12345678u) out[0] = acc; // keep the loads alive
 }
 
 } // namespace
@@ -605,6 +634,11 @@ hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t 
 
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(64), 0, s, in, out);
+    return hipGetLastError();
+}
+
+hipError_t ds2i_launch_calib_read(const uint32_t* base, unsigned long long ndw, uint32_t* out, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_calib_read, dim3(grid), dim3(64), 0, s, base, ndw, out);
     return hipGetLastError();
 }
 

@@ -123,6 +123,8 @@ int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total);
 int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches);
 void ds2i_hip_batch_free(ds2i_hip_batch* b);
 
+/* profiling aid: streams the whole index arena once with the decoders' load shape (calibrates FETCH_SIZE) */
+int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read);
 /* GPU unit-test hook: wave64 inclusive prefix sum over rows of 64 values */
 int ds2i_hip_selftest_scan(int device, const uint32_t* in, uint32_t* out, uint32_t rows);
 
