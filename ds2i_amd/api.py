@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4}
+CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4, "opt": 5}
 OPS = {"and": 0, "and_freq": 1, "or": 2, "or_freq": 3, "ranked_and": 4, "wand": 5, "maxscore": 6, "ranked_or": 7}
 REFERENCE_ORDER = 0x100
 _RANKED = {4, 5, 6, 7}

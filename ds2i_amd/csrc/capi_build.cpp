@@ -10,13 +10,15 @@
 #include "capi_error.hpp"
 #include "host_encode.hpp"
 #include "host_index.hpp"
+#include "host_pef.hpp"
 #include "host_synth.hpp"
 
 using namespace ds2i_host;
 
 struct ds2i_blob { bytes_t data; };
 struct ds2i_builder {
-    std::unique_ptr<block_index_builder> b;
+    std::unique_ptr<block_index_builder> b;   // kinds 0..4
+    std::unique_ptr<opt_index_builder> opt;   // kind 5 (DS2I_OPT)
 };
 struct ds2i_wand_builder {
     std::vector<float> norm_lens, max_w;
@@ -44,10 +46,11 @@ size_t ds2i_blob_size(const ds2i_blob* b) { return b ? b->data.size() : 0; }
 void ds2i_blob_free(ds2i_blob* b) { delete b; }
 
 int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out) {
-    if (!out || codec < 0 || codec > 4) return ds2i_set_error(-1, "ds2i_builder_create: bad argument");
+    if (!out || codec < 0 || codec > 5) return ds2i_set_error(-1, "ds2i_builder_create: bad argument");
     DS2I_TRY
     auto* h = new ds2i_builder;
-    h->b.reset(new block_index_builder(codec, num_docs));
+    if (codec == 5) h->opt.reset(new opt_index_builder(num_docs));
+    else h->b.reset(new block_index_builder(codec, num_docs));
     *out = h;
     return 0;
     DS2I_CATCH
@@ -55,7 +58,8 @@ int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out) {
 int ds2i_builder_add_posting_list(ds2i_builder* b, uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
     if (!b || !docs || !freqs) return ds2i_set_error(-1, "ds2i_builder_add_posting_list: null argument");
     DS2I_TRY
-    b->b->add_posting_list(n, docs, freqs);
+    if (b->opt) b->opt->add_posting_list(n, docs, freqs);
+    else b->b->add_posting_list(n, docs, freqs);
     return 0;
     DS2I_CATCH
 }
@@ -63,7 +67,8 @@ int ds2i_builder_freeze(ds2i_builder* b, ds2i_blob** image) {
     if (!b || !image) return ds2i_set_error(-1, "ds2i_builder_freeze: null argument");
     DS2I_TRY
     auto* blob = new ds2i_blob;
-    b->b->freeze(blob->data);
+    if (b->opt) b->opt->freeze(blob->data);
+    else b->b->freeze(blob->data);
     *image = blob;
     return 0;
     DS2I_CATCH
@@ -162,7 +167,7 @@ int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t*
 
 int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_blob** index_image,
                      ds2i_blob** wand_image, uint64_t* total_postings) {
-    if (!pp || !index_image || codec < 0 || codec > 4) return ds2i_set_error(-1, "ds2i_synth_build: bad argument");
+    if (!pp || !index_image || codec < 0 || codec > 5) return ds2i_set_error(-1, "ds2i_synth_build: bad argument");
     DS2I_TRY
     const synth_params p = to_params(pp);
     if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -174,6 +179,7 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
     sizes.shrink_to_fit();
     const uint32_t V = p.num_terms;
     std::vector<bytes_t> enc(V);
+    std::vector<bitvec_builder> enc_docs(codec == 5 ? V : 0), enc_freqs(codec == 5 ? V : 0);
     std::vector<float> max_w(V);
     std::atomic<uint32_t> next(0);
     std::atomic<uint64_t> postings(0);
@@ -186,7 +192,8 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
                 uint32_t t = next.fetch_add(1);
                 if (t >= V) break;
                 uint64_t n = synth_list(p, t, d, f);
-                write_posting_list(codec, enc[t], (uint32_t)n, d.data(), f.data());
+                if (codec == 5) opt_index_builder::encode_list(p.num_docs, global_parameters(), n, d.data(), f.data(), enc_docs[t], enc_freqs[t]);
+                else write_posting_list(codec, enc[t], (uint32_t)n, d.data(), f.data());
                 max_w[t] = list_max_weight(norm_lens.data(), n, d.data(), f.data());
                 postings += n;
             }
@@ -199,13 +206,23 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
     for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
     for (auto& th : pool) th.join();
     if (!err.empty()) return ds2i_set_error(-2, err.c_str());
-    block_index_builder builder(codec, p.num_docs);
-    for (uint32_t t = 0; t < V; ++t) {
-        builder.add_encoded_list(enc[t].data(), enc[t].size());
-        bytes_t().swap(enc[t]);
-    }
     auto* ib = new ds2i_blob;
-    builder.freeze(ib->data);
+    if (codec == 5) {
+        opt_index_builder builder(p.num_docs);
+        for (uint32_t t = 0; t < V; ++t) {
+            builder.add_encoded(enc_docs[t], enc_freqs[t]);
+            enc_docs[t] = bitvec_builder();
+            enc_freqs[t] = bitvec_builder();
+        }
+        builder.freeze(ib->data);
+    } else {
+        block_index_builder builder(codec, p.num_docs);
+        for (uint32_t t = 0; t < V; ++t) {
+            builder.add_encoded_list(enc[t].data(), enc[t].size());
+            bytes_t().swap(enc[t]);
+        }
+        builder.freeze(ib->data);
+    }
     *index_image = ib;
     if (wand_image) {
         auto* wb = new ds2i_blob;

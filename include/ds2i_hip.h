@@ -21,13 +21,15 @@
 extern "C" {
 #endif
 
-/* index kinds == reference index_types.hpp:35-39 (DS2I_BLOCK_INDEX_TYPES) */
+/* index kinds == reference index_types.hpp:18-39 */
 enum ds2i_hip_index_kind {
     DS2I_BLOCK_OPTPFOR = 0,
     DS2I_BLOCK_VARINT = 1,
     DS2I_BLOCK_INTERPOLATIVE = 2,
     DS2I_BLOCK_QMX = 3,
-    DS2I_BLOCK_MIXED = 4
+    DS2I_BLOCK_MIXED = 4,
+    DS2I_OPT = 5 /* opt_index: freq_index<partitioned_sequence<>, positive_sequence<partitioned_sequence<strict_sequence>>>
+                    (index_types.hpp:29-32) */
 };
 
 /* query operators == the strings queries.cpp:104-117 dispatches on (+ ranked_or, queries.hpp:404) */

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OPS = {"and": 0, "and_freq": 1, "or": 2, "or_freq": 3, "ranked_and": 4, "wand": 5, "maxscore": 6, "ranked_or": 7}
-CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4}
+CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4, "opt": 5}
 _lib = None
 _ref = None
 
@@ -64,6 +64,7 @@ def lib(path=None):
     L.oracle_list_enumerate.argtypes = [vp, C.c_uint64, vp, vp, C.c_uint64]
     L.oracle_list_enumerate.restype = C.c_int64
     L.oracle_list_next_geq.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp]
+    L.oracle_list_move.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     L.oracle_query.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, C.POINTER(Profile)]
     L.oracle_query.restype = C.c_int64
     L.oracle_query_batch.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(Profile)]
@@ -180,6 +181,14 @@ class Index:
         f = np.zeros(len(pr), dtype=np.uint32)
         if self._L.oracle_list_next_geq(self._h, term, _p(pr), len(pr), _p(d), _p(f)):
             raise RuntimeError("oracle_list_next_geq failed")
+        return d, f
+
+    def move(self, term, positions):
+        ps = np.ascontiguousarray(positions, dtype=np.uint32)
+        d = np.zeros(len(ps), dtype=np.uint32)
+        f = np.zeros(len(ps), dtype=np.uint32)
+        if self._L.oracle_list_move(self._h, term, _p(ps), len(ps), _p(d), _p(f)):
+            raise RuntimeError("oracle_list_move failed")
         return d, f
 
     def query(self, op, terms, k=10, want_matches=False, profile=False):

@@ -42,6 +42,8 @@
 #include <utility>
 #include <vector>
 
+#include "oracle_pef.hpp"
+
 namespace oracle {
 
 static inline uint32_t msb32(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
@@ -499,6 +501,7 @@ struct rd {
 };
 
 struct block_freq_index {
+    typedef oracle::document_enumerator document_enumerator;
     int codec = 0;
     uint8_t params[5];
     uint64_t m_size = 0, m_num_docs = 0;
@@ -506,6 +509,8 @@ struct block_freq_index {
     const uint8_t* m_lists = nullptr;
     uint64_t m_lists_size = 0;
     mutable profile* prof = nullptr;
+    void begin_profile(profile* p) const { prof = p; }
+    void end_profile() const { prof = nullptr; }
     void map(int codec_, const void* image, size_t bytes) {
         codec = codec_;
         rd r{(const uint8_t*)image, bytes};
@@ -528,6 +533,59 @@ struct block_freq_index {
     document_enumerator operator[](size_t i) const {
         if (i >= m_size) throw std::out_of_range("term id out of range");
         return document_enumerator(codec, m_lists + endpoint(i), m_num_docs, prof);
+    }
+};
+
+// freq_index<partitioned_sequence<>, positive_sequence<partitioned_sequence<strict_sequence>>> (index_types.hpp:29-32)
+struct opt_freq_index {
+    typedef opt_document_enumerator document_enumerator;
+    pef_params params;
+    uint64_t m_num_docs = 0;
+    bit_collection docs, freqs;
+    mutable profile* prof = nullptr;
+    mutable pef_profile pdocs, pfreqs;
+    static void map_bv(rd& r, bitvec& bv) {
+        bv.nbits = r.pod<uint64_t>();
+        uint64_t nw = r.pod<uint64_t>();
+        bv.nbytes = 8 * nw;
+        bv.bytes = r.take(8 * nw);
+    }
+    void map(const void* image, size_t bytes) {
+        rd r{(const uint8_t*)image, bytes};
+        params.ef_log_sampling0 = r.pod<uint8_t>();
+        params.ef_log_sampling1 = r.pod<uint8_t>();
+        params.rb_log_rank1_sampling = r.pod<uint8_t>();
+        params.rb_log_sampling1 = r.pod<uint8_t>();
+        params.log_partition_size = r.pod<uint8_t>();
+        m_num_docs = r.pod<uint64_t>();
+        for (bit_collection* c : {&docs, &freqs}) {
+            c->m_size = r.pod<uint64_t>();
+            map_bv(r, c->endpoints);
+            map_bv(r, c->bits);
+        }
+    }
+    size_t size() const { return docs.m_size; }
+    uint64_t num_docs() const { return m_num_docs; }
+    document_enumerator operator[](size_t i) const { // freq_index.hpp:192-214
+        if (i >= size()) throw std::out_of_range("term id out of range");
+        bit_enumerator it(docs.bits, docs.get(params, i));
+        const uint64_t start = it.position();
+        uint64_t occurrences = read_gamma_nonzero(it);
+        uint64_t n = 1;
+        if (occurrences > 1) n = it.take(pef_ceil_log2(occurrences + 1));
+        if (prof) prof->algorithmic_bytes += (it.position() - start + 7) / 8 + 16; // list header + two collection offsets
+        partitioned_enumerator<false> de(docs.bits, it.position(), m_num_docs, n, params, prof ? &pdocs : nullptr);
+        positive_enumerator fe(freqs.bits, freqs.get(params, i), occurrences + 1, n, params, prof ? &pfreqs : nullptr);
+        return document_enumerator(de, fe);
+    }
+    void begin_profile(profile* p) const { prof = p; pdocs = pef_profile(); pfreqs = pef_profile(); }
+    void end_profile() const {
+        if (prof) {
+            prof->docs_blocks += pdocs.partitions_entered;
+            prof->freqs_blocks += pfreqs.partitions_entered;
+            prof->algorithmic_bytes += pdocs.algorithmic_bytes + pfreqs.algorithmic_bytes;
+        }
+        prof = nullptr;
     }
 };
 
@@ -600,17 +658,20 @@ struct topk_queue {
     std::vector<float> m_q;
 };
 
+template <class Index>
 struct query_ctx {
-    const block_freq_index* index;
+    const Index* index;
     const wand_data* wdata;
     uint64_t k;
     std::vector<uint32_t>* matches; // optional doc-id list for and
     uint64_t freq_sum;               // and_freq / or_freq checksum
     topk_queue topk;
-    query_ctx(const block_freq_index* i, const wand_data* w, uint64_t k_) : index(i), wdata(w), k(k_), matches(nullptr), freq_sum(0), topk(k_) {}
+    query_ctx(const Index* i, const wand_data* w, uint64_t k_) : index(i), wdata(w), k(k_), matches(nullptr), freq_sum(0), topk(k_) {}
 };
 
-static uint64_t and_query(query_ctx& c, term_id_vec terms, bool with_freqs) {
+template <class Index>
+static uint64_t and_query(query_ctx<Index>& c, term_id_vec terms, bool with_freqs) {
+    typedef typename Index::document_enumerator document_enumerator;
     if (terms.empty()) return 0;
     remove_duplicate_terms(terms);
     std::vector<document_enumerator> enums;
@@ -636,7 +697,9 @@ static uint64_t and_query(query_ctx& c, term_id_vec terms, bool with_freqs) {
     return results;
 }
 
-static uint64_t or_query(query_ctx& c, term_id_vec terms, bool with_freqs) {
+template <class Index>
+static uint64_t or_query(query_ctx<Index>& c, term_id_vec terms, bool with_freqs) {
+    typedef typename Index::document_enumerator document_enumerator;
     if (terms.empty()) return 0;
     remove_duplicate_terms(terms);
     std::vector<document_enumerator> enums;
@@ -659,9 +722,12 @@ static uint64_t or_query(query_ctx& c, term_id_vec terms, bool with_freqs) {
     return results;
 }
 
-struct scored_enum { document_enumerator docs_enum; float q_weight; float max_weight; };
+template <class Index>
+struct scored_enum_t { typename Index::document_enumerator docs_enum; float q_weight; float max_weight; };
 
-static std::vector<scored_enum> make_scored(query_ctx& c, term_id_vec const& terms, bool need_max_weight) {
+template <class Index>
+static std::vector<scored_enum_t<Index>> make_scored(query_ctx<Index>& c, term_id_vec const& terms, bool need_max_weight) {
+    typedef scored_enum_t<Index> scored_enum;
     auto qf = query_freqs(terms);
     std::vector<scored_enum> enums;
     enums.reserve(qf.size());
@@ -678,12 +744,15 @@ static std::vector<scored_enum> make_scored(query_ctx& c, term_id_vec const& ter
     }
     return enums;
 }
-static inline float norm_len(query_ctx& c, uint64_t d) {
+template <class Index>
+static inline float norm_len(query_ctx<Index>& c, uint64_t d) {
     if (c.index->prof) { c.index->prof->algorithmic_bytes += 4; c.index->prof->postings_scored += 1; }
     return c.wdata->norm_len(d);
 }
 
-static uint64_t ranked_and_query(query_ctx& c, term_id_vec terms) {
+template <class Index>
+static uint64_t ranked_and_query(query_ctx<Index>& c, term_id_vec terms) {
+    typedef scored_enum_t<Index> scored_enum;
     c.topk.clear();
     if (terms.empty()) return 0;
     auto enums = make_scored(c, terms, false);
@@ -708,7 +777,9 @@ static uint64_t ranked_and_query(query_ctx& c, term_id_vec terms) {
     return c.topk.topk().size();
 }
 
-static uint64_t ranked_or_query(query_ctx& c, term_id_vec terms) {
+template <class Index>
+static uint64_t ranked_or_query(query_ctx<Index>& c, term_id_vec terms) {
+    typedef scored_enum_t<Index> scored_enum;
     c.topk.clear();
     if (terms.empty()) return 0;
     auto enums = make_scored(c, terms, false);
@@ -730,7 +801,9 @@ static uint64_t ranked_or_query(query_ctx& c, term_id_vec terms) {
     return c.topk.topk().size();
 }
 
-static uint64_t wand_query(query_ctx& c, term_id_vec const& terms) {
+template <class Index>
+static uint64_t wand_query(query_ctx<Index>& c, term_id_vec const& terms) {
+    typedef scored_enum_t<Index> scored_enum;
     c.topk.clear();
     if (terms.empty()) return 0;
     uint64_t num_docs = c.index->num_docs();
@@ -776,7 +849,9 @@ static uint64_t wand_query(query_ctx& c, term_id_vec const& terms) {
     return c.topk.topk().size();
 }
 
-static uint64_t maxscore_query(query_ctx& c, term_id_vec const& terms) {
+template <class Index>
+static uint64_t maxscore_query(query_ctx<Index>& c, term_id_vec const& terms) {
+    typedef scored_enum_t<Index> scored_enum;
     c.topk.clear();
     if (terms.empty()) return 0;
     auto enums = make_scored(c, terms, true);
@@ -817,7 +892,8 @@ static uint64_t maxscore_query(query_ctx& c, term_id_vec const& terms) {
 
 enum { OP_AND = 0, OP_AND_FREQ, OP_OR, OP_OR_FREQ, OP_RANKED_AND, OP_WAND, OP_MAXSCORE, OP_RANKED_OR };
 
-static uint64_t run_op(query_ctx& c, int op, term_id_vec const& terms) {
+template <class Index>
+static uint64_t run_op(query_ctx<Index>& c, int op, term_id_vec const& terms) {
     switch (op) {
     case OP_AND: return and_query(c, terms, false);
     case OP_AND_FREQ: return and_query(c, terms, true);
@@ -838,9 +914,12 @@ static double get_time_usecs() {
 }
 
 struct handle {
+    int kind = 0; // 0..4 block codecs, 5 = opt (partitioned Elias-Fano freq_index)
     block_freq_index index;
+    opt_freq_index opt;
     wand_data wdata;
     bool has_wand = false;
+    bool is_opt() const { return kind == 5; }
 };
 
 } // namespace oracle
@@ -871,38 +950,152 @@ void oracle_qmx_decode_stream(uint32_t* out, const uint8_t* src, uint64_t len) {
 void* oracle_index_open(int kind, const void* image, uint64_t bytes, const void* wand, uint64_t wand_bytes) {
     try {
         handle* h = new handle;
-        h->index.map(kind, image, bytes);
+        h->kind = kind;
+        if (kind == 5) h->opt.map(image, bytes);
+        else h->index.map(kind, image, bytes);
         if (wand) { h->wdata.map(wand, wand_bytes); h->has_wand = true; }
         return h;
     } catch (...) { return nullptr; }
 }
 void oracle_index_close(void* h) { delete (handle*)h; }
-uint64_t oracle_index_size(void* h) { return ((handle*)h)->index.size(); }
-uint64_t oracle_index_num_docs(void* h) { return ((handle*)h)->index.num_docs(); }
-uint64_t oracle_list_offset(void* h, uint64_t term) { return ((handle*)h)->index.endpoint(term); }
-int64_t oracle_list_size(void* h, uint64_t term) {
-    try { return (int64_t)((handle*)h)->index[term].size(); } catch (...) { return -1; }
+uint64_t oracle_index_size(void* hv) { handle* h = (handle*)hv; return h->is_opt() ? h->opt.size() : h->index.size(); }
+uint64_t oracle_index_num_docs(void* hv) { handle* h = (handle*)hv; return h->is_opt() ? h->opt.num_docs() : h->index.num_docs(); }
+uint64_t oracle_list_offset(void* hv, uint64_t term) {
+    handle* h = (handle*)hv;
+    return h->is_opt() ? h->opt.docs.get(h->opt.params, term) : h->index.endpoint(term);
 }
-// sequential enumeration with next(): docid()+freq() of every posting; returns n or -1
-int64_t oracle_list_enumerate(void* h, uint64_t term, uint32_t* docs, uint32_t* freqs, uint64_t cap) {
-    try {
-        auto e = ((handle*)h)->index[term];
-        uint64_t n = e.size();
-        if (n > cap) return -1;
-        for (uint64_t i = 0; i < n; ++i, e.next()) { docs[i] = (uint32_t)e.docid(); freqs[i] = (uint32_t)e.freq(); }
-        return (e.docid() == ((handle*)h)->index.num_docs()) ? (int64_t)n : -2;
-    } catch (...) { return -1; }
+
+extern "C++" {
+namespace {
+template <class Index> int64_t list_size_t(const Index& idx, uint64_t term) { return (int64_t)idx[term].size(); }
+template <class Index> int64_t list_enumerate_t(const Index& idx, uint64_t term, uint32_t* docs, uint32_t* freqs, uint64_t cap) {
+    auto e = idx[term];
+    uint64_t n = e.size();
+    if (n > cap) return -1;
+    for (uint64_t i = 0; i < n; ++i, e.next()) {
+        if (e.position() != i) return -3;
+        docs[i] = (uint32_t)e.docid();
+        freqs[i] = (uint32_t)e.freq();
+    }
+    return (e.docid() == idx.num_docs()) ? (int64_t)n : -2;
+}
+template <class Index> void list_next_geq_t(const Index& idx, uint64_t term, const uint32_t* probes, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
+    auto e = idx[term];
+    uint64_t N = idx.num_docs();
+    for (uint64_t i = 0; i < np; ++i) {
+        e.next_geq(probes[i]);
+        out_docid[i] = (uint32_t)e.docid();
+        out_freq[i] = e.docid() < N ? (uint32_t)e.freq() : 0;
+    }
+}
+// random access: move(position) for each position, docid + freq
+template <class Index> void list_move_t(const Index& idx, uint64_t term, const uint32_t* positions, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
+    auto e = idx[term];
+    for (uint64_t i = 0; i < np; ++i) {
+        e.move(positions[i]);
+        out_docid[i] = (uint32_t)e.docid();
+        out_freq[i] = (uint32_t)e.freq();
+    }
+}
+void fill_profile(oracle_profile* dst, profile const& p) {
+    dst->docs_blocks = p.docs_blocks; dst->freqs_blocks = p.freqs_blocks; dst->block_max_examined = p.block_max_examined;
+    dst->algorithmic_bytes = p.algorithmic_bytes; dst->postings_scored = p.postings_scored;
+}
+template <class Index>
+int64_t query_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* terms, uint32_t nterms, float* topk, uint32_t* topk_len,
+                uint32_t* matches, uint64_t match_cap, uint64_t* freq_sum, oracle_profile* prof) {
+    profile p;
+    idx.begin_profile(prof ? &p : nullptr);
+    query_ctx<Index> c(&idx, &h->wdata, k ? k : 1);
+    std::vector<uint32_t> m;
+    if (matches) c.matches = &m;
+    term_id_vec t(terms, terms + nterms);
+    uint64_t r = run_op(c, op, t);
+    idx.end_profile();
+    if (topk_len) *topk_len = (uint32_t)c.topk.topk().size();
+    if (topk) for (size_t i = 0; i < c.topk.topk().size() && i < k; ++i) topk[i] = c.topk.topk()[i];
+    if (matches) std::memcpy(matches, m.data(), 4 * std::min<uint64_t>(m.size(), match_cap));
+    if (freq_sum) *freq_sum = c.freq_sum;
+    if (prof) fill_profile(prof, p);
+    return (int64_t)r;
+}
+template <class Index>
+int query_batch_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq,
+                  uint64_t* out_count, float* out_topk, uint32_t* out_topk_len, uint64_t* out_freq_sum, oracle_profile* prof) {
+    profile p;
+    idx.begin_profile(prof ? &p : nullptr);
+    query_ctx<Index> c(&idx, &h->wdata, k ? k : 1);
+    for (uint32_t q = 0; q < nq; ++q) {
+        term_id_vec t(terms + offs[q], terms + offs[q + 1]);
+        c.freq_sum = 0;
+        c.topk.clear();
+        uint64_t r = run_op(c, op, t);
+        if (out_count) out_count[q] = r;
+        if (out_topk)
+            for (uint32_t i = 0; i < k; ++i) out_topk[(size_t)q * k + i] = i < c.topk.topk().size() ? c.topk.topk()[i] : -INFINITY;
+        if (out_topk_len) out_topk_len[q] = (uint32_t)c.topk.topk().size();
+        if (out_freq_sum) out_freq_sum[q] = c.freq_sum;
+    }
+    idx.end_profile();
+    if (prof) fill_profile(prof, p);
+    return 0;
+}
+// op_perftest (queries.cpp:13-62)
+template <class Index>
+int perftest_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq, uint32_t runs, double* stats_out) {
+    idx.begin_profile(nullptr);
+    query_ctx<Index> c(&idx, &h->wdata, k ? k : 1);
+    std::vector<double> times;
+    volatile uint64_t sink = 0;
+    for (uint32_t run = 0; run <= runs; ++run) {
+        for (uint32_t q = 0; q < nq; ++q) {
+            term_id_vec t(terms + offs[q], terms + offs[q + 1]);
+            double tick = get_time_usecs();
+            uint64_t r = run_op(c, op, t);
+            sink += r;
+            double el = get_time_usecs() - tick;
+            if (run != 0) times.push_back(el);
+        }
+    }
+    if (times.empty()) return -1;
+    std::sort(times.begin(), times.end());
+    double total = std::accumulate(times.begin(), times.end(), 0.0);
+    stats_out[0] = total / times.size();
+    stats_out[1] = times[times.size() / 2];
+    stats_out[2] = times[90 * times.size() / 100];
+    stats_out[3] = times[95 * times.size() / 100];
+    stats_out[4] = total * 1e-6;
+    return 0;
+}
+} // namespace
+} // extern "C++"
+
+#define DISPATCH(h, expr_block, expr_opt) ((h)->is_opt() ? (expr_opt) : (expr_block))
+
+int64_t oracle_list_size(void* hv, uint64_t term) {
+    handle* h = (handle*)hv;
+    try { return DISPATCH(h, list_size_t(h->index, term), list_size_t(h->opt, term)); } catch (...) { return -1; }
+}
+// sequential enumeration with next(): docid()+freq()+position() of every posting; returns n or a negative code
+int64_t oracle_list_enumerate(void* hv, uint64_t term, uint32_t* docs, uint32_t* freqs, uint64_t cap) {
+    handle* h = (handle*)hv;
+    try { return DISPATCH(h, list_enumerate_t(h->index, term, docs, freqs, cap), list_enumerate_t(h->opt, term, docs, freqs, cap)); } catch (...) { return -1; }
 }
 // reset(); then next_geq(probes[i]) in order (probes non-decreasing): records docid() and freq()-or-0
-int oracle_list_next_geq(void* h, uint64_t term, const uint32_t* probes, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
+int oracle_list_next_geq(void* hv, uint64_t term, const uint32_t* probes, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
+    handle* h = (handle*)hv;
     try {
-        auto e = ((handle*)h)->index[term];
-        uint64_t N = ((handle*)h)->index.num_docs();
-        for (uint64_t i = 0; i < np; ++i) {
-            e.next_geq(probes[i]);
-            out_docid[i] = (uint32_t)e.docid();
-            out_freq[i] = e.docid() < N ? (uint32_t)e.freq() : 0;
-        }
+        if (h->is_opt()) list_next_geq_t(h->opt, term, probes, np, out_docid, out_freq);
+        else list_next_geq_t(h->index, term, probes, np, out_docid, out_freq);
+        return 0;
+    } catch (...) { return -1; }
+}
+// move(positions[i]) in order (positions non-decreasing): docid() and freq()
+int oracle_list_move(void* hv, uint64_t term, const uint32_t* positions, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
+    handle* h = (handle*)hv;
+    try {
+        if (h->is_opt()) list_move_t(h->opt, term, positions, np, out_docid, out_freq);
+        else list_move_t(h->index, term, positions, np, out_docid, out_freq);
         return 0;
     } catch (...) { return -1; }
 }
@@ -910,82 +1103,32 @@ int oracle_list_next_geq(void* h, uint64_t term, const uint32_t* probes, uint64_
 // one query; topk holds k floats, matches (optional) holds match_cap doc-ids. Returns the operator's value.
 int64_t oracle_query(void* hv, int op, uint32_t k, const uint32_t* terms, uint32_t nterms, float* topk, uint32_t* topk_len,
                      uint32_t* matches, uint64_t match_cap, uint64_t* freq_sum, oracle_profile* prof) {
+    handle* h = (handle*)hv;
     try {
-        handle* h = (handle*)hv;
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        profile p;
-        h->index.prof = prof ? &p : nullptr;
-        query_ctx c(&h->index, &h->wdata, k ? k : 1);
-        std::vector<uint32_t> m;
-        if (matches) c.matches = &m;
-        term_id_vec t(terms, terms + nterms);
-        uint64_t r = run_op(c, op, t);
-        h->index.prof = nullptr;
-        if (topk_len) *topk_len = (uint32_t)c.topk.topk().size();
-        if (topk) for (size_t i = 0; i < c.topk.topk().size() && i < k; ++i) topk[i] = c.topk.topk()[i];
-        if (matches) std::memcpy(matches, m.data(), 4 * std::min<uint64_t>(m.size(), match_cap));
-        if (freq_sum) *freq_sum = c.freq_sum;
-        if (prof) { prof->docs_blocks = p.docs_blocks; prof->freqs_blocks = p.freqs_blocks; prof->block_max_examined = p.block_max_examined; prof->algorithmic_bytes = p.algorithmic_bytes; prof->postings_scored = p.postings_scored; }
-        return (int64_t)r;
+        return DISPATCH(h, query_t(h->index, h, op, k, terms, nterms, topk, topk_len, matches, match_cap, freq_sum, prof),
+                        query_t(h->opt, h, op, k, terms, nterms, topk, topk_len, matches, match_cap, freq_sum, prof));
     } catch (...) { return -1; }
 }
 
 // batch form of oracle_query: per-query results + summed profile (one untimed pass)
 int oracle_query_batch(void* hv, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq,
                        uint64_t* out_count, float* out_topk, uint32_t* out_topk_len, uint64_t* out_freq_sum, oracle_profile* prof) {
+    handle* h = (handle*)hv;
     try {
-        handle* h = (handle*)hv;
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        profile p;
-        h->index.prof = prof ? &p : nullptr;
-        query_ctx c(&h->index, &h->wdata, k ? k : 1);
-        for (uint32_t q = 0; q < nq; ++q) {
-            term_id_vec t(terms + offs[q], terms + offs[q + 1]);
-            c.freq_sum = 0;
-            c.topk.clear();
-            uint64_t r = run_op(c, op, t);
-            if (out_count) out_count[q] = r;
-            if (out_topk) {
-                for (uint32_t i = 0; i < k; ++i) out_topk[(size_t)q * k + i] = i < c.topk.topk().size() ? c.topk.topk()[i] : -INFINITY;
-            }
-            if (out_topk_len) out_topk_len[q] = (uint32_t)c.topk.topk().size();
-            if (out_freq_sum) out_freq_sum[q] = c.freq_sum;
-        }
-        h->index.prof = nullptr;
-        if (prof) { prof->docs_blocks = p.docs_blocks; prof->freqs_blocks = p.freqs_blocks; prof->block_max_examined = p.block_max_examined; prof->algorithmic_bytes = p.algorithmic_bytes; prof->postings_scored = p.postings_scored; }
-        return 0;
+        return DISPATCH(h, query_batch_t(h->index, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof),
+                        query_batch_t(h->opt, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof));
     } catch (...) { return -1; }
 }
 
 // op_perftest (queries.cpp:13-62): `runs`+1 passes, first untimed, per-query gettimeofday microseconds.
 // stats_out = {avg, q50, q90, q95, total_timed_seconds}. Single thread.
 int oracle_perftest(void* hv, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq, uint32_t runs, double* stats_out) {
+    handle* h = (handle*)hv;
     try {
-        handle* h = (handle*)hv;
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        h->index.prof = nullptr;
-        query_ctx c(&h->index, &h->wdata, k ? k : 1);
-        std::vector<double> times;
-        volatile uint64_t sink = 0;
-        for (uint32_t run = 0; run <= runs; ++run) {
-            for (uint32_t q = 0; q < nq; ++q) {
-                term_id_vec t(terms + offs[q], terms + offs[q + 1]);
-                double tick = get_time_usecs();
-                uint64_t r = run_op(c, op, t);
-                sink += r;
-                double el = get_time_usecs() - tick;
-                if (run != 0) times.push_back(el);
-            }
-        }
-        if (times.empty()) return -1;
-        std::sort(times.begin(), times.end());
-        double total = std::accumulate(times.begin(), times.end(), 0.0);
-        stats_out[0] = total / times.size();
-        stats_out[1] = times[times.size() / 2];
-        stats_out[2] = times[90 * times.size() / 100];
-        stats_out[3] = times[95 * times.size() / 100];
-        stats_out[4] = total * 1e-6;
-        return 0;
+        return DISPATCH(h, perftest_t(h->index, h, op, k, terms, offs, nq, runs, stats_out), perftest_t(h->opt, h, op, k, terms, offs, nq, runs, stats_out));
     } catch (...) { return -1; }
 }
 

@@ -1,0 +1,101 @@
+"""The partitioned Elias-Fano ("opt") index on the CPU: product writer (host_pef.hpp) x oracle enumerators.
+
+Mirrors reference test/test_freq_index.cpp (build -> freeze -> map -> enumerate), test_generic_sequence.hpp:28-164
+(move/next and the next_geq spec the reference never runs -- SURVEY.md §4 caveat: successor for every gap
+position, beyond-last, beyond-universe) and test_partitioned_sequence.cpp (singletons, short lists in big universes,
+single- and multi-partition lists), plus every query functor against the brute-force oracle.
+"""
+import numpy as np
+import pytest
+
+import ds2i_amd as d
+import oracle as o
+from helpers import Collection, brute_and, brute_or, brute_ranked, queries_for, small_params
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def coll(built_lib):
+    return Collection(small_params(num_docs=20000, num_terms=200))
+
+
+@pytest.fixture(scope="module")
+def idx(coll):
+    return o.Index("opt", coll.index_image("opt"), coll.wand_image())
+
+
+def test_freeze_map_enumerate(coll, idx):
+    assert idx.size() == len(coll.lists) and idx.num_docs() == coll.num_docs
+    for t, (docs, freqs) in enumerate(coll.lists):
+        assert idx.list_size(t) == len(docs)
+        dd, ff = idx.enumerate(t)  # next(): position()==i, docid()==num_docs after the last
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+
+
+def test_next_geq_spec(coll, idx):
+    N = coll.num_docs
+    rng = np.random.default_rng(11)
+    for t in range(0, len(coll.lists), 5):
+        docs, freqs = coll.lists[t]
+        got, gf = idx.next_geq(t, docs)
+        assert np.array_equal(got, docs) and np.array_equal(gf, freqs)
+        probes = np.sort(np.concatenate([rng.integers(0, N, 80), docs[:: max(1, len(docs) // 25)] + 1,
+                                         docs[:: max(1, len(docs) // 7)] + (1 << 9), [docs[-1] + 1, N]]))
+        probes = np.minimum(probes, N).astype(np.uint32)
+        got, gf = idx.next_geq(t, probes)
+        pos = np.searchsorted(docs, probes)
+        ok = pos < len(docs)
+        exp = np.where(ok, docs[np.minimum(pos, len(docs) - 1)], N).astype(np.uint32)
+        assert np.array_equal(got, exp), t
+        assert np.array_equal(gf[ok], freqs[pos[ok]])
+
+
+def test_move_random_access(coll, idx):
+    rng = np.random.default_rng(12)
+    for t in range(0, len(coll.lists), 9):
+        docs, freqs = coll.lists[t]
+        ps = np.sort(rng.integers(0, len(docs), min(60, len(docs)))).astype(np.uint32)
+        dd, ff = idx.move(t, ps)
+        assert np.array_equal(dd, docs[ps]) and np.array_equal(ff, freqs[ps])
+
+
+def test_shapes_partitions(built_lib):
+    """singletons, tiny lists in a huge universe, dense runs (all-ones / bitmap partitions), long multi-partition lists"""
+    N = 1 << 22
+    rng = np.random.default_rng(13)
+    lists = [(np.array([5], np.uint32), np.array([3], np.uint32)),
+             (np.array([N - 1], np.uint32), np.array([1], np.uint32)),
+             (np.array([0, N - 1], np.uint32), np.array([1, 2], np.uint32)),
+             (np.arange(1000, 1000 + 5000, dtype=np.uint32), np.ones(5000, np.uint32)),                 # all ones
+             (np.sort(rng.choice(3 * 4096, 4096, replace=False) + 777).astype(np.uint32), rng.integers(1, 9, 4096).astype(np.uint32)),  # bitmap-ish
+             (np.sort(rng.choice(N, 30000, replace=False)).astype(np.uint32), rng.integers(1, 300, 30000).astype(np.uint32)),
+             (np.concatenate([np.arange(100, 2100), np.sort(rng.choice(N - 10000, 3000, replace=False)) + 10000]).astype(np.uint32),
+              rng.integers(1, 4, 5000).astype(np.uint32))]
+    img = d.build_index("opt", N, lists)
+    idx = o.Index("opt", img)
+    for t, (docs, freqs) in enumerate(lists):
+        dd, ff = idx.enumerate(t)
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+        got, _ = idx.next_geq(t, np.array([0, docs[0], docs[-1], min(N, int(docs[-1]) + 1), N], np.uint32))
+        assert list(got) == [docs[0], docs[0], docs[-1], N, N]
+
+
+def test_queries_match_brute_force(coll, idx):
+    queries = queries_for(coll, 120) + [[], [5], [5, 5], [7, 3, 7, 3]]
+    for q in queries:
+        r = idx.query("and", q, want_matches=True)
+        exp = brute_and(coll, q)
+        assert r["count"] == len(exp) and np.array_equal(r["matches"], exp)
+        assert idx.query("or", q)["count"] == len(brute_or(coll, q))
+        got = idx.query("ranked_and", q)
+        np.testing.assert_allclose(got["topk"], brute_ranked(coll, q, 10, True, "size"), rtol=RTOL)
+        exp_or = brute_ranked(coll, q, 10, False, "term")
+        for op in ("ranked_or", "wand", "maxscore"):
+            got = idx.query(op, q)
+            assert got["count"] == len(exp_or)
+            np.testing.assert_allclose(got["topk"], exp_or, rtol=RTOL)
+
+
+def test_opt_is_smaller_than_block_indexes(coll):
+    assert len(coll.index_image("opt")) < len(coll.index_image("block_optpfor"))
