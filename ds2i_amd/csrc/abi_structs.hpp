@@ -5,14 +5,17 @@
 namespace ds2i_dev {
 
 // One query term as prepared by the host: byte range of its posting list inside the device
-// arena + BM25 weights (bm25.hpp:17-24 needs logf -> computed on the host).
+// arena (block indexes) or of its chunk directory (opt index: cmax[] at list_off, 12-dword chunk entries at
+// list_end) + BM25 weights (bm25.hpp:17-24 needs logf -> computed on the host).
 struct QTerm {
     uint64_t list_off; // byte offset of vbyte(n) in the arena
     uint64_t list_end; // byte offset one past the list
     uint32_t n;        // postings
     float q_weight;
     float max_weight; // q_weight * max_term_weight[term]
-    uint32_t term;
+    uint32_t term;    // block indexes: term id ; opt index: number of chunks of the list
+    uint64_t aux0;    // opt index: absolute bit offset of the list's docs sequence (after its gamma header)
+    uint64_t aux1;    // opt index: absolute bit offset of the list's freqs sequence
 };
 
 enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_COUNT };
@@ -34,7 +37,9 @@ struct Unit {
 };
 
 struct BatchArgs {
-    const uint8_t* arena;
+    const uint8_t* arena;     // block indexes: list bytes ; opt index: chunk directory
+    const uint8_t* bits0;     // opt index: docs bit vector words
+    const uint8_t* bits1;     // opt index: freqs bit vector words
     const float* norm_lens;
     const QTerm* qterms;      // terms of all queries, already in enumerator order
     const uint32_t* q_off;    // nq+1 offsets into qterms
@@ -77,6 +82,8 @@ struct MergeArgs {
 
 struct DecodeArgs {
     const uint8_t* arena;
+    const uint8_t* bits0;
+    const uint8_t* bits1;
     QTerm term;
     int codec;
     uint32_t num_docs;

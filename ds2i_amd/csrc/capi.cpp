@@ -15,6 +15,10 @@
 #include "abi_structs.hpp"
 #include "capi_error.hpp"
 #include "host_index.hpp"
+#include "host_pef.hpp"
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 using ds2i_dev::BatchArgs;
 using ds2i_dev::DecodeArgs;
@@ -64,6 +68,11 @@ struct ds2i_hip_index {
     std::vector<uint64_t> list_off; // arena offsets, size+1 (list i spans [off[i], end[i]))
     std::vector<uint64_t> list_end;
     std::vector<uint32_t> list_n;
+    std::vector<uint32_t> list_nb;  // blocks (block indexes) / chunks (opt index) per list
+    std::vector<uint64_t> list_aux0, list_aux1; // opt index: docs / freqs sequence bit offsets
+    uint8_t* d_bits0 = nullptr;     // opt index: docs bit vector
+    uint8_t* d_bits1 = nullptr;     // opt index: freqs bit vector
+    uint64_t extra_bytes = 0;
     std::vector<float> max_term_weight;
     hipStream_t stream[NCLS] = {};
     hipEvent_t ev[2 + 2 * NCLS] = {};
@@ -122,6 +131,8 @@ void free_index(ds2i_hip_index* x) {
     (void)hipSetDevice(x->device);
     if (x->d_arena) (void)hipFree(x->d_arena);
     if (x->d_norm_lens) (void)hipFree(x->d_norm_lens);
+    if (x->d_bits0) (void)hipFree(x->d_bits0);
+    if (x->d_bits1) (void)hipFree(x->d_bits1);
     if (x->d_stats) (void)hipFree(x->d_stats);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
@@ -144,7 +155,7 @@ int ds2i_hip_device_count(void) {
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
     if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
-    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_BLOCK_MIXED)
+    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_OPT)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
     int ndev = ds2i_hip_device_count();
     if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
@@ -152,28 +163,81 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     x->device = device;
     x->kind = kind;
     ds2i_host::block_index_view view;
+    ds2i_host::opt_index_view oview;
     ds2i_host::wand_view wv;
     try {
-        view.parse(index_image, index_bytes);
+        if (kind == DS2I_OPT) oview.parse(index_image, index_bytes);
+        else view.parse(index_image, index_bytes);
         if (wand_image) wv.parse(wand_image, wand_bytes);
     } catch (std::exception const& e) {
         return ds2i_set_error(DS2I_EFORMAT, e.what());
     }
-    x->size = view.size;
-    x->num_docs = view.num_docs;
+    x->size = kind == DS2I_OPT ? oview.size : view.size;
+    x->num_docs = kind == DS2I_OPT ? oview.num_docs : view.num_docs;
     if (wand_image) {
-        if (wv.num_docs != view.num_docs || wv.num_terms < view.size)
+        if (wv.num_docs != x->num_docs || wv.num_terms < x->size)
             return ds2i_set_error(DS2I_EFORMAT, "wand data does not match the index (num_docs / terms)");
         x->has_wand = true;
         x->max_term_weight.resize(wv.num_terms);
         std::memcpy(x->max_term_weight.data(), wv.max_term_weight, 4 * wv.num_terms);
     }
-    // Device arena: every list is copied byte-for-byte, shifted by <= 3 pad bytes so that its
-    // block_max / block_endpoint tables (which follow vbyte(n)) are dword aligned in HBM.
-    const uint64_t V = view.size;
+    const uint64_t V = x->size;
     x->list_off.resize(V);
     x->list_end.resize(V);
     x->list_n.resize(V);
+    x->list_nb.resize(V);
+    std::vector<uint8_t> arena;
+    if (kind == DS2I_OPT) {
+        // opt index: the two bit vectors go to HBM unchanged; every list is additionally flattened into a chunk
+        // directory (cmax[] + 12-dword entries) so that the device treats <=128-posting chunks like blocks.
+        x->list_aux0.resize(V);
+        x->list_aux1.resize(V);
+        std::vector<ds2i_host::pef_list_dir> dirs(V);
+        std::atomic<uint64_t> next(0);
+        std::string err;
+        std::mutex mu;
+        auto worker = [&]() {
+            try {
+                for (;;) {
+                    uint64_t t = next.fetch_add(1);
+                    if (t >= V) break;
+                    oview.build_dir(t, dirs[t]);
+                }
+            } catch (std::exception const& e) {
+                std::lock_guard<std::mutex> g(mu);
+                err = e.what();
+            }
+        };
+        unsigned nth = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nth; ++i) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+        if (!err.empty()) return ds2i_set_error(DS2I_EFORMAT, err.c_str());
+        uint64_t cursor = 0;
+        for (uint64_t t = 0; t < V; ++t) {
+            const uint64_t nch = dirs[t].chunks.size();
+            x->list_off[t] = cursor;                                   // cmax[]
+            x->list_end[t] = (cursor + 4 * nch + 15) & ~uint64_t(15);   // chunk entries
+            cursor = x->list_end[t] + nch * sizeof(ds2i_host::pef_chunk);
+            x->list_n[t] = dirs[t].n;
+            x->list_nb[t] = (uint32_t)nch;
+            x->list_aux0[t] = dirs[t].docs_bit0;
+            x->list_aux1[t] = dirs[t].freqs_bit0;
+        }
+        x->arena_bytes = ((cursor + 15) & ~uint64_t(15)) + 4096;
+        try {
+            arena.assign(x->arena_bytes, 0);
+        } catch (std::bad_alloc const&) {
+            return ds2i_set_error(DS2I_ENOMEM, "out of host memory staging the chunk directory");
+        }
+        for (uint64_t t = 0; t < V; ++t) {
+            std::memcpy(arena.data() + x->list_off[t], dirs[t].cmax.data(), 4 * dirs[t].cmax.size());
+            std::memcpy(arena.data() + x->list_end[t], dirs[t].chunks.data(), dirs[t].chunks.size() * sizeof(ds2i_host::pef_chunk));
+            ds2i_host::pef_list_dir().chunks.swap(dirs[t].chunks);
+        }
+    } else {
+    // Device arena: every list is copied byte-for-byte, shifted by <= 3 pad bytes so that its
+    // block_max / block_endpoint tables (which follow vbyte(n)) are dword aligned in HBM.
     uint64_t cursor = 0;
     for (uint64_t t = 0; t < V; ++t) {
         const uint8_t* lp = view.lists + view.list_offsets[t];
@@ -188,10 +252,10 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
         x->list_off[t] = off;
         x->list_end[t] = off + len;
         x->list_n[t] = n;
+        x->list_nb[t] = (uint32_t)nb;
         cursor = off + len;
     }
     x->arena_bytes = ((cursor + 3) & ~uint64_t(3)) + 4096; // zero slack: decoders may over-read
-    std::vector<uint8_t> arena;
     try {
         arena.assign(x->arena_bytes, 0);
     } catch (std::bad_alloc const&) {
@@ -200,12 +264,23 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     for (uint64_t t = 0; t < V; ++t)
         std::memcpy(arena.data() + x->list_off[t], view.lists + view.list_offsets[t],
                     view.list_offsets[t + 1] - view.list_offsets[t]);
+    }
     HIP_OK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, device));
     x->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_OK(hipMalloc((void**)&x->d_arena, x->arena_bytes));
     HIP_OK(hipMemcpy(x->d_arena, arena.data(), x->arena_bytes, hipMemcpyHostToDevice));
+    if (kind == DS2I_OPT) {
+        const uint64_t b0 = oview.docs_bits.nbytes, b1 = oview.freqs_bits.nbytes;
+        HIP_OK(hipMalloc((void**)&x->d_bits0, b0 + 4096));
+        HIP_OK(hipMalloc((void**)&x->d_bits1, b1 + 4096));
+        HIP_OK(hipMemset(x->d_bits0 + b0, 0, 4096));
+        HIP_OK(hipMemset(x->d_bits1 + b1, 0, 4096));
+        HIP_OK(hipMemcpy(x->d_bits0, oview.docs_bits.bytes, b0, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(x->d_bits1, oview.freqs_bits.bytes, b1, hipMemcpyHostToDevice));
+        x->extra_bytes = b0 + b1 + 8192;
+    }
     if (x->has_wand) {
         HIP_OK(hipMalloc((void**)&x->d_norm_lens, 4 * (wv.num_docs + 1)));
         HIP_OK(hipMemcpy(x->d_norm_lens, wv.norm_lens, 4 * wv.num_docs, hipMemcpyHostToDevice));
@@ -222,7 +297,7 @@ void ds2i_hip_index_close(ds2i_hip_index* idx) { free_index(idx); }
 uint64_t ds2i_hip_index_size(const ds2i_hip_index* idx) { return idx ? idx->size : 0; }
 uint64_t ds2i_hip_index_num_docs(const ds2i_hip_index* idx) { return idx ? idx->num_docs : 0; }
 uint64_t ds2i_hip_index_device_bytes(const ds2i_hip_index* idx) {
-    return idx ? idx->arena_bytes + (idx->has_wand ? 4 * idx->num_docs : 0) : 0;
+    return idx ? idx->arena_bytes + idx->extra_bytes + (idx->has_wand ? 4 * idx->num_docs : 0) : 0;
 }
 
 int ds2i_hip_list_size(const ds2i_hip_index* idx, uint32_t term, uint64_t* n) {
@@ -240,16 +315,20 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     *n = len;
     if (capacity < len) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_decode_list: capacity too small");
     HIP_OK(hipSetDevice(idx->device));
-    const uint64_t nb = (len + 127) / 128;
+    const uint64_t nb = idx->list_nb[term];
     uint32_t *d_docs = nullptr, *d_freqs = nullptr;
-    HIP_OK(hipMalloc((void**)&d_docs, 4 * nb * 128));
-    HIP_OK(hipMalloc((void**)&d_freqs, 4 * nb * 128));
+    HIP_OK(hipMalloc((void**)&d_docs, 4 * (len + 128)));
+    HIP_OK(hipMalloc((void**)&d_freqs, 4 * (len + 128)));
     DecodeArgs a{};
     a.arena = idx->d_arena;
+    a.bits0 = idx->d_bits0;
+    a.bits1 = idx->d_bits1;
     a.term.list_off = idx->list_off[term];
     a.term.list_end = idx->list_end[term];
     a.term.n = (uint32_t)len;
-    a.term.term = term;
+    a.term.term = idx->kind == DS2I_OPT ? idx->list_nb[term] : term;
+    a.term.aux0 = idx->kind == DS2I_OPT ? idx->list_aux0[term] : 0;
+    a.term.aux1 = idx->kind == DS2I_OPT ? idx->list_aux1[term] : 0;
     a.codec = idx->kind;
     a.num_docs = (uint32_t)idx->num_docs;
     a.out_docs = d_docs;
@@ -305,6 +384,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     b->want_matches = want_matches && (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ);
 
     std::vector<QTerm> qterms;
+    std::vector<uint32_t> qnbs; // blocks / chunks of each query term's list (parallel to qterms)
     std::vector<uint32_t> qoff(nq + 1, 0);
     std::vector<double> qcost(nq, 0.0);   // estimated block decodes of the whole query
     std::vector<uint32_t> qnb0(nq, 0);    // blocks of the shortest list (conjunctive)
@@ -331,7 +411,9 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             qt.list_off = idx->list_off[p.first];
             qt.list_end = idx->list_end[p.first];
             qt.n = idx->list_n[p.first];
-            qt.term = p.first;
+            qt.term = idx->kind == DS2I_OPT ? idx->list_nb[p.first] : p.first;
+            qt.aux0 = idx->kind == DS2I_OPT ? idx->list_aux0[p.first] : 0;
+            qt.aux1 = idx->kind == DS2I_OPT ? idx->list_aux1[p.first] : 0;
             qt.q_weight = 0.f;
             qt.max_weight = 0.f;
             if (ranked) {
@@ -339,20 +421,27 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
                 qt.max_weight = qt.q_weight * idx->max_term_weight[p.first];
             }
             qterms.push_back(qt);
+            qnbs.push_back(idx->list_nb[p.first]);
         }
         double cost = 0;
         if (conj) { // sort by increasing frequency (queries.hpp:53-56, 357-360)
-            std::stable_sort(qterms.begin() + begin, qterms.end(),
-                             [](QTerm const& l, QTerm const& r) { return l.n < r.n; });
+            std::vector<size_t> perm(qterms.size() - begin);
+            for (size_t i = 0; i < perm.size(); ++i) perm[i] = begin + i;
+            std::stable_sort(perm.begin(), perm.end(), [&](size_t l, size_t r) { return qterms[l].n < qterms[r].n; });
+            std::vector<QTerm> tq;
+            std::vector<uint32_t> tn;
+            for (size_t i : perm) { tq.push_back(qterms[i]); tn.push_back(qnbs[i]); }
+            std::copy(tq.begin(), tq.end(), qterms.begin() + begin);
+            std::copy(tn.begin(), tn.end(), qnbs.begin() + begin);
             if (!tf.empty()) {
                 const double n0 = qterms[begin].n;
-                qnb0[q] = (qterms[begin].n + 127u) / 128u;
+                qnb0[q] = qnbs[begin];
                 cost = qnb0[q] * (ranked ? 2.0 : 1.0);
-                for (size_t i = begin + 1; i < qterms.size(); ++i) cost += std::min<double>((qterms[i].n + 127u) / 128u, n0);
+                for (size_t i = begin + 1; i < qterms.size(); ++i) cost += std::min<double>(qnbs[i], n0);
                 b->match_off[q + 1] = 128ull * qnb0[q];
             }
         } else {
-            for (size_t i = begin; i < qterms.size(); ++i) cost += (qterms[i].n + 127u) / 128u * (ranked ? 2.0 : 1.0);
+            for (size_t i = begin; i < qterms.size(); ++i) cost += qnbs[i] * (ranked ? 2.0 : 1.0);
         }
         qoff[q + 1] = (uint32_t)qterms.size();
         qcost[q] = cost;
@@ -471,6 +560,8 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
         if (b->ncls[c]) {
             BatchArgs a{};
             a.arena = idx->d_arena;
+            a.bits0 = idx->d_bits0;
+            a.bits1 = idx->d_bits1;
             a.norm_lens = idx->d_norm_lens;
             a.qterms = b->d_qterms;
             a.q_off = b->d_qoff;

@@ -128,6 +128,32 @@ int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const 
     DS2I_CATCH
 }
 
+int ds2i_opt_list_directory(const void* opt_image, size_t bytes, uint32_t term, ds2i_blob** cmax, ds2i_blob** chunks,
+                            uint64_t info[5]) {
+    if (!opt_image || !cmax || !chunks || !info) return ds2i_set_error(-1, "ds2i_opt_list_directory: null argument");
+    DS2I_TRY
+    opt_index_view v;
+    v.parse(opt_image, bytes);
+    if (term >= v.size) return ds2i_set_error(-3, "term id out of range");
+    pef_list_dir dir;
+    v.build_dir(term, dir);
+    auto* bc = new ds2i_blob;
+    auto* bk = new ds2i_blob;
+    const uint8_t* p = (const uint8_t*)dir.cmax.data();
+    bc->data.assign(p, p + 4 * dir.cmax.size());
+    p = (const uint8_t*)dir.chunks.data();
+    bk->data.assign(p, p + sizeof(pef_chunk) * dir.chunks.size());
+    *cmax = bc;
+    *chunks = bk;
+    info[0] = dir.n;
+    info[1] = dir.docs_bit0;
+    info[2] = dir.freqs_bit0;
+    info[3] = (uint64_t)(v.docs_bits.bytes - (const uint8_t*)opt_image);
+    info[4] = (uint64_t)(v.freqs_bits.bytes - (const uint8_t*)opt_image);
+    return 0;
+    DS2I_CATCH
+}
+
 uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term) {
     (void)term;
     return p ? p->num_docs : 0;

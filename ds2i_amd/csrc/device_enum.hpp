@@ -13,11 +13,13 @@
 #pragma once
 #include "abi_structs.hpp"
 #include "device_codecs.hpp"
+#include "device_pef.hpp"
 
 namespace ds2i_dev {
 
 enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
-       M_QW, M_MAXW, M_END_LO, M_END_HI, M_WORDS };
+       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_PAD0, M_PAD1, M_PAD2,
+       M_WORDS }; // 24 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
 #define PT_BEGIN(cx) const unsigned long long pt_t0_ = __builtin_readcyclecounter()
@@ -35,8 +37,11 @@ struct CtxT {
     uint32_t* exc;   // [EXC_DW]
     Window win;
     const uint8_t* arena;
+    const uint8_t* bits0; // opt index: docs / freqs bit vectors
+    const uint8_t* bits1;
     int codec;
     uint32_t num_docs;
+    DS2I_DEV bool is_pef() const { return CODEC_T == CODEC_PEF || (CODEC_T < 0 && codec == CODEC_PEF); }
     // per-wave statistics (wave-uniform)
     uint32_t s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
     unsigned long long s_bytes;
@@ -72,8 +77,71 @@ struct CtxT {
     }
 
     // ---- decode_docs_block (block_posting_list.hpp:292-319)
+    // ---- opt index: chunk b of the list = <=128 elements of one docs partition (device_pef.hpp)
+    DS2I_DEV void decode_docs_pef(uint32_t s, uint32_t b) {
+        const uint32_t lane = lane_id();
+        const uint8_t* cmaxp = ptr(s, M_MAXS_LO);
+        const uint32_t* ent = (const uint32_t*)(ptr(s, M_END_LO) + (uint64_t)b * (4 * PC_WORDS));
+        uint32_t ev = 0;
+        if (lane < PC_WORDS) ev = ent[lane];
+        if (lane == PC_WORDS) ev = ((const uint32_t*)cmaxp)[b];
+        const uint32_t packed = bcast(ev, PC_PACKED), cnt = packed & 0xFFu;
+        const uint32_t bmax = bcast(ev, PC_WORDS);
+        const uint64_t bit0 = ((uint64_t)m(s, M_DBIT_HI) << 32) | m(s, M_DBIT_LO);
+        uint32_t v0, v1;
+        pef_decode_side<false>(bits0, bit0, (packed >> 8) & 3u, (packed >> 10) & 63u, bcast(ev, PC_D_BASE), bcast(ev, PC_D_HI),
+                               bcast(ev, PC_D_HBIAS), bcast(ev, PC_D_LO), bcast(ev, PC_SPANS) & 0xFFFFu, cnt, exc, v0, v1);
+        uint32_t* dst = D(s);
+        const uint32_t d0 = lane < cnt ? v0 : 0xFFFFFFFFu;
+        dst[lane] = d0;
+        dst[lane + 64] = lane + 64 < cnt ? v1 : 0xFFFFFFFFu;
+        const uint32_t gpos = bcast(ev, PC_GPOS);
+        if (lane == 0) {
+            uint32_t* mm = meta + s * M_WORDS;
+            mm[M_CUR] = b;
+            mm[M_SIZE] = cnt;
+            mm[M_BMAX] = bmax;
+            mm[M_POS] = 0;
+            mm[M_DOCID] = d0 < num_docs ? d0 : num_docs;
+            mm[M_FDEC] = 0;
+            mm[M_GPOS] = gpos;
+        }
+        wave_sync();
+        ++s_docs_blocks;
+        const uint32_t l = (packed >> 10) & 63u, span = bcast(ev, PC_SPANS) & 0xFFFFu;
+        s_bytes += 4 + ((span + cnt * l + 7) >> 3); // cmax entry + the chunk's high and low bits
+    }
+    DS2I_DEV void decode_freqs_pef(uint32_t s) {
+        const uint32_t lane = lane_id();
+        const uint32_t b = m(s, M_CUR);
+        const uint32_t* ent = (const uint32_t*)(ptr(s, M_END_LO) + (uint64_t)b * (4 * PC_WORDS));
+        uint32_t ev = 0;
+        if (lane < PC_WORDS) ev = ent[lane];
+        const uint32_t packed = bcast(ev, PC_PACKED), cnt = packed & 0xFFu;
+        const uint64_t bit0 = ((uint64_t)m(s, M_FBIT_HI) << 32) | m(s, M_FBIT_LO);
+        uint32_t s0, s1;
+        pef_decode_side<true>(bits1, bit0, (packed >> 16) & 3u, (packed >> 18) & 63u, bcast(ev, PC_F_BASE), bcast(ev, PC_F_HI),
+                              bcast(ev, PC_F_HBIAS), bcast(ev, PC_F_LO), bcast(ev, PC_SPANS) >> 16, cnt, exc, s0, s1);
+        // freq_i = S_i - S_{i-1} (positive_sequence.hpp:48-66); S_{-1} of the chunk comes from the directory
+        uint32_t p0 = __shfl_up(s0, 1), p1 = __shfl_up(s1, 1);
+        const uint32_t fprev = bcast(ev, PC_F_PREV), s0_last = bcast(s0, 63);
+        if (lane == 0) { p0 = fprev; p1 = s0_last; }
+        uint32_t* dst = F(s);
+        dst[lane] = s0 - p0;
+        dst[lane + 64] = s1 - p1;
+        setm(s, M_FDEC, 1);
+        wave_sync();
+        ++s_freqs_blocks;
+        s_bytes += ((bcast(ev, PC_SPANS) >> 16) + cnt * ((packed >> 18) & 63u) + 7) >> 3;
+    }
+
     DS2I_DEV void decode_docs(uint32_t s, uint32_t b) {
         PT_BEGIN(*this);
+        if (is_pef()) {
+            decode_docs_pef(s, b);
+            PT_END(*this, PH_DOCS);
+            return;
+        }
         const uint32_t lane = lane_id();
         const uint8_t* maxs = ptr(s, M_MAXS_LO);
         const uint32_t n = m(s, M_N), nb = m(s, M_NB);
@@ -114,6 +182,7 @@ struct CtxT {
             mm[M_FREQ_LO] = (uint32_t)fo;
             mm[M_FREQ_HI] = (uint32_t)(fo >> 32);
             mm[M_FDEC] = 0;
+            mm[M_GPOS] = b * 128u;
         }
         wave_sync();
         ++s_docs_blocks;
@@ -124,6 +193,11 @@ struct CtxT {
     // ---- decode_freqs_block (block_posting_list.hpp:321-331)
     DS2I_DEV void decode_freqs(uint32_t s) {
         PT_BEGIN(*this);
+        if (is_pef()) {
+            decode_freqs_pef(s);
+            PT_END(*this, PH_FREQS);
+            return;
+        }
         const uint32_t lane = lane_id();
         const uint8_t* p = ptr(s, M_FREQ_LO);
         const uint32_t sz = m(s, M_SIZE);
@@ -146,6 +220,29 @@ struct CtxT {
     // ---- ctor (block_posting_list.hpp:86-103). bind() only records the list geometry; open()
     // additionally decodes block 0 like the reference constructor does.
     DS2I_DEV void bind(uint32_t s, const QTerm& t) {
+        if (is_pef()) { // freq_index::operator[] (freq_index.hpp:192-214); header fields were parsed at upload
+            if (lane_id() == 0) {
+                uint32_t* mm = meta + s * M_WORDS;
+                mm[M_MAXS_LO] = (uint32_t)t.list_off; // cmax[] of the chunk directory
+                mm[M_MAXS_HI] = (uint32_t)(t.list_off >> 32);
+                mm[M_N] = t.n;
+                mm[M_NB] = t.term; // chunks
+                mm[M_QW] = __float_as_uint(t.q_weight);
+                mm[M_MAXW] = __float_as_uint(t.max_weight);
+                mm[M_END_LO] = (uint32_t)t.list_end; // chunk entries
+                mm[M_END_HI] = (uint32_t)(t.list_end >> 32);
+                mm[M_DBIT_LO] = (uint32_t)t.aux0;
+                mm[M_DBIT_HI] = (uint32_t)(t.aux0 >> 32);
+                mm[M_FBIT_LO] = (uint32_t)t.aux1;
+                mm[M_FBIT_HI] = (uint32_t)(t.aux1 >> 32);
+                mm[M_CUR] = 0xFFFFFFFFu;
+                mm[M_BMAX] = 0;
+                mm[M_FDEC] = 0;
+            }
+            wave_sync();
+            s_bytes += 16 + 8; // two collection offsets + gamma(occurrences), n
+            return;
+        }
         const uint32_t n = t.n;
         const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
         const uint64_t maxs = t.list_off + vl;

@@ -307,3 +307,263 @@ private:
 };
 
 } // namespace ds2i_host
+
+// =====================================================================================================
+// Read side used at GPU upload: walk an opt image and flatten it into a per-list CHUNK DIRECTORY.
+// A chunk = <= 128 consecutive postings that lie inside ONE docs partition and ONE freqs partition; the
+// device decodes a chunk like a block of a block index (cmax[] plays block_max[]). The on-disk image is
+// uploaded unchanged (the two bit vectors); the directory is auxiliary, like the list-offset table.
+// =====================================================================================================
+namespace ds2i_host {
+
+struct bit_cursor { // succinct::bit_vector::enumerator
+    bitview const* bv;
+    uint64_t pos;
+    uint64_t take(unsigned l) { uint64_t v = l ? bv->get_bits(pos, l) : 0; pos += l; return v; }
+    uint64_t skip_zeros() { uint64_t z = 0; while (!bv->get(pos)) { ++pos; ++z; } ++pos; return z; }
+};
+inline uint64_t read_gamma(bit_cursor& it) { uint64_t l = it.skip_zeros(); return (it.take((unsigned)l) | (uint64_t(1) << l)) - 1; }
+inline uint64_t read_delta(bit_cursor& it) { uint64_t l = read_gamma(it); return (it.take((unsigned)l) | (uint64_t(1) << l)) - 1; }
+
+struct seq_partition {
+    uint64_t begin, end;   // positions [begin, end) in the list
+    uint64_t base;         // value added to the partition's local values
+    uint64_t upper_bound;  // last value of the partition (absolute)
+    int type;              // SEQ_EF / SEQ_RB / SEQ_ALL_ONES
+    uint64_t lower_bits;   // EF
+    uint64_t hi_offset;    // EF: higher_bits_offset ; RB: bits_offset (absolute bit positions)
+    uint64_t lo_offset;    // EF: lower_bits_offset
+};
+
+template <bool STRICT>
+inline void describe_base(bitview const& bv, uint64_t offset, uint64_t universe, uint64_t n, global_parameters const& params,
+                          seq_partition& p) {
+    const global_parameters sp = STRICT ? strict_params(params) : params;
+    p.lower_bits = 0;
+    p.hi_offset = p.lo_offset = 0;
+    if (universe == n) { p.type = SEQ_ALL_ONES; return; }
+    p.type = (int)(bv.get_bits(offset, 1));
+    if (p.type == SEQ_EF) {
+        ef_offsets of(offset + 1, STRICT ? universe - n + 1 : universe, n, sp);
+        p.lower_bits = of.lower_bits;
+        p.hi_offset = of.higher_bits_offset;
+        p.lo_offset = of.lower_bits_offset;
+    } else {
+        rb_offsets of(offset + 1, universe, n, sp);
+        p.hi_offset = of.bits_offset;
+    }
+}
+
+// partitioned_sequence header (partitioned_sequence.hpp:131-178) -> list of partitions
+template <bool STRICT>
+inline void walk_partitioned(bitview const& bv, uint64_t offset, uint64_t universe, uint64_t n, global_parameters const& params,
+                             std::vector<seq_partition>& out) {
+    out.clear();
+    bit_cursor it{&bv, offset};
+    const uint64_t partitions = read_gamma(it) + 1;
+    if (partitions == 1) {
+        seq_partition p;
+        p.begin = 0;
+        p.end = n;
+        p.base = it.take((unsigned)ceil_log2(universe));
+        uint64_t ub = 0;
+        if (n > 1) {
+            uint64_t ud = read_delta(it);
+            ub = ud ? ud : (universe - p.base - 1);
+        }
+        p.upper_bound = p.base + ub;
+        describe_base<STRICT>(bv, it.pos, ub + 1, n, params, p);
+        out.push_back(p);
+        return;
+    }
+    const uint64_t endpoint_bits = read_gamma(it);
+    uint64_t cur = it.pos;
+    std::vector<uint64_t> sizes, ubs;
+    ef_decode_all(bv, cur, n, partitions - 1, params, sizes);
+    cur += ef_bitsize(params, n, partitions - 1);
+    ef_decode_all(bv, cur, universe, partitions + 1, params, ubs);
+    cur += ef_bitsize(params, universe, partitions + 1);
+    const uint64_t endpoints_offset = cur;
+    const uint64_t sequences_offset = cur + endpoint_bits * (partitions - 1);
+    out.reserve(partitions);
+    for (uint64_t k = 0; k < partitions; ++k) {
+        seq_partition p;
+        p.begin = k ? sizes[k - 1] : 0;
+        p.end = k + 1 < partitions ? sizes[k] : n;
+        p.base = k ? ubs[k] + 1 : ubs[0];
+        p.upper_bound = ubs[k + 1];
+        uint64_t endpoint = k ? bv.get_bits(endpoints_offset + (k - 1) * endpoint_bits, (unsigned)endpoint_bits) : 0;
+        describe_base<STRICT>(bv, sequences_offset + endpoint, p.upper_bound - p.base + 1, p.end - p.begin, params, p);
+        out.push_back(p);
+    }
+}
+
+// sequential cursor over the set bits of one partition's high bits / bitmap
+struct ones_cursor {
+    bitview const* bv = nullptr;
+    uint64_t pos = 0;   // bit position of the current (rank-th) one
+    uint64_t rank = 0;  // index of the element at `pos`
+    void start(bitview const& b, uint64_t from) { // positions on the first one at/after `from`
+        bv = &b;
+        pos = from;
+        rank = 0;
+        while (!bv->get(pos)) ++pos;
+    }
+    void advance_to(uint64_t r) { // r >= rank; afterwards pos = position of the r-th one
+        while (rank < r) {
+            uint64_t scan = pos + 1, w;
+            for (;;) {
+                w = bv->get_bits(scan, 56);
+                if (w) break;
+                scan += 56;
+            }
+            const uint64_t pc = (uint64_t)__builtin_popcountll(w);
+            if (rank + pc <= r) { // take the whole window: land on its last one
+                rank += pc;
+                pos = scan + (63 - (uint64_t)__builtin_clzll(w));
+            } else {
+                for (uint64_t k = r - rank - 1; k; --k) w &= w - 1;
+                pos = scan + (uint64_t)__builtin_ctzll(w);
+                rank = r;
+            }
+        }
+    }
+};
+
+// one side (docs or freqs) of a chunk, as the device consumes it (bit offsets relative to the list's sequence start)
+struct chunk_side { uint32_t type, l, base, hi, hbias, lo, span; };
+
+struct pef_chunk { // 12 dwords, see device_pef.hpp
+    uint32_t gpos, packed, d_base, d_hi, d_hbias, d_lo, f_base, f_hi, f_hbias, f_lo, f_prev, spans;
+};
+
+struct pef_list_dir {
+    uint32_t n = 0;
+    uint64_t docs_bit0 = 0, freqs_bit0 = 0; // absolute bit offsets all rel fields are relative to
+    std::vector<uint32_t> cmax;
+    std::vector<pef_chunk> chunks;
+};
+
+struct opt_index_view {
+    global_parameters params;
+    uint64_t num_docs = 0, size = 0;
+    bitview docs_endpoints, docs_bits, freqs_endpoints, freqs_bits;
+    std::vector<uint64_t> docs_off, freqs_off;
+    static void take_bv(reader& r, bitview& bv) {
+        bv.nbits = r.pod<uint64_t>();
+        uint64_t nw = r.pod<uint64_t>();
+        if (nw != ceil_div(bv.nbits, (uint64_t)64)) throw std::runtime_error("bad bit vector in opt image");
+        bv.nbytes = 8 * nw;
+        bv.bytes = r.take(8 * nw);
+    }
+    void parse(const void* image, size_t bytes) {
+        reader r(image, bytes);
+        params.ef_log_sampling0 = r.pod<uint8_t>();
+        params.ef_log_sampling1 = r.pod<uint8_t>();
+        params.rb_log_rank1_sampling = r.pod<uint8_t>();
+        params.rb_log_sampling1 = r.pod<uint8_t>();
+        params.log_partition_size = r.pod<uint8_t>();
+        num_docs = r.pod<uint64_t>();
+        size = r.pod<uint64_t>();
+        take_bv(r, docs_endpoints);
+        take_bv(r, docs_bits);
+        uint64_t fsize = r.pod<uint64_t>();
+        take_bv(r, freqs_endpoints);
+        take_bv(r, freqs_bits);
+        if (fsize != size) throw std::runtime_error("docs / freqs collections differ in size");
+        if (num_docs > 0xFFFFFFFFull) throw std::runtime_error("num_docs exceeds 32 bits");
+        if (size) {
+            ef_decode_all(docs_endpoints, 0, docs_bits.nbits, size, params, docs_off);
+            ef_decode_all(freqs_endpoints, 0, freqs_bits.nbits, size, params, freqs_off);
+        }
+    }
+
+    // flatten list t into its chunk directory
+    void build_dir(uint64_t t, pef_list_dir& dir) const {
+        bit_cursor it{&docs_bits, docs_off[t]};
+        const uint64_t occurrences = read_gamma(it) + 1;
+        uint64_t n = 1;
+        if (occurrences > 1) n = it.take((unsigned)ceil_log2(occurrences + 1));
+        if (!n || n > 0xFFFFFFFFull) throw std::runtime_error("corrupt opt posting list header");
+        std::vector<seq_partition> dp, fp;
+        walk_partitioned<false>(docs_bits, it.pos, num_docs, n, params, dp);
+        walk_partitioned<true>(freqs_bits, freqs_off[t], occurrences + 1, n, params, fp);
+        dir.n = (uint32_t)n;
+        dir.docs_bit0 = docs_off[t];
+        dir.freqs_bit0 = freqs_off[t];
+        dir.cmax.clear();
+        dir.chunks.clear();
+        size_t di = 0, fi = 0;
+        ones_cursor dc, fc;
+        auto start_cursor = [](ones_cursor& c, bitview const& bv, seq_partition const& p) {
+            if (p.type == SEQ_EF) c.start(bv, p.hi_offset);
+            else if (p.type == SEQ_RB) c.start(bv, p.hi_offset);
+        };
+        start_cursor(dc, docs_bits, dp[0]);
+        start_cursor(fc, freqs_bits, fp[0]);
+        uint64_t pos = 0, prev_s = 0;
+        auto value_at = [&](bitview const& bv, seq_partition const& p, ones_cursor& c, uint64_t i, bool strict) -> uint64_t {
+            // local element i of partition p (cursor already at rank i for EF / RB)
+            if (p.type == SEQ_ALL_ONES) return p.base + i;
+            if (p.type == SEQ_RB) return p.base + (c.pos - p.hi_offset);
+            uint64_t high = c.pos - p.hi_offset - i - 1;
+            uint64_t low = bv.get_bits(p.lo_offset + i * p.lower_bits, (unsigned)p.lower_bits);
+            return p.base + ((high << p.lower_bits) | low) + (strict ? i : 0);
+        };
+        auto rel32 = [](uint64_t abs, uint64_t bit0) -> uint32_t {
+            uint64_t r = abs - bit0;
+            if (r > 0xFFFFFFFFull) throw std::runtime_error("posting list too large for the chunk directory");
+            return (uint32_t)r;
+        };
+        while (pos < n) {
+            while (dp[di].end <= pos) { ++di; start_cursor(dc, docs_bits, dp[di]); }
+            while (fp[fi].end <= pos) { ++fi; start_cursor(fc, freqs_bits, fp[fi]); }
+            const seq_partition& D = dp[di];
+            const seq_partition& F = fp[fi];
+            const uint64_t cnt = std::min<uint64_t>(128, std::min(D.end, F.end) - pos);
+            const uint64_t di0 = pos - D.begin, fi0 = pos - F.begin;
+            pef_chunk c{};
+            c.gpos = (uint32_t)pos;
+            uint32_t dspan = 0, fspan = 0;
+            // ---- docs side
+            if (D.type != SEQ_ALL_ONES) dc.advance_to(di0);
+            const uint64_t d_first_hi = dc.pos;
+            if (D.type == SEQ_ALL_ONES) {
+                c.d_base = (uint32_t)(D.base + di0);
+            } else {
+                c.d_base = (uint32_t)D.base;
+                c.d_hi = rel32(d_first_hi, dir.docs_bit0);
+                c.d_hbias = D.type == SEQ_EF ? rel32(D.hi_offset + di0 + 1, dir.docs_bit0) : rel32(D.hi_offset, dir.docs_bit0);
+                c.d_lo = D.type == SEQ_EF ? rel32(D.lo_offset + di0 * D.lower_bits, dir.docs_bit0) : 0;
+            }
+            // last element of the chunk: cmax + span of high bits
+            if (D.type != SEQ_ALL_ONES) dc.advance_to(di0 + cnt - 1);
+            const uint64_t last_doc = value_at(docs_bits, D, dc, di0 + cnt - 1, false);
+            if (D.type != SEQ_ALL_ONES) dspan = (uint32_t)(dc.pos - d_first_hi + 1);
+            // ---- freqs side (strictly increasing prefix sums S)
+            if (F.type != SEQ_ALL_ONES) fc.advance_to(fi0);
+            const uint64_t f_first_hi = fc.pos;
+            if (F.type == SEQ_ALL_ONES) {
+                c.f_base = (uint32_t)(F.base + fi0);
+            } else {
+                c.f_base = (uint32_t)(F.type == SEQ_EF ? F.base + fi0 : F.base);
+                c.f_hi = rel32(f_first_hi, dir.freqs_bit0);
+                c.f_hbias = F.type == SEQ_EF ? rel32(F.hi_offset + fi0 + 1, dir.freqs_bit0) : rel32(F.hi_offset, dir.freqs_bit0);
+                c.f_lo = F.type == SEQ_EF ? rel32(F.lo_offset + fi0 * F.lower_bits, dir.freqs_bit0) : 0;
+            }
+            c.f_prev = (uint32_t)prev_s;
+            if (F.type != SEQ_ALL_ONES) fc.advance_to(fi0 + cnt - 1);
+            prev_s = value_at(freqs_bits, F, fc, fi0 + cnt - 1, true);
+            if (F.type != SEQ_ALL_ONES) fspan = (uint32_t)(fc.pos - f_first_hi + 1);
+            if (dspan > 0xFFFF || fspan > 0xFFFF) { dspan = std::min(dspan, 0xFFFFu); fspan = std::min(fspan, 0xFFFFu); } // 0xFFFF = "scan until count reached"
+            c.packed = (uint32_t)cnt | ((uint32_t)D.type << 8) | ((uint32_t)D.lower_bits << 10) | ((uint32_t)F.type << 16) |
+                       ((uint32_t)F.lower_bits << 18);
+            c.spans = dspan | (fspan << 16);
+            dir.cmax.push_back((uint32_t)last_doc);
+            dir.chunks.push_back(c);
+            pos += cnt;
+        }
+    }
+};
+
+} // namespace ds2i_host

@@ -42,6 +42,8 @@ DS2I_DEV CtxT<CODEC_T> make_ctx(Lds<TMAX>& L, const BatchArgs& a) {
     c.win.gbase = a.arena;
     c.win.nbytes = 0;
     c.arena = a.arena;
+    c.bits0 = a.bits0;
+    c.bits1 = a.bits1;
     c.codec = a.codec;
     c.num_docs = a.num_docs;
     c.init_stats();
@@ -517,29 +519,22 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
     __shared__ Lds<1> L;
     BatchArgs ba{};
     ba.arena = a.arena;
+    ba.bits0 = a.bits0;
+    ba.bits1 = a.bits1;
     ba.codec = a.codec;
     ba.num_docs = a.num_docs;
     Ctx cx = make_ctx<-1>(L, ba);
     const uint32_t lane = lane_id();
-    const uint32_t n = a.term.n, nb = (n + 127u) >> 7;
-    const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
-    const uint64_t maxs = a.term.list_off + vl;
-    if (lane == 0) {
-        L.meta[0][M_MAXS_LO] = (uint32_t)maxs;
-        L.meta[0][M_MAXS_HI] = (uint32_t)(maxs >> 32);
-        L.meta[0][M_N] = n;
-        L.meta[0][M_NB] = nb;
-        L.meta[0][M_END_LO] = (uint32_t)a.term.list_end;
-        L.meta[0][M_END_HI] = (uint32_t)(a.term.list_end >> 32);
-    }
-    wave_sync();
+    cx.bind(0, a.term);
+    const uint32_t nb = cx.m(0, M_NB);
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         cx.decode_docs(0, b);
         cx.decode_freqs(0);
         const uint32_t sz = cx.m(0, M_SIZE);
+        const size_t gpos = cx.m(0, M_GPOS);
         for (uint32_t i = lane; i < sz; i += 64) {
-            a.out_docs[(size_t)b * 128 + i] = L.docs[0][i];
-            a.out_freqs[(size_t)b * 128 + i] = L.freqs[0][i];
+            a.out_docs[gpos + i] = L.docs[0][i];
+            a.out_freqs[gpos + i] = L.freqs[0][i];
         }
         wave_sync();
     }
@@ -581,14 +576,17 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
     // codec goes through the runtime-dispatch instantiation (CODEC_T = -1)
     case OP_AND:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_AND_FREQ:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_RANKED_AND:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;

@@ -52,6 +52,12 @@ int ds2i_encode_block(int codec, const uint32_t* values, uint32_t sum_of_values,
 int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out);
 int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const uint32_t* freqs, ds2i_blob** out);
 
+/* The chunk directory ds2i_hip_index_open builds for one list of an opt image (inspection / test hook):
+ * cmax = u32[nchunks] last doc-id per chunk, chunks = nchunks x 12 dwords (ds2i_amd/csrc/device_pef.hpp),
+ * info = {n, docs_bit0, freqs_bit0, docs bit-vector byte offset in the image, freqs bit-vector byte offset} */
+int ds2i_opt_list_directory(const void* opt_image, size_t bytes, uint32_t term, ds2i_blob** cmax, ds2i_blob** chunks,
+                            uint64_t info[5]);
+
 /* synthetic collection */
 uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term);
 int ds2i_synth_list(const ds2i_synth_params* p, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,

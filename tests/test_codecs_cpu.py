@@ -15,7 +15,7 @@ import ds2i_amd as d
 import oracle as o
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "appendix_c.json")
-CODECS = list(d.CODECS)
+CODECS = list(d.BLOCK_CODECS)
 
 
 @pytest.mark.parametrize("codec", CODECS)

@@ -149,6 +149,59 @@ def test_query_op_concept(coll, images):
     np.testing.assert_allclose(op.topk(), exp, rtol=RTOL)
 
 
+def test_opt_index_partition_shapes(built_lib):
+    """opt index on the GPU: singletons, all-ones runs, bitmap partitions, long multi-partition lists, tiny lists in a
+    big universe (the shapes of test_partitioned_sequence.cpp) -- decode + next_geq-driven intersections."""
+    N = 1 << 22
+    rng = np.random.default_rng(13)
+    lists = [(np.array([5], np.uint32), np.array([3], np.uint32)),
+             (np.array([N - 1], np.uint32), np.array([1], np.uint32)),
+             (np.array([0, N - 1], np.uint32), np.array([1, 2], np.uint32)),
+             (np.arange(1000, 1000 + 5000, dtype=np.uint32), np.ones(5000, np.uint32)),
+             (np.sort(rng.choice(3 * 4096, 4096, replace=False) + 777).astype(np.uint32), rng.integers(1, 9, 4096).astype(np.uint32)),
+             (np.sort(rng.choice(N, 30000, replace=False)).astype(np.uint32), rng.integers(1, 300, 30000).astype(np.uint32)),
+             (np.concatenate([np.arange(100, 2100), np.sort(rng.choice(N - 10000, 3000, replace=False)) + 10000]).astype(np.uint32),
+              rng.integers(1, 4, 5000).astype(np.uint32))]
+    img = d.build_index("opt", N, lists)
+    wand = d.build_wand(np.full(N, 100, np.uint32), lists)
+    gidx = d.Index("opt", img, wand)
+    oidx = o.Index("opt", img, wand)
+    for t, (docs, freqs) in enumerate(lists):
+        dd, ff = gidx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+    queries = [[a, b] for a in range(7) for b in range(a, 7)] + [[3, 4, 5], [3, 4, 6], [4, 5, 6], [2, 5], [0, 1]]
+    for op in ALL_OPS:
+        _check_against_oracle(gidx, oidx, op, queries)
+
+
+def test_full_size_c2_opt_index(built_lib):
+    """BASELINE configs[2] shape at configs[1] scale: opt (PEF) index, ranked_and, 4096-query batch, every query vs oracle."""
+    p = d.SynthParams(seed=0xD5210002, num_docs=1000000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128,
+                      clustered_every=4)
+    img, wand, postings = d.synth_build(p, "opt")
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
+    gidx = d.Index("opt", img, wand)
+    oidx = o.Index("opt", img, wand)
+    for op in ("and", "ranked_and"):
+        count, topk, tlen, _ = gidx.query_batch(op, queries)
+        oc, otopk, otlen, _, _ = oidx.query_batch(op, queries)
+        assert np.array_equal(count, oc)
+        if op == "ranked_and":
+            assert np.array_equal(tlen, otlen)
+            f = np.isfinite(otopk)
+            np.testing.assert_allclose(topk[f], otopk[f], rtol=RTOL)
+    sub = queries[:256]
+    _, t_or, l_or, _ = gidx.query_batch("ranked_or", sub)
+    _, o_or, ol_or, _, _ = oidx.query_batch("ranked_or", sub)
+    assert np.array_equal(l_or, ol_or)
+    f = np.isfinite(o_or)
+    np.testing.assert_allclose(t_or[f], o_or[f], rtol=RTOL)
+    for op in ("wand", "maxscore"):
+        _, t2, l2, _ = gidx.query_batch(op, sub)
+        assert np.array_equal(l_or, l2)
+        np.testing.assert_allclose(t2[f], t_or[f], rtol=RTOL)
+
+
 def test_full_size_c2_properties(built_lib):
     """BASELINE configs[1]: 1M docs Zipf, block_optpfor, 4096-query batch. Parity on every query against the
     oracle (it finishes in seconds) plus size-independent properties."""

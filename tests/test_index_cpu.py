@@ -12,7 +12,7 @@ import ds2i_amd as d
 import oracle as o
 from helpers import Collection, small_params
 
-CODECS = list(d.CODECS)
+CODECS = list(d.BLOCK_CODECS)
 
 
 @pytest.fixture(scope="module")

@@ -99,3 +99,50 @@ def test_queries_match_brute_force(coll, idx):
 
 def test_opt_is_smaller_than_block_indexes(coll):
     assert len(coll.index_image("opt")) < len(coll.index_image("block_optpfor"))
+
+
+def _emulate_chunk_side(bits, bit0, typ, l, base, hi, hbias, lo, count, freq):
+    """Python restatement of device_pef.hpp::pef_decode_side from the directory fields (bits = python int)."""
+    if typ == 2:
+        return [base + j for j in range(count)]
+    out, pos = [], bit0 + hi
+    for j in range(count):
+        while not (bits >> pos) & 1:
+            pos += 1
+        hp = pos - bit0
+        if typ == 1:
+            out.append(base + (hp - hbias))
+        else:
+            low = (bits >> (bit0 + lo + j * l)) & ((1 << l) - 1) if l else 0
+            out.append(base + (((hp - hbias - j) << l) | low) + (j if freq else 0))
+        pos += 1
+    return out
+
+
+def test_upload_chunk_directory(coll):
+    """The directory built at GPU upload (host_pef.hpp::build_dir) decodes back to the raw lists with the device's
+    formulas: chunks never cross a docs or freqs partition, cmax[] is each chunk's last doc-id."""
+    img = coll.index_image("opt")
+    for t in list(range(0, len(coll.lists), 11)) + [0, 1]:
+        docs, freqs = coll.lists[t]
+        cmax, chunks, (n, dbit0, fbit0, doff, foff) = d.opt_list_directory(img, t)
+        assert n == len(docs) and len(cmax) == len(chunks)
+        dbits = int.from_bytes(img[doff:], "little")  # the bit vector words start at this byte; later bytes are harmless
+        fbits = int.from_bytes(img[foff:], "little")
+        pos = 0
+        for b, c in enumerate(chunks):
+            gpos, packed = int(c[0]), int(c[1])
+            cnt = packed & 0xFF
+            assert gpos == pos and 1 <= cnt <= 128
+            dv = _emulate_chunk_side(dbits, dbit0, (packed >> 8) & 3, (packed >> 10) & 63, int(c[2]), int(c[3]), int(c[4]), int(c[5]), cnt, False)
+            assert dv == docs[pos:pos + cnt].tolist(), (t, b)
+            assert cmax[b] == docs[pos + cnt - 1]
+            sv = _emulate_chunk_side(fbits, fbit0, (packed >> 16) & 3, (packed >> 18) & 63, int(c[6]), int(c[7]), int(c[8]), int(c[9]), cnt, True)
+            prev = int(c[10])
+            fv = [sv[0] - prev] + [sv[i] - sv[i - 1] for i in range(1, cnt)]
+            assert fv == freqs[pos:pos + cnt].tolist(), (t, b)
+            dspan, fspan = int(c[11]) & 0xFFFF, int(c[11]) >> 16
+            if (packed >> 8) & 3 != 2:
+                assert dspan >= cnt
+            pos += cnt
+        assert pos == n

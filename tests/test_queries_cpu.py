@@ -23,7 +23,7 @@ def queries(coll):
     return queries_for(coll, 150) + [[], [5], [5, 5], [7, 3, 7, 3], [0, 1, 2]]
 
 
-@pytest.mark.parametrize("codec", list(d.CODECS))
+@pytest.mark.parametrize("codec", list(d.BLOCK_CODECS))
 def test_and_or_match_brute_force(coll, queries, codec):
     idx = o.Index(codec, coll.index_image(codec), coll.wand_image())
     for q in queries:
