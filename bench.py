@@ -59,7 +59,11 @@ def main():
     from ds2i_amd import sharding as sh
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the query path has no CPU fallback)")
-    rank, local_rank, world, dist = sh.init_distributed("nccl")  # "nccl" is RCCL on ROCm; None when N == 1
+    # "nccl" is RCCL on ROCm; dist is None when N == 1. DS2I_BENCH_BACKEND / DS2I_BENCH_ONE_DEVICE exist only to
+    # exercise the multi-rank code path on a single-GPU box (tests): gloo rendezvous, every rank on cuda:0.
+    rank, local_rank, world, dist = sh.init_distributed(os.environ.get("DS2I_BENCH_BACKEND", "nccl"))
+    if os.environ.get("DS2I_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     d.lib()  # fail loudly if the HIP extension is missing
 

@@ -21,7 +21,7 @@ def init_distributed(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)  # one process per GPU
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world, dist
