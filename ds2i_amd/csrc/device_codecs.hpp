@@ -57,6 +57,22 @@ DS2I_DEV uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 
+template <int CTRL, int ROW_MASK>
+DS2I_DEV uint32_t dpp_max(uint32_t x) {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return x > t ? x : t;
+}
+// wave64 inclusive prefix maximum (unsigned), same DPP pattern as the prefix sum
+DS2I_DEV uint32_t wave_incl_max_scan(uint32_t x) {
+    x = dpp_max<0x111, 0xF>(x);
+    x = dpp_max<0x112, 0xF>(x);
+    x = dpp_max<0x114, 0xF>(x);
+    x = dpp_max<0x118, 0xF>(x);
+    x = dpp_max<0x142, 0xA>(x);
+    x = dpp_max<0x143, 0xC>(x);
+    return x;
+}
+
 // ---- unaligned global loads (lists are byte-aligned on disk; gfx950 under HSA runs
 // in unaligned-access mode, the compiler emits one global_load_dword per memcpy)
 DS2I_DEV uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -265,13 +281,37 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
     }
     if (nexc) {
         const uint32_t need = 2 * nexc;
-        uint32_t off = 0;
-        for (uint32_t j = 0; j < ew && off < need; ++j) {
-            const uint32_t word = uniform(fast ? blk[1 + j] : w.rd32(p + 4 + 4 * j));
+        if (ew <= 64) {
+            // one lane per Simple16 WORD computes (count, offset); then one lane per VALUE finds its word with a
+            // prefix-max over start markers and extracts its field -- no per-word serial loop
+            const uint32_t word = lane < ew ? (fast ? blk[1 + lane] : w.rd32(p + 4 + 4 * lane)) : 0u;
             const uint32_t d = S16_DESC[word >> 28];
-            const uint32_t cnt = (d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31);
-            if (lane < cnt && off + lane < EXC_DW) exc[off + lane] = s16_value(word, d, lane);
-            off += cnt;
+            const uint32_t cnt = lane < ew ? (d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31) : 0u;
+            const uint32_t off = wave_incl_scan(cnt) - cnt; // first value index of my word
+            for (uint32_t r0 = 0; r0 < need; r0 += 64) {
+                out[lane] = 0;
+                if (lane < ew && off - r0 < 64u) out[off - r0] = lane + 1; // words hold >= 1 value: starts are distinct
+                const uint32_t carry = (uint32_t)__builtin_popcountll(ballot(lane < ew && off < r0)); // words begun before r0
+                wave_sync();
+                uint32_t mk = out[lane];
+                wave_sync();
+                mk = wave_incl_max_scan(mk);
+                const uint32_t widx = (mk ? mk : carry) - 1u; // word holding value g = r0 + lane
+                const uint32_t g = r0 + lane;
+                const uint32_t wword = (uint32_t)__shfl((int)word, (int)(widx & 63u));
+                const uint32_t wd = (uint32_t)__shfl((int)d, (int)(widx & 63u));
+                const uint32_t woff = (uint32_t)__shfl((int)off, (int)(widx & 63u));
+                if (g < need && g < EXC_DW) exc[g] = s16_value(wword, wd, g - woff);
+            }
+        } else {
+            uint32_t off = 0;
+            for (uint32_t j = 0; j < ew && off < need; ++j) {
+                const uint32_t word = uniform(fast ? blk[1 + j] : w.rd32(p + 4 + 4 * j));
+                const uint32_t d = S16_DESC[word >> 28];
+                const uint32_t cnt = (d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31);
+                if (lane < cnt && off + lane < EXC_DW) exc[off + lane] = s16_value(word, d, lane);
+                off += cnt;
+            }
         }
         out[lane] = v0;
         out[lane + 64] = v1;

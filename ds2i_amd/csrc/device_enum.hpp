@@ -18,7 +18,7 @@
 namespace ds2i_dev {
 
 enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
-       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_PAD0, M_PAD1, M_PAD2,
+       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PAD2,
        M_WORDS }; // 24 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
@@ -147,19 +147,44 @@ struct CtxT {
         const uint32_t n = m(s, M_N), nb = m(s, M_NB);
         const uint8_t* endpoints = maxs + 4ull * nb;
         const uint8_t* data = endpoints + 4ull * (nb - 1);
-        // four independent header words: lanes 0..3 fetch one each, then broadcast
         const uint8_t* lend = ptr(s, M_END_LO);
-        uint32_t hv = 0;
-        if (lane == 0) hv = b ? ld32(endpoints + 4ull * (b - 1)) : 0u;
-        if (lane == 1) hv = ld32(maxs + 4ull * b);
-        if (lane == 2) hv = b ? ld32(maxs + 4ull * (b - 1)) + 1u : 0u;
-        if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
-        const uint32_t ep = bcast(hv, 0), bmax = bcast(hv, 1), base = bcast(hv, 2), next_ep = bcast(hv, 3);
+        const uint32_t cur = m(s, M_CUR);
         const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
-        uint32_t hint = next_ep - ep; // docs+freqs bytes of this block when endpoints are monotone
-        if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
-        const uint8_t* p = data + ep;
-        win.load(p, hint);
+        uint32_t ep, bmax, base, next_ep;
+        const uint8_t* p;
+        if (cur != 0xFFFFFFFFu && b == cur + 1) {
+            // sequential access: the block starts where the previous one ended (its endpoint was read then) and its
+            // base is the previous block_max + 1, so the two remaining table words and the block bytes are fetched
+            // in ONE round trip (window size guessed from the previous block)
+            ep = m(s, M_NEXTEP);
+            base = m(s, M_BMAX) + 1u;
+            p = data + ep;
+            uint32_t hv = 0;
+            if (lane == 1) hv = ld32(maxs + 4ull * b);
+            if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
+            uint32_t guess = m(s, M_HINT) + 32u;
+            if (guess > STAGE_DW * 4 - 4) guess = STAGE_DW * 4 - 4;
+            win.load(p, guess);
+            bmax = bcast(hv, 1);
+            next_ep = bcast(hv, 3);
+        } else {
+            // four independent table words: lanes 0..3 fetch one each, then broadcast; then the block bytes
+            uint32_t hv = 0;
+            if (lane == 0) hv = b ? ld32(endpoints + 4ull * (b - 1)) : 0u;
+            if (lane == 1) hv = ld32(maxs + 4ull * b);
+            if (lane == 2) hv = b ? ld32(maxs + 4ull * (b - 1)) + 1u : 0u;
+            if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
+            ep = bcast(hv, 0);
+            bmax = bcast(hv, 1);
+            base = bcast(hv, 2);
+            next_ep = bcast(hv, 3);
+            uint32_t hint = next_ep - ep; // docs+freqs bytes of this block when endpoints are monotone
+            if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+            p = data + ep;
+            win.load(p, hint);
+        }
+        uint32_t blk_bytes = next_ep - ep;
+        if (blk_bytes > STAGE_DW * 4) blk_bytes = STAGE_DW * 4;
         uint32_t v0, v1;
         uint32_t* dst = D(s);
         uint32_t consumed = decode_block<CODEC_T>(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
@@ -183,6 +208,8 @@ struct CtxT {
             mm[M_FREQ_HI] = (uint32_t)(fo >> 32);
             mm[M_FDEC] = 0;
             mm[M_GPOS] = b * 128u;
+            mm[M_NEXTEP] = next_ep;
+            mm[M_HINT] = blk_bytes;
         }
         wave_sync();
         ++s_docs_blocks;
