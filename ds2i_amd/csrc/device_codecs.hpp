@@ -90,9 +90,16 @@ struct Window {
         uint32_t sh = (uint32_t)(a & 3);
         uint32_t ndw = (sh + want_bytes + 3) >> 2;
         if (ndw > STAGE_DW) ndw = STAGE_DW;
+        if (ndw == 0) ndw = 1;
         nbytes = ndw * 4;
         const uint32_t* g = (const uint32_t*)gbase;
-        for (uint32_t i = lane_id(); i < ndw; i += 64) st[i] = g[i];
+        // branch-free: lanes past the end re-load (and re-store) the last dword instead of being masked off
+        const uint32_t last = ndw - 1;
+        for (uint32_t i0 = 0; i0 < ndw; i0 += 64) {
+            uint32_t i = i0 + lane_id();
+            i = i < last ? i : last;
+            st[i] = g[i];
+        }
         wave_sync();
     }
     DS2I_DEV bool covers(const uint8_t* p, uint32_t len) const {

@@ -152,28 +152,30 @@ struct CtxT {
         const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
         uint32_t ep, bmax, base, next_ep;
         const uint8_t* p;
+        // Table words come from ONE unconditional load with a per-lane address (lane 0: endpoint[b-1], 1: block_max[b],
+        // 2: block_max[b-1], 3: endpoint[b]); lanes whose word does not exist read block_max[b] and are overridden.
+        const uint8_t* a1 = maxs + 4ull * b;
+        const uint8_t* taddr = a1;
+        if (lane == 0 && b) taddr = endpoints + 4ull * (b - 1);
+        if (lane == 2 && b) taddr = maxs + 4ull * (b - 1);
+        if (lane == 3 && b + 1 < nb) taddr = endpoints + 4ull * b;
+        uint32_t hv = ld32(taddr);
+        if (lane == 0 && !b) hv = 0u;
+        if (lane == 2) hv = b ? hv + 1u : 0u;
+        if (lane == 3 && !(b + 1 < nb)) hv = (uint32_t)(lend - data);
         if (cur != 0xFFFFFFFFu && b == cur + 1) {
-            // sequential access: the block starts where the previous one ended (its endpoint was read then) and its
-            // base is the previous block_max + 1, so the two remaining table words and the block bytes are fetched
-            // in ONE round trip (window size guessed from the previous block)
+            // sequential access: the block starts at the endpoint read with the previous block and its base is the
+            // previous block_max + 1, so the table words and the block bytes are fetched in ONE round trip (window
+            // size guessed from the previous block)
             ep = m(s, M_NEXTEP);
             base = m(s, M_BMAX) + 1u;
             p = data + ep;
-            uint32_t hv = 0;
-            if (lane == 1) hv = ld32(maxs + 4ull * b);
-            if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
             uint32_t guess = m(s, M_HINT) + 32u;
             if (guess > STAGE_DW * 4 - 4) guess = STAGE_DW * 4 - 4;
             win.load(p, guess);
             bmax = bcast(hv, 1);
             next_ep = bcast(hv, 3);
         } else {
-            // four independent table words: lanes 0..3 fetch one each, then broadcast; then the block bytes
-            uint32_t hv = 0;
-            if (lane == 0) hv = b ? ld32(endpoints + 4ull * (b - 1)) : 0u;
-            if (lane == 1) hv = ld32(maxs + 4ull * b);
-            if (lane == 2) hv = b ? ld32(maxs + 4ull * (b - 1)) + 1u : 0u;
-            if (lane == 3) hv = (b + 1 < nb) ? ld32(endpoints + 4ull * b) : (uint32_t)(lend - data);
             ep = bcast(hv, 0);
             bmax = bcast(hv, 1);
             base = bcast(hv, 2);
