@@ -29,11 +29,29 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
 #define PT_END(cx, ph) do {} while (0)
 #endif
 
-template <int CODEC_T>
+// Where the per-list enumerator state (M_* words) lives.
+//  MetaLds: in LDS, one writer lane + wave-uniform reads -- needed when the list slot is a run-time value
+//           (document-at-a-time operators walk their lists through an index array);
+//  MetaReg: in registers -- the conjunctive kernels with <=4 lists address every slot with a compile-time
+//           constant (fully unrolled list loops), so the state stays in SGPRs/VGPRs: no LDS round trip, no
+//           v_readfirstlane, and the compiler can CSE the pointer arithmetic.
+struct MetaLds {
+    uint32_t* p;
+    DS2I_DEV uint32_t get(uint32_t s, int f) const { return uniform(p[s * M_WORDS + f]); }
+    DS2I_DEV void set(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) p[s * M_WORDS + f] = v; }
+};
+template <int TMAX>
+struct MetaReg {
+    uint32_t v[TMAX * M_WORDS];
+    DS2I_DEV uint32_t get(uint32_t s, int f) const { return v[s * M_WORDS + f]; }
+    DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = x; }
+};
+
+template <int CODEC_T, class META = MetaLds>
 struct CtxT {
     uint32_t* docs;  // [TMAX][128]
     uint32_t* freqs; // [TMAX][128]
-    uint32_t* meta;  // [TMAX][M_WORDS]
+    META meta;       // [TMAX][M_WORDS]
     uint32_t* exc;   // [EXC_DW]
     Window win;
     const uint8_t* arena;
@@ -49,8 +67,8 @@ struct CtxT {
 
     DS2I_DEV uint32_t* D(uint32_t s) const { return docs + 128 * s; }
     DS2I_DEV uint32_t* F(uint32_t s) const { return freqs + 128 * s; }
-    DS2I_DEV uint32_t m(uint32_t s, int f) const { return uniform(meta[s * M_WORDS + f]); }
-    DS2I_DEV void setm(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) meta[s * M_WORDS + f] = v; }
+    DS2I_DEV uint32_t m(uint32_t s, int f) const { return meta.get(s, f); }
+    DS2I_DEV void setm(uint32_t s, int f, uint32_t v) { meta.set(s, f, v); } // v must be wave-uniform
     DS2I_DEV const uint8_t* ptr(uint32_t s, int lo) const {
         return arena + (((uint64_t)m(s, lo + 1) << 32) | m(s, lo));
     }
@@ -95,17 +113,14 @@ struct CtxT {
         const uint32_t d0 = lane < cnt ? v0 : 0xFFFFFFFFu;
         dst[lane] = d0;
         dst[lane + 64] = lane + 64 < cnt ? v1 : 0xFFFFFFFFu;
-        const uint32_t gpos = bcast(ev, PC_GPOS);
-        if (lane == 0) {
-            uint32_t* mm = meta + s * M_WORDS;
-            mm[M_CUR] = b;
-            mm[M_SIZE] = cnt;
-            mm[M_BMAX] = bmax;
-            mm[M_POS] = 0;
-            mm[M_DOCID] = d0 < num_docs ? d0 : num_docs;
-            mm[M_FDEC] = 0;
-            mm[M_GPOS] = gpos;
-        }
+        const uint32_t gpos = bcast(ev, PC_GPOS), first = bcast(d0, 0);
+        setm(s, M_CUR, b);
+        setm(s, M_SIZE, cnt);
+        setm(s, M_BMAX, bmax);
+        setm(s, M_POS, 0);
+        setm(s, M_DOCID, first < num_docs ? first : num_docs);
+        setm(s, M_FDEC, 0);
+        setm(s, M_GPOS, gpos);
         wave_sync();
         ++s_docs_blocks;
         const uint32_t l = (packed >> 10) & 63u, span = bcast(ev, PC_SPANS) & 0xFFFFu;
@@ -199,20 +214,18 @@ struct CtxT {
         dst[lane] = d0;
         dst[lane + 64] = d1;
         const uint64_t fo = (uint64_t)(p + consumed - arena);
-        if (lane == 0) {
-            uint32_t* mm = meta + s * M_WORDS;
-            mm[M_CUR] = b;
-            mm[M_SIZE] = sz;
-            mm[M_BMAX] = bmax;
-            mm[M_POS] = 0;
-            mm[M_DOCID] = d0 < num_docs ? d0 : num_docs; // num_docs doubles as the unit's doc-id limit
-            mm[M_FREQ_LO] = (uint32_t)fo;
-            mm[M_FREQ_HI] = (uint32_t)(fo >> 32);
-            mm[M_FDEC] = 0;
-            mm[M_GPOS] = b * 128u;
-            mm[M_NEXTEP] = next_ep;
-            mm[M_HINT] = blk_bytes;
-        }
+        const uint32_t first = bcast(d0, 0);
+        setm(s, M_CUR, b);
+        setm(s, M_SIZE, sz);
+        setm(s, M_BMAX, bmax);
+        setm(s, M_POS, 0);
+        setm(s, M_DOCID, first < num_docs ? first : num_docs); // num_docs doubles as the unit's doc-id limit
+        setm(s, M_FREQ_LO, (uint32_t)fo);
+        setm(s, M_FREQ_HI, (uint32_t)(fo >> 32));
+        setm(s, M_FDEC, 0);
+        setm(s, M_GPOS, b * 128u);
+        setm(s, M_NEXTEP, next_ep);
+        setm(s, M_HINT, blk_bytes);
         wave_sync();
         ++s_docs_blocks;
         s_bytes += 4 + consumed; // endpoint + docs part
@@ -250,24 +263,21 @@ struct CtxT {
     // additionally decodes block 0 like the reference constructor does.
     DS2I_DEV void bind(uint32_t s, const QTerm& t) {
         if (is_pef()) { // freq_index::operator[] (freq_index.hpp:192-214); header fields were parsed at upload
-            if (lane_id() == 0) {
-                uint32_t* mm = meta + s * M_WORDS;
-                mm[M_MAXS_LO] = (uint32_t)t.list_off; // cmax[] of the chunk directory
-                mm[M_MAXS_HI] = (uint32_t)(t.list_off >> 32);
-                mm[M_N] = t.n;
-                mm[M_NB] = t.term; // chunks
-                mm[M_QW] = __float_as_uint(t.q_weight);
-                mm[M_MAXW] = __float_as_uint(t.max_weight);
-                mm[M_END_LO] = (uint32_t)t.list_end; // chunk entries
-                mm[M_END_HI] = (uint32_t)(t.list_end >> 32);
-                mm[M_DBIT_LO] = (uint32_t)t.aux0;
-                mm[M_DBIT_HI] = (uint32_t)(t.aux0 >> 32);
-                mm[M_FBIT_LO] = (uint32_t)t.aux1;
-                mm[M_FBIT_HI] = (uint32_t)(t.aux1 >> 32);
-                mm[M_CUR] = 0xFFFFFFFFu;
-                mm[M_BMAX] = 0;
-                mm[M_FDEC] = 0;
-            }
+            setm(s, M_MAXS_LO, (uint32_t)t.list_off); // cmax[] of the chunk directory
+            setm(s, M_MAXS_HI, (uint32_t)(t.list_off >> 32));
+            setm(s, M_N, t.n);
+            setm(s, M_NB, t.term); // chunks
+            setm(s, M_QW, __float_as_uint(t.q_weight));
+            setm(s, M_MAXW, __float_as_uint(t.max_weight));
+            setm(s, M_END_LO, (uint32_t)t.list_end); // chunk entries
+            setm(s, M_END_HI, (uint32_t)(t.list_end >> 32));
+            setm(s, M_DBIT_LO, (uint32_t)t.aux0);
+            setm(s, M_DBIT_HI, (uint32_t)(t.aux0 >> 32));
+            setm(s, M_FBIT_LO, (uint32_t)t.aux1);
+            setm(s, M_FBIT_HI, (uint32_t)(t.aux1 >> 32));
+            setm(s, M_CUR, 0xFFFFFFFFu);
+            setm(s, M_BMAX, 0);
+            setm(s, M_FDEC, 0);
             wave_sync();
             s_bytes += 16 + 8; // two collection offsets + gamma(occurrences), n
             return;
@@ -275,20 +285,17 @@ struct CtxT {
         const uint32_t n = t.n;
         const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
         const uint64_t maxs = t.list_off + vl;
-        if (lane_id() == 0) {
-            uint32_t* mm = meta + s * M_WORDS;
-            mm[M_MAXS_LO] = (uint32_t)maxs;
-            mm[M_MAXS_HI] = (uint32_t)(maxs >> 32);
-            mm[M_N] = n;
-            mm[M_NB] = (n + 127u) >> 7;
-            mm[M_QW] = __float_as_uint(t.q_weight);
-            mm[M_MAXW] = __float_as_uint(t.max_weight);
-            mm[M_END_LO] = (uint32_t)t.list_end;
-            mm[M_END_HI] = (uint32_t)(t.list_end >> 32);
-            mm[M_CUR] = 0xFFFFFFFFu; // no block decoded yet
-            mm[M_BMAX] = 0;
-            mm[M_FDEC] = 0;
-        }
+        setm(s, M_MAXS_LO, (uint32_t)maxs);
+        setm(s, M_MAXS_HI, (uint32_t)(maxs >> 32));
+        setm(s, M_N, n);
+        setm(s, M_NB, (n + 127u) >> 7);
+        setm(s, M_QW, __float_as_uint(t.q_weight));
+        setm(s, M_MAXW, __float_as_uint(t.max_weight));
+        setm(s, M_END_LO, (uint32_t)t.list_end);
+        setm(s, M_END_HI, (uint32_t)(t.list_end >> 32));
+        setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
+        setm(s, M_BMAX, 0);
+        setm(s, M_FDEC, 0);
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
     }
@@ -367,10 +374,8 @@ struct CtxT {
             idx = 64 + l;
             val = bcast(d1, l);
         }
-        if (lane == 0) {
-            meta[s * M_WORDS + M_POS] = idx;
-            meta[s * M_WORDS + M_DOCID] = val < num_docs ? val : num_docs;
-        }
+        setm(s, M_POS, idx);
+        setm(s, M_DOCID, val < num_docs ? val : num_docs);
         wave_sync();
     }
 
@@ -389,11 +394,9 @@ struct CtxT {
             s_bytes += 4;
             decode_docs(s, cur + 1);
         } else {
-            uint32_t v = D(s)[pos];
-            if (lane_id() == 0) {
-                meta[s * M_WORDS + M_POS] = pos;
-                meta[s * M_WORDS + M_DOCID] = v < num_docs ? v : num_docs;
-            }
+            uint32_t v = uniform(D(s)[pos]);
+            setm(s, M_POS, pos);
+            setm(s, M_DOCID, v < num_docs ? v : num_docs);
             wave_sync();
         }
     }
@@ -405,7 +408,7 @@ struct CtxT {
     }
 };
 
-typedef CtxT<-1> Ctx;
+typedef CtxT<-1, MetaLds> Ctx;
 
 // bm25::doc_term_weight (bm25.hpp:11-15). Compiled with -ffp-contract=off so the
 // float32 operation order matches the reference exactly.

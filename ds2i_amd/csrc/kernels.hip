@@ -12,17 +12,19 @@
 //   k_selftest      primitives (scan, ballot) used by the GPU unit tests
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_enum.hpp"
 
 using namespace ds2i_dev;
 
 namespace {
 
-template <int TMAX>
+template <int TMAX, bool META_IN_LDS = true>
 struct Lds {
     uint32_t docs[TMAX][128];
     uint32_t freqs[TMAX][128];
-    uint32_t meta[TMAX][M_WORDS];
+    uint32_t meta[META_IN_LDS ? TMAX : 1][META_IN_LDS ? M_WORDS : 1];
     uint32_t exc[EXC_DW];
     uint32_t st[STAGE_DW];
     uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring; row 0 unused
@@ -31,12 +33,15 @@ struct Lds {
     DS2I_DEV float* ub() { return (float*)&pos[0][64]; }             // maxscore upper_bounds [TMAX<=16]
 };
 
-template <int CODEC_T, int TMAX>
-DS2I_DEV CtxT<CODEC_T> make_ctx(Lds<TMAX>& L, const BatchArgs& a) {
-    CtxT<CODEC_T> c;
+DS2I_DEV void bind_meta(MetaLds& m, uint32_t* lds_meta) { m.p = lds_meta; }
+template <int T> DS2I_DEV void bind_meta(MetaReg<T>&, uint32_t*) {}
+
+template <int CODEC_T, class META, class LDS>
+DS2I_DEV CtxT<CODEC_T, META> make_ctx(LDS& L, const BatchArgs& a) {
+    CtxT<CODEC_T, META> c;
     c.docs = &L.docs[0][0];
     c.freqs = &L.freqs[0][0];
-    c.meta = &L.meta[0][0];
+    bind_meta(c.meta, &L.meta[0][0]);
     c.exc = L.exc;
     c.win.st = L.st;
     c.win.gbase = a.arena;
@@ -75,11 +80,35 @@ DS2I_DEV bool member_bsearch(const uint32_t* d, uint32_t c, bool want, uint32_t&
     return want && d[idx] == c;
 }
 
+// Runs body(i) for i in [FROM, nt); body returns false to break. With REG the loop is expanded at compile time
+// (template recursion), so i is a constant inside the body and the register-resident enumerator state is never
+// indexed dynamically; otherwise it is a plain loop.
+template <int I, int N, class F>
+DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
+    if constexpr (I < N) {
+        if ((uint32_t)I >= nt) return true;
+        if (!f(std::integral_constant<uint32_t, (uint32_t)I>{})) return false;
+        return static_list_loop<I + 1, N>(nt, f);
+    }
+    return true;
+}
+#define DS2I_LIST_LOOP(FROM, body)                                   \
+    if constexpr (REG) {                                             \
+        static_list_loop<(FROM), TMAX>(nt, body);                    \
+    } else {                                                         \
+        for (uint32_t i_ = (FROM); i_ < nt; ++i_)                    \
+            if (!body(i_)) break;                                    \
+    }
+
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T>
 __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
-    __shared__ Lds<TMAX> L;
+    // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
+    // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
+    constexpr bool REG = TMAX <= 4;
+    typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
+    __shared__ Lds<TMAX, !REG> L;
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T> cx = make_ctx<CODEC_T>(L, a);
+    CtxT<CODEC_T, META> cx = make_ctx<CODEC_T, META>(L, a);
     // one work unit per (single-wave) workgroup, costliest units first: the hardware dispatcher
     // interleaves the workgroups of the concurrently running LDS classes as resources free up
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
@@ -101,7 +130,8 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
         }
         // list 0 (shortest) drives; the unit owns its blocks [blk_begin, blk_end). The other lists are
         // bound lazily: their first block is located by the first candidate (no block-0 decode).
-        for (uint32_t i = 0; i < nt; ++i) cx.bind(i, a.qterms[t0 + i]);
+        auto bind_one = [&](auto ic) __attribute__((always_inline)) { const uint32_t i = ic; cx.bind(i, a.qterms[t0 + i]); return true; };
+        DS2I_LIST_LOOP(0, bind_one)
         const unsigned long long mbase = a.out_matches ? a.match_off[q] + 128ull * u.blk_begin : 0;
         const unsigned long long mcap = a.out_matches ? 128ull * (u.blk_end - u.blk_begin) : 0;
         cx.s_bytes += 4;
@@ -124,9 +154,10 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
             uint32_t hi = cx.m(0, M_BMAX);
             const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
             bool al0 = c0 >= lo && c0 != 0xFFFFFFFFu, al1 = c1 >= lo && c1 != 0xFFFFFFFFu;
-            for (uint32_t i = 1; i < nt; ++i) {
+            auto probe_list = [&](auto ic) __attribute__((always_inline)) -> bool {
+                const uint32_t i = ic;
                 uint64_t b0 = ballot(al0), b1 = ballot(al1);
-                if (!(b0 | b1)) break;
+                if (!(b0 | b1)) return false;
                 uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
                 if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
                     uint32_t cur = cx.m(i, M_CUR);
@@ -137,7 +168,7 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                         cx.s_bytes += 4;
                         al0 = al1 = false;
                         finished = true;
-                        break;
+                        return false;
                     }
                     // a lazily bound list is positioned by one 64-ary search, not a scan from block 0
                     cx.s_bm_examined += (cur == 0xFFFFFFFFu) ? 1u : blk - cur;
@@ -181,7 +212,9 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                     if (al1) L.pos[i][lane + 64] = (uint8_t)p1;
                 }
                 PT_END(cx, PH_MEMBER);
-            }
+                return true;
+            };
+            DS2I_LIST_LOOP(1, probe_list)
             // candidates that survived every list and lie inside the window are matches
             al0 = al0 && c0 <= hi;
             al1 = al1 && c1 <= hi;
@@ -210,7 +243,8 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                         cx.s_scored += ns;
                     }
                     uint32_t fs = 0;
-                    for (uint32_t i = 0; i < nt; ++i) {
+                    auto score_list = [&](auto ic) __attribute__((always_inline)) -> bool {
+                        const uint32_t i = ic;
                         if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
                         const uint32_t* f = L.freqs[i];
                         uint32_t f0 = 0, f1 = 0;
@@ -223,7 +257,9 @@ __global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
                         } else {
                             fs += f0 + f1;
                         }
-                    }
+                        return true;
+                    };
+                    DS2I_LIST_LOOP(0, score_list)
                     if (WITH_FREQS && !RANKED) {
                         for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
                         fsum += fs;
@@ -333,7 +369,7 @@ template <int OP, int TMAX>
 __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     __shared__ Lds<TMAX> L;
     const uint32_t lane = lane_id();
-    Ctx cx = make_ctx<-1>(L, a);
+    Ctx cx = make_ctx<-1, MetaLds>(L, a);
     constexpr bool RANKED = OP >= OP_RANKED_AND;
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         // a unit of these operators is a doc-id range [blk_begin, blk_end) of the query (whole range when
@@ -523,7 +559,7 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
     ba.bits1 = a.bits1;
     ba.codec = a.codec;
     ba.num_docs = a.num_docs;
-    Ctx cx = make_ctx<-1>(L, ba);
+    Ctx cx = make_ctx<-1, MetaLds>(L, ba);
     const uint32_t lane = lane_id();
     cx.bind(0, a.term);
     const uint32_t nb = cx.m(0, M_NB);
