@@ -36,12 +36,17 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
 //           constant (fully unrolled list loops), so the state stays in SGPRs/VGPRs: no LDS round trip, no
 //           v_readfirstlane, and the compiler can CSE the pointer arithmetic.
 struct MetaLds {
+    static constexpr bool PREFETCH = false;
     uint32_t* p;
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return uniform(p[s * M_WORDS + f]); }
     DS2I_DEV void set(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) p[s * M_WORDS + f] = v; }
 };
 template <int TMAX>
 struct MetaReg {
+    static constexpr bool PREFETCH = TMAX <= 2; // 3-4 lists: the extra VGPRs cost more occupancy than the prefetch wins
+    // software prefetch of each list's NEXT sequential block (issued right after a block is decoded, consumed by the
+    // next decode of that list if it is indeed block+1): table words + 512 B of block bytes, per lane
+    uint32_t pf_blk[TMAX], pf_tab[TMAX], pf_w0[TMAX], pf_w1[TMAX];
     uint32_t v[TMAX * M_WORDS];
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return v[s * M_WORDS + f]; }
     DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = x; }
@@ -167,6 +172,23 @@ struct CtxT {
         const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
         uint32_t ep, bmax, base, next_ep;
         const uint8_t* p;
+        bool have = false;
+        if constexpr (META::PREFETCH) {
+            if (cur != 0xFFFFFFFFu && meta.pf_blk[s] == b) { // the bytes are already in registers
+                have = true;
+                ep = m(s, M_NEXTEP);
+                base = m(s, M_BMAX) + 1u;
+                p = data + ep;
+                win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
+                win.nbytes = 512;
+                win.st[lane] = meta.pf_w0[s];
+                win.st[lane + 64] = meta.pf_w1[s];
+                wave_sync();
+                bmax = bcast(meta.pf_tab[s], 1);
+                next_ep = bcast(meta.pf_tab[s], 3);
+            }
+        }
+        if (!have) {
         // Table words come from ONE unconditional load with a per-lane address (lane 0: endpoint[b-1], 1: block_max[b],
         // 2: block_max[b-1], 3: endpoint[b]); lanes whose word does not exist read block_max[b] and are overridden.
         const uint8_t* a1 = maxs + 4ull * b;
@@ -200,6 +222,7 @@ struct CtxT {
             p = data + ep;
             win.load(p, hint);
         }
+        }
         uint32_t blk_bytes = next_ep - ep;
         if (blk_bytes > STAGE_DW * 4) blk_bytes = STAGE_DW * 4;
         uint32_t v0, v1;
@@ -226,6 +249,21 @@ struct CtxT {
         setm(s, M_GPOS, b * 128u);
         setm(s, M_NEXTEP, next_ep);
         setm(s, M_HINT, blk_bytes);
+        if constexpr (META::PREFETCH) {
+            meta.pf_blk[s] = 0xFFFFFFFFu;
+            if (b + 1 < nb) { // speculate that this list's next access is block b+1
+                const uint32_t nb1 = b + 1;
+                const uint8_t* taddr = maxs + 4ull * nb1;
+                if (lane == 3 && nb1 + 1 < nb) taddr = endpoints + 4ull * nb1;
+                uint32_t hv = ld32(taddr);
+                if (lane == 3 && !(nb1 + 1 < nb)) hv = (uint32_t)(lend - data);
+                const uint32_t* g = (const uint32_t*)((uintptr_t)(data + next_ep) & ~(uintptr_t)3);
+                meta.pf_tab[s] = hv;
+                meta.pf_w0[s] = g[lane];
+                meta.pf_w1[s] = g[lane + 64];
+                meta.pf_blk[s] = nb1;
+            }
+        }
         wave_sync();
         ++s_docs_blocks;
         s_bytes += 4 + consumed; // endpoint + docs part
@@ -296,6 +334,7 @@ struct CtxT {
         setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
         setm(s, M_BMAX, 0);
         setm(s, M_FDEC, 0);
+        if constexpr (META::PREFETCH) meta.pf_blk[s] = 0xFFFFFFFFu;
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
     }
