@@ -89,7 +89,17 @@ def main():
     W = WORKLOADS[wl]
     p = d.SynthParams(seed=W["seed"], num_docs=W["num_docs"], num_terms=W["num_terms"], zipf_exp=W["zipf_exp"],
                       top_df_frac=W["top_df_frac"], min_len=W["min_len"], clustered_every=W["clustered_every"])
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    import tempfile
+    need = 4 << 30  # rank 0 hands the index image (~3 GB at GOV2 scale) to the other ranks through a file
+    shm = tempfile.gettempdir()
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > need:
+                shm = cand
+                break
+        except OSError:
+            pass
     tag = "ds2i_bench_%s_%s_%d" % (wl, args.codec, os.getppid() if world > 1 else os.getpid())
     f_idx, f_wand = os.path.join(shm, tag + ".idx"), os.path.join(shm, tag + ".wand")
     postings = 0

@@ -101,7 +101,7 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
     }
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T>
-__global__ void __launch_bounds__(64) k_conjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
