@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                         cx.s_bytes += 4ull * ns;
                         cx.s_scored += ns;
                     }
-                    uint32_t fs = 0;
+                    unsigned long long fs = 0; // freqs are u32: the checksum must not wrap at 2^32
                     auto score_list = [&](auto ic) __attribute__((always_inline)) -> bool {
                         const uint32_t i = ic;
                         if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                             if (al0) sc0 += qw * doc_term_weight(f0, nl0);
                             if (al1) sc1 += qw * doc_term_weight(f1, nl1);
                         } else {
-                            fs += f0 + f1;
+                            fs += (unsigned long long)f0 + f1;
                         }
                         return true;
                     };

@@ -149,6 +149,55 @@ def test_query_op_concept(coll, images):
     np.testing.assert_allclose(op.topk(), exp, rtol=RTOL)
 
 
+def test_adversarial_blocks(built_lib):
+    """Decoder edge paths: 32-bit raw OptPFor blocks, blocks larger than the LDS staging window, ~50 % exceptions
+    (more than 64 Simple16 words), wide QMX classes, huge freqs, a 2^31 universe -- every codec, decode + queries."""
+    N = (1 << 31) - 1
+    rng = np.random.default_rng(99)
+    def mk(n, gaps):
+        d = np.cumsum(gaps.astype(np.int64)) - 1
+        d = d[d < N][:n]
+        return d.astype(np.uint32)
+    n = 128 * 9 + 57
+    lists = []
+    # huge gaps (b ~ 20..28) and huge freqs (b = 32 raw blocks)
+    d1 = mk(n, rng.integers(1, 1 << 20, n))
+    f1 = rng.integers(1, (1 << 31) - 2, len(d1)).astype(np.uint32)
+    f1[(len(d1) // 128) * 128:] = rng.integers(1, 1 << 20, len(d1) % 128)  # the interpolative tail codes u32 prefix sums
+    lists.append((d1, f1))
+    # alternating tiny / large values: about half of each block are exceptions with wide payloads
+    g = np.where(np.arange(n) % 2 == 0, 1, rng.integers(1 << 14, 1 << 19, n))
+    d2 = mk(n, g)
+    f2 = np.where(np.arange(len(d2)) % 2 == 0, 1, rng.integers(1 << 16, 1 << 24, len(d2))).astype(np.uint32)
+    lists.append((d2, f2))
+    # a few giant outliers in otherwise dense data
+    g = np.ones(n, dtype=np.int64); g[::37] = 1 << 24
+    d3 = mk(n, g)
+    f3 = np.ones(len(d3), np.uint32); f3[::41] = (1 << 27) - 1
+    lists.append((d3, f3))
+    # dense run sharing doc-ids with the lists above (so intersections are non-empty)
+    d4 = np.unique(np.concatenate([d1[::3], d2[::2], d3[::5], np.arange(5000, 5000 + 700, dtype=np.uint32)])).astype(np.uint32)
+    lists.append((d4, rng.integers(1, 300, len(d4)).astype(np.uint32)))
+    wand = d.build_wand(np.full(8, 10, np.uint32), [(np.array([0], np.uint32), np.array([1], np.uint32))])  # placeholder sizes
+    queries = [[0, 3], [1, 3], [2, 3], [0, 1], [0, 1, 2, 3], [3], [0], [1], [2]]
+    all_lists = lists
+    for codec in CODECS:
+        lists = all_lists
+        if codec == "block_interpolative":  # codes u32 prefix sums of every block: keep block sums below 2^32
+            lists = [(dd, (ff % (1 << 24)) + 1) for dd, ff in all_lists]
+        img = d.build_index(codec, N, lists)
+        gidx = d.Index(codec, img)
+        oidx = o.Index(codec, img)
+        for t, (docs, freqs) in enumerate(lists):
+            dd, ff = gidx[t]
+            assert np.array_equal(dd, docs), (codec, t)
+            assert np.array_equal(ff, freqs), (codec, t)
+        for op in ("and", "and_freq", "or", "or_freq"):
+            _check_against_oracle(gidx, oidx, op, queries)
+        for op in ("and", "and_freq"):
+            _check_against_oracle(gidx, oidx, op, queries, reference_order=True)
+
+
 def test_opt_index_partition_shapes(built_lib):
     """opt index on the GPU: singletons, all-ones runs, bitmap partitions, long multi-partition lists, tiny lists in a
     big universe (the shapes of test_partitioned_sequence.cpp) -- decode + next_geq-driven intersections."""
