@@ -61,6 +61,10 @@ struct BatchArgs {
     float* unit_topk;         // nunits*k
     uint32_t* unit_topk_len;
     unsigned long long* unit_freq_sum;
+    // wand / maxscore: top-k of the ranked_and pass over the same batch. Its k-th score is a valid lower bound of
+    // the final k-th score (AND results are a subset of OR results), used as a pruning floor from the first posting
+    const float* seed_topk;    // nq*k or null
+    const uint32_t* seed_len;  // nq
     Stats* stats;
 };
 

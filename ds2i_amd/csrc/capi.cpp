@@ -31,6 +31,9 @@ extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
+                                 const unsigned long long* seed_count, float* out_topk, uint32_t* out_len,
+                                 unsigned long long* out_count, hipStream_t s);
 hipError_t ds2i_launch_calib_read(const uint32_t* base, unsigned long long ndw, uint32_t* out, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s);
 }
@@ -81,6 +84,9 @@ struct ds2i_hip_index {
 };
 
 struct ds2i_hip_batch {
+    ds2i_hip_batch* seed = nullptr; // wand / maxscore: ranked_and pass over the same queries (pruning floor)
+    uint32_t* d_single = nullptr;   // ids of one-term queries answered by the seed pass
+    uint32_t nsingle = 0;
     ds2i_hip_index* idx = nullptr;
     int op = 0;
     uint32_t k = 0, nq = 0;
@@ -347,6 +353,7 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
 
 void ds2i_hip_batch_free(ds2i_hip_batch* b) {
     if (!b) return;
+    ds2i_hip_batch_free(b->seed);
     (void)hipSetDevice(b->idx->device);
     (void)hipFree(b->d_qterms);
     (void)hipFree(b->d_qoff);
@@ -453,7 +460,8 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     // that one giant query does not pin a single wavefront (SURVEY.md §7 "Load imbalance")
     std::vector<std::pair<double, uint32_t>> cls[NCLS];
     b->q_unit_off.assign(nq + 1, 0);
-    std::vector<uint32_t> split_queries;
+    std::vector<uint32_t> split_queries, single_queries;
+    const bool seeded = (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE) && nq;
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
@@ -461,6 +469,12 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = class_of(nt);
         const double target = std::max(48.0, all_cost / (16.0 * resident));
+        if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
+            single_queries.push_back(q);
+            ++b->nqcls[c];
+            b->q_unit_off[q + 1] = (uint32_t)b->units.size();
+            continue;
+        }
         if (conj) {
             uint32_t parts = 1;
             if (split_ok && nt && qnb0[q] > 1) {
@@ -540,6 +554,12 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         HIP_OK(hipMalloc((void**)&b->d_matches, 4 * (size_t)(b->match_off[nq] ? b->match_off[nq] : 1)));
         HIP_OK(upload((void**)&b->d_match_off, b->match_off.data(), b->match_off.size() * 8));
     }
+    if (seeded) {
+        int rc = ds2i_hip_batch_prepare(idx, DS2I_OP_RANKED_AND, k, terms, query_offsets, nq, 0, &b->seed);
+        if (rc) return rc;
+        b->nsingle = (uint32_t)single_queries.size();
+        HIP_OK(upload((void**)&b->d_single, single_queries.data(), single_queries.size() * 4));
+    }
     *out = b.release();
     return DS2I_OK;
 }
@@ -548,6 +568,13 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_run: null batch");
     ds2i_hip_index* idx = b->idx;
     HIP_OK(hipSetDevice(idx->device));
+    double seed_ms = 0;
+    if (b->seed) { // block-synchronous ranked_and first: its k-th score seeds the pruning floor of every unit
+        ds2i_hip_stats ss;
+        int rc = ds2i_hip_batch_run(b->seed, &ss);
+        if (rc) return rc;
+        seed_ms = ss.kernel_ms;
+    }
     hipStream_t s0 = idx->stream[0];
     HIP_OK(hipMemsetAsync(idx->d_stats, 0, NCLS * sizeof(Stats), s0));
     // ev[0] start (s0); class c kernel on stream c between ev[1+2c], ev[2+2c]; ev[1+2*NCLS] end (s0).
@@ -582,6 +609,8 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.unit_topk = b->d_unit_topk;
             a.unit_topk_len = b->d_unit_topk_len;
             a.unit_freq_sum = b->d_unit_freq_sum;
+            a.seed_topk = b->seed ? b->seed->d_topk : nullptr;
+            a.seed_len = b->seed ? b->seed->d_topk_len : nullptr;
             a.stats = idx->d_stats + c;
             HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }
@@ -605,6 +634,9 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
         m.out_freq_sum = b->d_freq_sum;
         HIP_OK(ds2i_launch_merge(&m, std::min<unsigned>(b->nsplit, 4096u), s0));
     }
+    if (b->seed && b->nsingle)
+        HIP_OK(ds2i_launch_copy_seed(b->d_single, b->nsingle, b->k, b->seed->d_topk, b->seed->d_topk_len, b->seed->d_count, b->d_topk,
+                                     b->d_topk_len, b->d_count, s0));
     HIP_OK(hipEventRecord(idx->ev[1 + 2 * NCLS], s0));
     HIP_OK(hipStreamSynchronize(s0));
     float ms = 0.f;
@@ -612,7 +644,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     for (int c = 0; c < NCLS; ++c) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], idx->ev[1 + 2 * c], idx->ev[2 + 2 * c]));
     HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     if (stats) {
-        stats->kernel_ms = ms;
+        stats->kernel_ms = ms + seed_ms;
         stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;
         stats->algorithmic_bytes = stats->postings_scored = stats->rounds = 0;
         for (int c = 0; c < NCLS; ++c) {

@@ -463,9 +463,10 @@ struct TopK {
     float v;      // per lane
     uint32_t n;   // uniform
     uint32_t k;
-    DS2I_DEV void init(uint32_t k_) { v = -__builtin_inff(); n = 0; k = k_; }
+    float floor;  // scores below it can never be in the final top-k (seeded lower bound); -inf = none
+    DS2I_DEV void init(uint32_t k_) { v = -__builtin_inff(); n = 0; k = k_; floor = -__builtin_inff(); }
     DS2I_DEV float threshold() const { return __uint_as_float(bcast(__float_as_uint(v), k - 1)); }
-    DS2I_DEV bool would_enter(float s) const { return n < k || s > threshold(); }
+    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > threshold()); }
     DS2I_DEV bool insert(float s) { // s wave-uniform
         if (!would_enter(s)) return false;
         const uint32_t lane = lane_id();

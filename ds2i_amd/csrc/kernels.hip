@@ -394,7 +394,16 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
         } else {
             for (uint32_t i = 0; i < nt; ++i) { cx.bind(i, a.qterms[t0 + i]); cx.next_geq(i, u.blk_begin); }
         }
-        if (OP == OP_WAND || OP == OP_MAXSCORE) cx.s_bytes += 4ull * nt; // max_term_weight[term]
+        if (OP == OP_WAND || OP == OP_MAXSCORE) {
+            cx.s_bytes += 4ull * nt; // max_term_weight[term]
+            if (a.seed_topk && a.seed_len[q] >= a.k) {
+                // the ranked_and pass found >= k documents: its k-th score bounds the final k-th score from below.
+                // The two operators sum a document's terms in different orders (size- vs docid-sorted lists), so the
+                // floor is relaxed by 1e-5 relative -- far above float32 re-association noise, far below any pruning loss
+                const float kth = a.seed_topk[(size_t)q * a.k + a.k - 1];
+                tk.floor = __uint_as_float(uniform(__float_as_uint(kth * (1.0f - 1.0e-5f))));
+            }
+        }
         auto norm_len = [&](uint32_t d) {
             cx.s_bytes += 4;
             ++cx.s_scored;
@@ -505,6 +514,10 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             }
             wave_sync();
             uint32_t non_ess = 0, cur = N;
+            // with a seeded floor some lists are non-essential before the first document (the reference only updates
+            // this after a successful insert, queries.hpp:568-574 -- same rule, applied to the initial bound)
+            while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub()[non_ess])))))
+                ++non_ess;
             for (uint32_t i = 0; i < nt; ++i) { uint32_t d = cx.docid(i); cur = d < cur ? d : cur; }
             while (non_ess < nt && cur < N) {
                 float score = 0.f, nl = norm_len(cur);
@@ -582,6 +595,26 @@ __global__ void __launch_bounds__(64) k_selftest(const uint32_t* in, uint32_t* o
     const uint32_t lane = lane_id();
     uint32_t x = in[blockIdx.x * 64 + lane];
     out[blockIdx.x * 64 + lane] = wave_incl_scan(x);
+}
+
+// wand / maxscore / ranked_or of a ONE-term query are exactly its ranked_and result: copy it from the seed pass
+struct CopySeedArgs {
+    const uint32_t* queries;
+    uint32_t n, k;
+    const float* seed_topk;
+    const uint32_t* seed_len;
+    const unsigned long long* seed_count;
+    float* out_topk;
+    uint32_t* out_len;
+    unsigned long long* out_count;
+};
+__global__ void __launch_bounds__(64) k_copy_seed(CopySeedArgs a) {
+    const uint32_t lane = lane_id();
+    for (uint32_t w = blockIdx.x; w < a.n; w += gridDim.x) {
+        const uint32_t q = a.queries[w];
+        if (lane < a.k) a.out_topk[(size_t)q * a.k + lane] = a.seed_topk[(size_t)q * a.k + lane];
+        if (lane == 0) { a.out_len[q] = a.seed_len[q]; a.out_count[q] = a.seed_count[q]; }
+    }
 }
 
 // FETCH_SIZE calibration (MI355X_MICROARCH.md §HBM): streams `ndw` dwords of the arena with the same
@@ -668,6 +701,14 @@ hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t 
 
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(64), 0, s, in, out);
+    return hipGetLastError();
+}
+
+hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
+                                 const unsigned long long* seed_count, float* out_topk, uint32_t* out_len,
+                                 unsigned long long* out_count, hipStream_t s) {
+    CopySeedArgs a{queries, n, k, seed_topk, seed_len, seed_count, out_topk, out_len, out_count};
+    hipLaunchKernelGGL(k_copy_seed, dim3(n < 1024 ? n : 1024), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
