@@ -468,7 +468,8 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = class_of(nt);
-        const double target = std::max(48.0, all_cost / (16.0 * resident));
+        // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
+        const double target = std::max(48.0, all_cost / (16.0 * resident) / (c == 0 ? 1.0 : 4.0));
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             single_queries.push_back(q);
             ++b->nqcls[c];
