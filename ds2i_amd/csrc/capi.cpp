@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -465,11 +466,14 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
+    // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
+    const char* uf = std::getenv("DS2I_UNIT_FACTOR");
+    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : 8.0;
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = class_of(nt);
         // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
-        const double target = std::max(48.0, all_cost / (16.0 * resident) / (c == 0 ? 1.0 : 4.0));
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : 4.0));
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             single_queries.push_back(q);
             ++b->nqcls[c];

@@ -36,17 +36,19 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
 //           constant (fully unrolled list loops), so the state stays in SGPRs/VGPRs: no LDS round trip, no
 //           v_readfirstlane, and the compiler can CSE the pointer arithmetic.
 struct MetaLds {
-    static constexpr bool PREFETCH = false;
+    static constexpr int NPF = 0; // prefetch slots
     uint32_t* p;
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return uniform(p[s * M_WORDS + f]); }
     DS2I_DEV void set(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) p[s * M_WORDS + f] = v; }
 };
 template <int TMAX>
 struct MetaReg {
-    static constexpr bool PREFETCH = TMAX <= 2; // 3-4 lists: the extra VGPRs cost more occupancy than the prefetch wins
+    // prefetch slots: both lists of the <=2-list kernel; none with 3-4 lists, where the extra VGPRs cost more
+    // occupancy than the prefetch wins (measured)
+    static constexpr int NPF = TMAX <= 2 ? TMAX : 0;
     // software prefetch of each list's NEXT sequential block (issued right after a block is decoded, consumed by the
     // next decode of that list if it is indeed block+1): table words + 512 B of block bytes, per lane
-    uint32_t pf_blk[TMAX], pf_tab[TMAX], pf_w0[TMAX], pf_w1[TMAX];
+    uint32_t pf_blk[NPF], pf_tab[NPF], pf_w0[NPF], pf_w1[NPF];
     uint32_t v[TMAX * M_WORDS];
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return v[s * M_WORDS + f]; }
     DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = x; }
@@ -173,8 +175,8 @@ struct CtxT {
         uint32_t ep, bmax, base, next_ep;
         const uint8_t* p;
         bool have = false;
-        if constexpr (META::PREFETCH) {
-            if (cur != 0xFFFFFFFFu && meta.pf_blk[s] == b) { // the bytes are already in registers
+        if constexpr (META::NPF > 0) {
+            if (s < (uint32_t)META::NPF && cur != 0xFFFFFFFFu && meta.pf_blk[s < (uint32_t)META::NPF ? s : 0] == b) { // the bytes are already in registers
                 have = true;
                 ep = m(s, M_NEXTEP);
                 base = m(s, M_BMAX) + 1u;
@@ -249,7 +251,8 @@ struct CtxT {
         setm(s, M_GPOS, b * 128u);
         setm(s, M_NEXTEP, next_ep);
         setm(s, M_HINT, blk_bytes);
-        if constexpr (META::PREFETCH) {
+        if constexpr (META::NPF > 0) {
+          if (s < (uint32_t)META::NPF) {
             meta.pf_blk[s] = 0xFFFFFFFFu;
             if (b + 1 < nb) { // speculate that this list's next access is block b+1
                 const uint32_t nb1 = b + 1;
@@ -263,6 +266,7 @@ struct CtxT {
                 meta.pf_w1[s] = g[lane + 64];
                 meta.pf_blk[s] = nb1;
             }
+          }
         }
         wave_sync();
         ++s_docs_blocks;
@@ -334,7 +338,7 @@ struct CtxT {
         setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
         setm(s, M_BMAX, 0);
         setm(s, M_FDEC, 0);
-        if constexpr (META::PREFETCH) meta.pf_blk[s] = 0xFFFFFFFFu;
+        if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
     }
