@@ -5,7 +5,7 @@ include/ds2i_build.h (libds2i_hip.so, built in-tree by ds2i_amd/build.py).
 All query results come from the HIP kernels; there is no CPU fallback.
 """
 from .api import (  # noqa: F401
-    CODECS, BLOCK_CODECS, OPS, Ds2iError, Index, Batch, lib, library_path,
+    CODECS, BLOCK_CODECS, FREQ_INDEX_KINDS, OPS, Ds2iError, Index, Batch, lib, library_path,
     encode_block, encode_vbyte, encode_posting_list, build_index, build_wand,
     SynthParams, opt_list_directory, synth_list, synth_doc_sizes, synth_queries, synth_build,
     and_query, or_query, ranked_and_query, wand_query, maxscore_query, ranked_or_query,

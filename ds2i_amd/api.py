@@ -10,7 +10,9 @@ import os
 
 import numpy as np
 
-CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4, "opt": 5}
+CODECS = {"block_optpfor": 0, "block_varint": 1, "block_interpolative": 2, "block_qmx": 3, "block_mixed": 4, "opt": 5,
+          "ef": 6, "single": 7, "uniform": 8}
+FREQ_INDEX_KINDS = ["opt", "ef", "single", "uniform"]  # freq_index<...> layouts (index_types.hpp:18-32)
 BLOCK_CODECS = ["block_optpfor", "block_varint", "block_interpolative", "block_qmx", "block_mixed"]
 OPS = {"and": 0, "and_freq": 1, "or": 2, "or_freq": 3, "ranked_and": 4, "wand": 5, "maxscore": 6, "ranked_or": 7}
 REFERENCE_ORDER = 0x100
@@ -96,6 +98,7 @@ def lib():
         L.ds2i_encode_vbyte.argtypes = [C.c_uint32, C.POINTER(vp)]
         L.ds2i_encode_posting_list.argtypes = [C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]
         L.ds2i_opt_list_directory.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(vp), u64p]
+        L.ds2i_freq_list_directory.argtypes = [C.c_int, vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(vp), u64p]
         L.ds2i_synth_list_upper_bound.argtypes = [C.POINTER(SynthParams), C.c_uint32]
         L.ds2i_synth_list_upper_bound.restype = C.c_uint64
         L.ds2i_synth_list.argtypes = [C.POINTER(SynthParams), C.c_uint32, vp, vp, C.c_uint64, u64p]
@@ -185,11 +188,11 @@ def build_wand(doc_sizes, lists):
         L.ds2i_wand_free(w)
 
 
-def opt_list_directory(image, term):
-    """The chunk directory the GPU upload builds for one list of an opt image (inspection / tests)."""
+def opt_list_directory(image, term, kind="opt"):
+    """The chunk directory the GPU upload builds for one list of a freq_index image (inspection / tests)."""
     hc, hk = C.c_void_p(), C.c_void_p()
     info = (C.c_uint64 * 5)()
-    _check(lib().ds2i_opt_list_directory(image, len(image), term, C.byref(hc), C.byref(hk), info))
+    _check(lib().ds2i_freq_list_directory(_codec(kind), image, len(image), term, C.byref(hc), C.byref(hk), info))
     cmax = np.frombuffer(_take_blob(hc), dtype=np.uint32)
     chunks = np.frombuffer(_take_blob(hk), dtype=np.uint32).reshape(-1, 12)
     return cmax, chunks, [int(x) for x in info]

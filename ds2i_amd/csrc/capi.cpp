@@ -162,25 +162,27 @@ int ds2i_hip_device_count(void) {
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
     if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
-    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_OPT)
+    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_UNIFORM)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
     int ndev = ds2i_hip_device_count();
     if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
     std::unique_ptr<ds2i_hip_index, void (*)(ds2i_hip_index*)> x(new ds2i_hip_index, free_index);
     x->device = device;
     x->kind = kind;
+    const bool freq_layout = ds2i_host::is_freq_layout(kind); // opt / ef / single / uniform: freq_index images
     ds2i_host::block_index_view view;
     ds2i_host::opt_index_view oview;
     ds2i_host::wand_view wv;
     try {
-        if (kind == DS2I_OPT) oview.parse(index_image, index_bytes);
+        oview.layout = kind;
+        if (freq_layout) oview.parse(index_image, index_bytes);
         else view.parse(index_image, index_bytes);
         if (wand_image) wv.parse(wand_image, wand_bytes);
     } catch (std::exception const& e) {
         return ds2i_set_error(DS2I_EFORMAT, e.what());
     }
-    x->size = kind == DS2I_OPT ? oview.size : view.size;
-    x->num_docs = kind == DS2I_OPT ? oview.num_docs : view.num_docs;
+    x->size = freq_layout ? oview.size : view.size;
+    x->num_docs = freq_layout ? oview.num_docs : view.num_docs;
     if (wand_image) {
         if (wv.num_docs != x->num_docs || wv.num_terms < x->size)
             return ds2i_set_error(DS2I_EFORMAT, "wand data does not match the index (num_docs / terms)");
@@ -194,8 +196,8 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     x->list_n.resize(V);
     x->list_nb.resize(V);
     std::vector<uint8_t> arena;
-    if (kind == DS2I_OPT) {
-        // opt index: the two bit vectors go to HBM unchanged; every list is additionally flattened into a chunk
+    if (freq_layout) {
+        // freq_index (opt / ef / single / uniform): the two bit vectors go to HBM unchanged; every list is additionally flattened into a chunk
         // directory (cmax[] + 12-dword entries) so that the device treats <=128-posting chunks like blocks.
         x->list_aux0.resize(V);
         x->list_aux1.resize(V);
@@ -278,7 +280,7 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     x->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_OK(hipMalloc((void**)&x->d_arena, x->arena_bytes));
     HIP_OK(hipMemcpy(x->d_arena, arena.data(), x->arena_bytes, hipMemcpyHostToDevice));
-    if (kind == DS2I_OPT) {
+    if (freq_layout) {
         const uint64_t b0 = oview.docs_bits.nbytes, b1 = oview.freqs_bits.nbytes;
         HIP_OK(hipMalloc((void**)&x->d_bits0, b0 + 4096));
         HIP_OK(hipMalloc((void**)&x->d_bits1, b1 + 4096));
@@ -333,10 +335,10 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     a.term.list_off = idx->list_off[term];
     a.term.list_end = idx->list_end[term];
     a.term.n = (uint32_t)len;
-    a.term.term = idx->kind == DS2I_OPT ? idx->list_nb[term] : term;
-    a.term.aux0 = idx->kind == DS2I_OPT ? idx->list_aux0[term] : 0;
-    a.term.aux1 = idx->kind == DS2I_OPT ? idx->list_aux1[term] : 0;
-    a.codec = idx->kind;
+    a.term.term = idx->kind >= DS2I_OPT ? idx->list_nb[term] : term;
+    a.term.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[term] : 0;
+    a.term.aux1 = idx->kind >= DS2I_OPT ? idx->list_aux1[term] : 0;
+    a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
     a.num_docs = (uint32_t)idx->num_docs;
     a.out_docs = d_docs;
     a.out_freqs = d_freqs;
@@ -419,9 +421,9 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             qt.list_off = idx->list_off[p.first];
             qt.list_end = idx->list_end[p.first];
             qt.n = idx->list_n[p.first];
-            qt.term = idx->kind == DS2I_OPT ? idx->list_nb[p.first] : p.first;
-            qt.aux0 = idx->kind == DS2I_OPT ? idx->list_aux0[p.first] : 0;
-            qt.aux1 = idx->kind == DS2I_OPT ? idx->list_aux1[p.first] : 0;
+            qt.term = idx->kind >= DS2I_OPT ? idx->list_nb[p.first] : p.first;
+            qt.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[p.first] : 0;
+            qt.aux1 = idx->kind >= DS2I_OPT ? idx->list_aux1[p.first] : 0;
             qt.q_weight = 0.f;
             qt.max_weight = 0.f;
             if (ranked) {
@@ -602,7 +604,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.nslice = b->ncls[c];
             a.num_docs = (uint32_t)idx->num_docs;
             a.k = b->k;
-            a.codec = idx->kind;
+            a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
             a.ticket = idx->d_ticket + c;
             a.out_count = b->d_count;
             a.out_topk = b->d_topk;

@@ -18,7 +18,7 @@ using namespace ds2i_host;
 struct ds2i_blob { bytes_t data; };
 struct ds2i_builder {
     std::unique_ptr<block_index_builder> b;   // kinds 0..4
-    std::unique_ptr<opt_index_builder> opt;   // kind 5 (DS2I_OPT)
+    std::unique_ptr<opt_index_builder> opt;   // kinds 5..8 (DS2I_OPT / EF / SINGLE / UNIFORM)
 };
 struct ds2i_wand_builder {
     std::vector<float> norm_lens, max_w;
@@ -46,10 +46,10 @@ size_t ds2i_blob_size(const ds2i_blob* b) { return b ? b->data.size() : 0; }
 void ds2i_blob_free(ds2i_blob* b) { delete b; }
 
 int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out) {
-    if (!out || codec < 0 || codec > 5) return ds2i_set_error(-1, "ds2i_builder_create: bad argument");
+    if (!out || codec < 0 || codec > LAYOUT_UNIFORM) return ds2i_set_error(-1, "ds2i_builder_create: bad argument");
     DS2I_TRY
     auto* h = new ds2i_builder;
-    if (codec == 5) h->opt.reset(new opt_index_builder(num_docs));
+    if (is_freq_layout(codec)) h->opt.reset(new opt_index_builder(num_docs, global_parameters(), codec));
     else h->b.reset(new block_index_builder(codec, num_docs));
     *out = h;
     return 0;
@@ -130,9 +130,15 @@ int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const 
 
 int ds2i_opt_list_directory(const void* opt_image, size_t bytes, uint32_t term, ds2i_blob** cmax, ds2i_blob** chunks,
                             uint64_t info[5]) {
-    if (!opt_image || !cmax || !chunks || !info) return ds2i_set_error(-1, "ds2i_opt_list_directory: null argument");
+    return ds2i_freq_list_directory(LAYOUT_OPT, opt_image, bytes, term, cmax, chunks, info);
+}
+int ds2i_freq_list_directory(int kind, const void* opt_image, size_t bytes, uint32_t term, ds2i_blob** cmax,
+                             ds2i_blob** chunks, uint64_t info[5]) {
+    if (!opt_image || !cmax || !chunks || !info || !is_freq_layout(kind))
+        return ds2i_set_error(-1, "ds2i_freq_list_directory: bad argument");
     DS2I_TRY
     opt_index_view v;
+    v.layout = kind;
     v.parse(opt_image, bytes);
     if (term >= v.size) return ds2i_set_error(-3, "term id out of range");
     pef_list_dir dir;
@@ -193,7 +199,8 @@ int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t*
 
 int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_blob** index_image,
                      ds2i_blob** wand_image, uint64_t* total_postings) {
-    if (!pp || !index_image || codec < 0 || codec > 5) return ds2i_set_error(-1, "ds2i_synth_build: bad argument");
+    if (!pp || !index_image || codec < 0 || codec > LAYOUT_UNIFORM) return ds2i_set_error(-1, "ds2i_synth_build: bad argument");
+    const bool freq_layout = is_freq_layout(codec);
     DS2I_TRY
     const synth_params p = to_params(pp);
     if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -205,7 +212,7 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
     sizes.shrink_to_fit();
     const uint32_t V = p.num_terms;
     std::vector<bytes_t> enc(V);
-    std::vector<bitvec_builder> enc_docs(codec == 5 ? V : 0), enc_freqs(codec == 5 ? V : 0);
+    std::vector<bitvec_builder> enc_docs(freq_layout ? V : 0), enc_freqs(freq_layout ? V : 0);
     std::vector<float> max_w(V);
     std::atomic<uint32_t> next(0);
     std::atomic<uint64_t> postings(0);
@@ -218,7 +225,7 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
                 uint32_t t = next.fetch_add(1);
                 if (t >= V) break;
                 uint64_t n = synth_list(p, t, d, f);
-                if (codec == 5) opt_index_builder::encode_list(p.num_docs, global_parameters(), n, d.data(), f.data(), enc_docs[t], enc_freqs[t]);
+                if (freq_layout) opt_index_builder::encode_list(p.num_docs, global_parameters(), n, d.data(), f.data(), enc_docs[t], enc_freqs[t], codec);
                 else write_posting_list(codec, enc[t], (uint32_t)n, d.data(), f.data());
                 max_w[t] = list_max_weight(norm_lens.data(), n, d.data(), f.data());
                 postings += n;
@@ -233,8 +240,8 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
     for (auto& th : pool) th.join();
     if (!err.empty()) return ds2i_set_error(-2, err.c_str());
     auto* ib = new ds2i_blob;
-    if (codec == 5) {
-        opt_index_builder builder(p.num_docs);
+    if (freq_layout) {
+        opt_index_builder builder(p.num_docs, global_parameters(), codec);
         for (uint32_t t = 0; t < V; ++t) {
             builder.add_encoded(enc_docs[t], enc_freqs[t]);
             enc_docs[t] = bitvec_builder();

@@ -237,17 +237,88 @@ inline void partitioned_write(bitvec_builder& bvb, const uint64_t* seq, uint64_t
     bv_append(bvb, bv_sequences);
 }
 
-// ---------------------------------------------------------------- freq_index<partitioned, positive<partitioned<strict>>>
+// ---------------------------------------------------------------- uniform_partitioned_sequence (uniform_partitioned_sequence.hpp:19-111)
+// fixed partitions of 2^log_partition_size elements: no `sizes` sequence, otherwise the partitioned layout
+template <bool STRICT>
+inline void uniform_write(bitvec_builder& bvb, const uint64_t* seq, uint64_t universe, uint64_t n, global_parameters const& params) {
+    const uint64_t psize = uint64_t(1) << params.log_partition_size;
+    const uint64_t partitions = ceil_div(n, psize);
+    write_gamma_nonzero(bvb, partitions);
+    std::vector<uint64_t> cur;
+    if (partitions == 1) {
+        const uint64_t cur_base = seq[0];
+        cur.resize(n);
+        for (uint64_t i = 0; i < n; ++i) cur[i] = seq[i] - cur_base;
+        bvb.append_bits(cur_base, (unsigned)ceil_log2(universe));
+        if (n > 1) {
+            if (cur_base + cur.back() + 1 == universe) write_delta(bvb, 0);
+            else write_delta(bvb, cur.back());
+        }
+        seq_write<STRICT>(bvb, cur.data(), cur.back() + 1, n, params);
+        return;
+    }
+    bitvec_builder bv_sequences;
+    std::vector<uint64_t> endpoints, upper_bounds;
+    uint64_t cur_base = seq[0];
+    upper_bounds.push_back(cur_base);
+    for (uint64_t p = 0; p < partitions; ++p) {
+        const uint64_t lo = p * psize, hi = std::min(n, lo + psize);
+        cur.clear();
+        for (uint64_t i = lo; i < hi; ++i) cur.push_back(seq[i] - cur_base);
+        seq_write<STRICT>(bv_sequences, cur.data(), cur.back() + 1, cur.size(), params);
+        endpoints.push_back(bv_sequences.size());
+        upper_bounds.push_back(seq[hi - 1]);
+        cur_base = seq[hi - 1] + 1;
+    }
+    bitvec_builder bv_ub;
+    ef_write(bv_ub, upper_bounds.begin(), universe, partitions + 1, params);
+    const uint64_t endpoint_bits = ceil_log2(bv_sequences.size() + 1);
+    write_gamma(bvb, endpoint_bits);
+    bv_append(bvb, bv_ub);
+    for (uint64_t p = 0; p + 1 < endpoints.size(); ++p) bvb.append_bits(endpoints[p], (unsigned)endpoint_bits);
+    bv_append(bvb, bv_sequences);
+}
+
+// The four freq_index instantiations of index_types.hpp:18-32; numbered like enum ds2i_hip_index_kind.
+//   opt     : partitioned_sequence<indexed>          + positive<partitioned_sequence<strict_sequence>>
+//   ef      : compact_elias_fano                     + positive<strict_elias_fano>
+//   single  : indexed_sequence                       + positive<strict_sequence>
+//   uniform : uniform_partitioned_sequence<indexed>  + positive<uniform_partitioned_sequence<strict_sequence>>
+enum freq_layout : int { LAYOUT_OPT = 5, LAYOUT_EF = 6, LAYOUT_SINGLE = 7, LAYOUT_UNIFORM = 8 };
+inline bool is_freq_layout(int kind) { return kind >= LAYOUT_OPT && kind <= LAYOUT_UNIFORM; }
+
+template <bool STRICT>
+inline void layout_write(int layout, bitvec_builder& bvb, const uint64_t* seq, uint64_t universe, uint64_t n,
+                         global_parameters const& params) {
+    switch (layout) {
+    case LAYOUT_OPT: partitioned_write<STRICT>(bvb, seq, universe, n, params); break;
+    case LAYOUT_UNIFORM: uniform_write<STRICT>(bvb, seq, universe, n, params); break;
+    case LAYOUT_SINGLE: seq_write<STRICT>(bvb, seq, universe, n, params); break;
+    case LAYOUT_EF:
+        if (STRICT) { // strict_elias_fano.hpp:21-36: v_i - i over universe - n + 1, the index's own parameters
+            std::vector<uint64_t> shifted(n);
+            for (uint64_t i = 0; i < n; ++i) shifted[i] = seq[i] - i;
+            ef_write(bvb, shifted.begin(), universe - n + 1, n, params);
+        } else {
+            ef_write(bvb, seq, universe, n, params);
+        }
+        break;
+    default: throw std::invalid_argument("unknown freq_index layout");
+    }
+}
+
+// ---------------------------------------------------------------- freq_index<DocsSequence, positive_sequence<...>>
 class opt_index_builder {
 public:
-    opt_index_builder(uint64_t num_docs, global_parameters const& params = global_parameters())
-        : m_num_docs(num_docs), m_params(params) {
+    opt_index_builder(uint64_t num_docs, global_parameters const& params = global_parameters(), int layout = LAYOUT_OPT)
+        : m_num_docs(num_docs), m_params(params), m_layout(layout) {
         m_docs_endpoints.push_back(0);
         m_freqs_endpoints.push_back(0);
     }
     // one list -> (docs bits, freqs bits); thread-safe (no shared state), used by the parallel synth builder
     static void encode_list(uint64_t num_docs, global_parameters const& params, uint64_t n, const uint32_t* docs,
-                            const uint32_t* freqs, bitvec_builder& docs_bits, bitvec_builder& freqs_bits) {
+                            const uint32_t* freqs, bitvec_builder& docs_bits, bitvec_builder& freqs_bits,
+                            int layout = LAYOUT_OPT) {
         if (!n) throw std::invalid_argument("List must be nonempty");
         uint64_t occurrences = 0;
         std::vector<uint64_t> d(n), cum(n);
@@ -258,12 +329,12 @@ public:
         }
         write_gamma_nonzero(docs_bits, occurrences);
         if (occurrences > 1) docs_bits.append_bits(n, (unsigned)ceil_log2(occurrences + 1));
-        partitioned_write<false>(docs_bits, d.data(), num_docs, n, params);
-        partitioned_write<true>(freqs_bits, cum.data(), occurrences + 1, n, params);
+        layout_write<false>(layout, docs_bits, d.data(), num_docs, n, params);
+        layout_write<true>(layout, freqs_bits, cum.data(), occurrences + 1, n, params);
     }
     void add_posting_list(uint64_t n, const uint32_t* docs, const uint32_t* freqs) {
         bitvec_builder db, fb;
-        encode_list(m_num_docs, m_params, n, docs, freqs, db, fb);
+        encode_list(m_num_docs, m_params, n, docs, freqs, db, fb, m_layout);
         add_encoded(db, fb);
     }
     void add_encoded(bitvec_builder const& db, bitvec_builder const& fb) {
@@ -302,6 +373,7 @@ private:
     }
     uint64_t m_num_docs;
     global_parameters m_params;
+    int m_layout;
     bitvec_builder m_docs, m_freqs;
     std::vector<uint64_t> m_docs_endpoints, m_freqs_endpoints;
 };
@@ -334,6 +406,15 @@ struct seq_partition {
     uint64_t hi_offset;    // EF: higher_bits_offset ; RB: bits_offset (absolute bit positions)
     uint64_t lo_offset;    // EF: lower_bits_offset
 };
+
+template <bool STRICT>
+inline void describe_raw_ef(uint64_t offset, uint64_t universe, uint64_t n, global_parameters const& params, seq_partition& p) {
+    ef_offsets of(offset, STRICT ? universe - n + 1 : universe, n, params);
+    p.type = SEQ_EF;
+    p.lower_bits = of.lower_bits;
+    p.hi_offset = of.higher_bits_offset;
+    p.lo_offset = of.lower_bits_offset;
+}
 
 template <bool STRICT>
 inline void describe_base(bitview const& bv, uint64_t offset, uint64_t universe, uint64_t n, global_parameters const& params,
@@ -398,6 +479,71 @@ inline void walk_partitioned(bitview const& bv, uint64_t offset, uint64_t univer
     }
 }
 
+// uniform_partitioned_sequence header (uniform_partitioned_sequence.hpp:121-166)
+template <bool STRICT>
+inline void walk_uniform(bitview const& bv, uint64_t offset, uint64_t universe, uint64_t n, global_parameters const& params,
+                         std::vector<seq_partition>& out) {
+    out.clear();
+    bit_cursor it{&bv, offset};
+    const uint64_t partitions = read_gamma(it) + 1;
+    if (partitions == 1) {
+        seq_partition p;
+        p.begin = 0;
+        p.end = n;
+        p.base = it.take((unsigned)ceil_log2(universe));
+        uint64_t ub = 0;
+        if (n > 1) {
+            uint64_t ud = read_delta(it);
+            ub = ud ? ud : (universe - p.base - 1);
+        }
+        p.upper_bound = p.base + ub;
+        describe_base<STRICT>(bv, it.pos, ub + 1, n, params, p);
+        out.push_back(p);
+        return;
+    }
+    if (partitions != ceil_div(n, uint64_t(1) << params.log_partition_size))
+        throw std::runtime_error("corrupt uniform partitioned sequence");
+    const uint64_t endpoint_bits = read_gamma(it);
+    uint64_t cur = it.pos;
+    std::vector<uint64_t> ubs;
+    ef_decode_all(bv, cur, universe, partitions + 1, params, ubs);
+    cur += ef_bitsize(params, universe, partitions + 1);
+    const uint64_t endpoints_offset = cur;
+    const uint64_t sequences_offset = cur + endpoint_bits * (partitions - 1);
+    out.reserve(partitions);
+    for (uint64_t k = 0; k < partitions; ++k) {
+        seq_partition p;
+        p.begin = k << params.log_partition_size;
+        p.end = std::min(n, (k + 1) << params.log_partition_size);
+        p.base = k ? ubs[k] + 1 : ubs[0];
+        p.upper_bound = ubs[k + 1];
+        uint64_t endpoint = k ? bv.get_bits(endpoints_offset + (k - 1) * endpoint_bits, (unsigned)endpoint_bits) : 0;
+        describe_base<STRICT>(bv, sequences_offset + endpoint, p.upper_bound - p.base + 1, p.end - p.begin, params, p);
+        out.push_back(p);
+    }
+}
+
+// any of the four layouts -> list of partitions (ef / single are one partition with base 0)
+template <bool STRICT>
+inline void walk_layout(int layout, bitview const& bv, uint64_t offset, uint64_t universe, uint64_t n,
+                        global_parameters const& params, std::vector<seq_partition>& out) {
+    if (layout == LAYOUT_OPT) return walk_partitioned<STRICT>(bv, offset, universe, n, params, out);
+    if (layout == LAYOUT_UNIFORM) return walk_uniform<STRICT>(bv, offset, universe, n, params, out);
+    out.clear();
+    seq_partition p;
+    p.begin = 0;
+    p.end = n;
+    p.base = 0;
+    p.upper_bound = universe - 1;
+    if (layout == LAYOUT_EF) {
+        p.lower_bits = 0;
+        describe_raw_ef<STRICT>(offset, universe, n, params, p);
+    } else {
+        describe_base<STRICT>(bv, offset, universe, n, params, p);
+    }
+    out.push_back(p);
+}
+
 // sequential cursor over the set bits of one partition's high bits / bitmap
 struct ones_cursor {
     bitview const* bv = nullptr;
@@ -445,6 +591,7 @@ struct pef_list_dir {
 };
 
 struct opt_index_view {
+    int layout = LAYOUT_OPT;
     global_parameters params;
     uint64_t num_docs = 0, size = 0;
     bitview docs_endpoints, docs_bits, freqs_endpoints, freqs_bits;
@@ -486,8 +633,8 @@ struct opt_index_view {
         if (occurrences > 1) n = it.take((unsigned)ceil_log2(occurrences + 1));
         if (!n || n > 0xFFFFFFFFull) throw std::runtime_error("corrupt opt posting list header");
         std::vector<seq_partition> dp, fp;
-        walk_partitioned<false>(docs_bits, it.pos, num_docs, n, params, dp);
-        walk_partitioned<true>(freqs_bits, freqs_off[t], occurrences + 1, n, params, fp);
+        walk_layout<false>(layout, docs_bits, it.pos, num_docs, n, params, dp);
+        walk_layout<true>(layout, freqs_bits, freqs_off[t], occurrences + 1, n, params, fp);
         dir.n = (uint32_t)n;
         dir.docs_bit0 = docs_off[t];
         dir.freqs_bit0 = freqs_off[t];

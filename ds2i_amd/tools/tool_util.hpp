@@ -63,8 +63,10 @@ inline double get_time_usecs() {
 }
 
 inline int kind_of(std::string const& type) {
-    static const char* names[] = {"block_optpfor", "block_varint", "block_interpolative", "block_qmx", "block_mixed"};
-    for (int i = 0; i < 5; ++i)
+    // DS2I_INDEX_TYPES (index_types.hpp:41), numbered like enum ds2i_hip_index_kind
+    static const char* names[] = {"block_optpfor", "block_varint", "block_interpolative", "block_qmx", "block_mixed",
+                                  "opt", "ef", "single", "uniform"};
+    for (int i = 0; i < 9; ++i)
         if (type == names[i]) return i;
     return -1;
 }

@@ -33,7 +33,8 @@ const uint8_t* ds2i_blob_data(const ds2i_blob* b);
 size_t ds2i_blob_size(const ds2i_blob* b);
 void ds2i_blob_free(ds2i_blob* b);
 
-/* block_freq_index<Codec>::builder (block_freq_index.hpp:18-70); codec = enum ds2i_hip_index_kind */
+/* block_freq_index<Codec>::builder (block_freq_index.hpp:18-70) for kinds 0..4, freq_index<...>::builder
+ * (freq_index.hpp:19-94) for kinds 5..8; codec = enum ds2i_hip_index_kind */
 int ds2i_builder_create(int codec, uint64_t num_docs, ds2i_builder** out);
 int ds2i_builder_add_posting_list(ds2i_builder* b, uint64_t n, const uint32_t* docs, const uint32_t* freqs);
 int ds2i_builder_freeze(ds2i_builder* b, ds2i_blob** image); /* succinct::mapper::freeze image */
@@ -57,6 +58,9 @@ int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const 
  * info = {n, docs_bit0, freqs_bit0, docs bit-vector byte offset in the image, freqs bit-vector byte offset} */
 int ds2i_opt_list_directory(const void* opt_image, size_t bytes, uint32_t term, ds2i_blob** cmax, ds2i_blob** chunks,
                             uint64_t info[5]);
+/* same for any freq_index kind (DS2I_OPT / DS2I_EF / DS2I_SINGLE / DS2I_UNIFORM) */
+int ds2i_freq_list_directory(int kind, const void* image, size_t bytes, uint32_t term, ds2i_blob** cmax,
+                             ds2i_blob** chunks, uint64_t info[5]);
 
 /* synthetic collection */
 uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term);

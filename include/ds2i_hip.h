@@ -28,8 +28,12 @@ enum ds2i_hip_index_kind {
     DS2I_BLOCK_INTERPOLATIVE = 2,
     DS2I_BLOCK_QMX = 3,
     DS2I_BLOCK_MIXED = 4,
-    DS2I_OPT = 5 /* opt_index: freq_index<partitioned_sequence<>, positive_sequence<partitioned_sequence<strict_sequence>>>
-                    (index_types.hpp:29-32) */
+    DS2I_OPT = 5,     /* opt_index: freq_index<partitioned_sequence<>, positive_sequence<partitioned_sequence<strict_sequence>>>
+                         (index_types.hpp:29-32) */
+    DS2I_EF = 6,      /* ef_index: freq_index<compact_elias_fano, positive_sequence<strict_elias_fano>> (index_types.hpp:18-19) */
+    DS2I_SINGLE = 7,  /* single_index: freq_index<indexed_sequence, positive_sequence<>> (index_types.hpp:21-22) */
+    DS2I_UNIFORM = 8  /* uniform_index: freq_index<uniform_partitioned_sequence<>,
+                         positive_sequence<uniform_partitioned_sequence<strict_sequence>>> (index_types.hpp:24-27) */
 };
 
 /* query operators == the strings queries.cpp:104-117 dispatches on (+ ranked_or, queries.hpp:404) */

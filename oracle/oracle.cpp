@@ -530,15 +530,18 @@ struct block_freq_index {
         ef_enumerator e(m_endpoints, 0, m_lists_size, m_size, params[0], params[1]);
         return e.move(i).second;
     }
+    uint64_t list_offset(size_t i) const { return endpoint(i); }
     document_enumerator operator[](size_t i) const {
         if (i >= m_size) throw std::out_of_range("term id out of range");
         return document_enumerator(codec, m_lists + endpoint(i), m_num_docs, prof);
     }
 };
 
-// freq_index<partitioned_sequence<>, positive_sequence<partitioned_sequence<strict_sequence>>> (index_types.hpp:29-32)
-struct opt_freq_index {
-    typedef opt_document_enumerator document_enumerator;
+// freq_index<DocsSequence, positive_sequence<FreqsBase>> (freq_index.hpp:12-249); the four instantiations of
+// index_types.hpp:18-32 follow as typedefs
+template <class DocsEnum, class FreqsBase>
+struct freq_index_t {
+    typedef freq_document_enumerator<DocsEnum, FreqsBase> document_enumerator;
     pef_params params;
     uint64_t m_num_docs = 0;
     bit_collection docs, freqs;
@@ -566,6 +569,7 @@ struct opt_freq_index {
     }
     size_t size() const { return docs.m_size; }
     uint64_t num_docs() const { return m_num_docs; }
+    uint64_t list_offset(size_t i) const { return docs.get(params, i); }
     document_enumerator operator[](size_t i) const { // freq_index.hpp:192-214
         if (i >= size()) throw std::out_of_range("term id out of range");
         bit_enumerator it(docs.bits, docs.get(params, i));
@@ -574,8 +578,8 @@ struct opt_freq_index {
         uint64_t n = 1;
         if (occurrences > 1) n = it.take(pef_ceil_log2(occurrences + 1));
         if (prof) prof->algorithmic_bytes += (it.position() - start + 7) / 8 + 16; // list header + two collection offsets
-        partitioned_enumerator<false> de(docs.bits, it.position(), m_num_docs, n, params, prof ? &pdocs : nullptr);
-        positive_enumerator fe(freqs.bits, freqs.get(params, i), occurrences + 1, n, params, prof ? &pfreqs : nullptr);
+        DocsEnum de(docs.bits, it.position(), m_num_docs, n, params, prof ? &pdocs : nullptr);
+        positive_enumerator<FreqsBase> fe(freqs.bits, freqs.get(params, i), occurrences + 1, n, params, prof ? &pfreqs : nullptr);
         return document_enumerator(de, fe);
     }
     void begin_profile(profile* p) const { prof = p; pdocs = pef_profile(); pfreqs = pef_profile(); }
@@ -588,6 +592,10 @@ struct opt_freq_index {
         prof = nullptr;
     }
 };
+typedef freq_index_t<partitioned_enumerator<false>, partitioned_enumerator<true>> opt_freq_index;  // index_types.hpp:29-32
+typedef freq_index_t<plain_ef_enumerator, plain_sef_enumerator> ef_freq_index;                    // index_types.hpp:18-19
+typedef freq_index_t<single_enumerator<false>, single_enumerator<true>> single_freq_index;        // index_types.hpp:21-22
+typedef freq_index_t<uniform_enumerator<false>, uniform_enumerator<true>> uniform_freq_index;     // index_types.hpp:24-27
 
 struct wand_data {
     uint64_t n_docs = 0, n_terms = 0;
@@ -914,13 +922,25 @@ static double get_time_usecs() {
 }
 
 struct handle {
-    int kind = 0; // 0..4 block codecs, 5 = opt (partitioned Elias-Fano freq_index)
+    int kind = 0; // 0..4 block codecs, 5 = opt, 6 = ef, 7 = single, 8 = uniform (freq_index layouts)
     block_freq_index index;
     opt_freq_index opt;
+    ef_freq_index ef;
+    single_freq_index single;
+    uniform_freq_index uniform;
     wand_data wdata;
     bool has_wand = false;
-    bool is_opt() const { return kind == 5; }
 };
+// run f on whichever index the handle holds
+template <class F> auto visit(handle* h, F&& f) -> decltype(f(h->index)) {
+    switch (h->kind) {
+    case 5: return f(h->opt);
+    case 6: return f(h->ef);
+    case 7: return f(h->single);
+    case 8: return f(h->uniform);
+    default: return f(h->index);
+    }
+}
 
 } // namespace oracle
 
@@ -951,19 +971,20 @@ void* oracle_index_open(int kind, const void* image, uint64_t bytes, const void*
     try {
         handle* h = new handle;
         h->kind = kind;
-        if (kind == 5) h->opt.map(image, bytes);
-        else h->index.map(kind, image, bytes);
+        if (kind < 0 || kind > 8) throw std::invalid_argument("unknown index kind");
+        if (kind <= 4) h->index.map(kind, image, bytes);
+        else if (kind == 5) h->opt.map(image, bytes);
+        else if (kind == 6) h->ef.map(image, bytes);
+        else if (kind == 7) h->single.map(image, bytes);
+        else h->uniform.map(image, bytes);
         if (wand) { h->wdata.map(wand, wand_bytes); h->has_wand = true; }
         return h;
     } catch (...) { return nullptr; }
 }
 void oracle_index_close(void* h) { delete (handle*)h; }
-uint64_t oracle_index_size(void* hv) { handle* h = (handle*)hv; return h->is_opt() ? h->opt.size() : h->index.size(); }
-uint64_t oracle_index_num_docs(void* hv) { handle* h = (handle*)hv; return h->is_opt() ? h->opt.num_docs() : h->index.num_docs(); }
-uint64_t oracle_list_offset(void* hv, uint64_t term) {
-    handle* h = (handle*)hv;
-    return h->is_opt() ? h->opt.docs.get(h->opt.params, term) : h->index.endpoint(term);
-}
+uint64_t oracle_index_size(void* hv) { return visit((handle*)hv, [](auto& idx) { return (uint64_t)idx.size(); }); }
+uint64_t oracle_index_num_docs(void* hv) { return visit((handle*)hv, [](auto& idx) { return (uint64_t)idx.num_docs(); }); }
+uint64_t oracle_list_offset(void* hv, uint64_t term) { return visit((handle*)hv, [&](auto& idx) { return (uint64_t)idx.list_offset(term); }); }
 
 extern "C++" {
 namespace {
@@ -1070,33 +1091,28 @@ int perftest_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* 
 } // namespace
 } // extern "C++"
 
-#define DISPATCH(h, expr_block, expr_opt) ((h)->is_opt() ? (expr_opt) : (expr_block))
 
 int64_t oracle_list_size(void* hv, uint64_t term) {
     handle* h = (handle*)hv;
-    try { return DISPATCH(h, list_size_t(h->index, term), list_size_t(h->opt, term)); } catch (...) { return -1; }
+    try { return visit(h, [&](auto& idx) { return list_size_t(idx, term); }); } catch (...) { return -1; }
 }
 // sequential enumeration with next(): docid()+freq()+position() of every posting; returns n or a negative code
 int64_t oracle_list_enumerate(void* hv, uint64_t term, uint32_t* docs, uint32_t* freqs, uint64_t cap) {
     handle* h = (handle*)hv;
-    try { return DISPATCH(h, list_enumerate_t(h->index, term, docs, freqs, cap), list_enumerate_t(h->opt, term, docs, freqs, cap)); } catch (...) { return -1; }
+    try { return visit(h, [&](auto& idx) { return list_enumerate_t(idx, term, docs, freqs, cap); }); } catch (...) { return -1; }
 }
 // reset(); then next_geq(probes[i]) in order (probes non-decreasing): records docid() and freq()-or-0
 int oracle_list_next_geq(void* hv, uint64_t term, const uint32_t* probes, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
     handle* h = (handle*)hv;
     try {
-        if (h->is_opt()) list_next_geq_t(h->opt, term, probes, np, out_docid, out_freq);
-        else list_next_geq_t(h->index, term, probes, np, out_docid, out_freq);
-        return 0;
+        return visit(h, [&](auto& idx) { list_next_geq_t(idx, term, probes, np, out_docid, out_freq); return 0; });
     } catch (...) { return -1; }
 }
 // move(positions[i]) in order (positions non-decreasing): docid() and freq()
 int oracle_list_move(void* hv, uint64_t term, const uint32_t* positions, uint64_t np, uint32_t* out_docid, uint32_t* out_freq) {
     handle* h = (handle*)hv;
     try {
-        if (h->is_opt()) list_move_t(h->opt, term, positions, np, out_docid, out_freq);
-        else list_move_t(h->index, term, positions, np, out_docid, out_freq);
-        return 0;
+        return visit(h, [&](auto& idx) { list_move_t(idx, term, positions, np, out_docid, out_freq); return 0; });
     } catch (...) { return -1; }
 }
 
@@ -1106,8 +1122,7 @@ int64_t oracle_query(void* hv, int op, uint32_t k, const uint32_t* terms, uint32
     handle* h = (handle*)hv;
     try {
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        return DISPATCH(h, query_t(h->index, h, op, k, terms, nterms, topk, topk_len, matches, match_cap, freq_sum, prof),
-                        query_t(h->opt, h, op, k, terms, nterms, topk, topk_len, matches, match_cap, freq_sum, prof));
+        return visit(h, [&](auto& idx) { return query_t(idx, h, op, k, terms, nterms, topk, topk_len, matches, match_cap, freq_sum, prof); });
     } catch (...) { return -1; }
 }
 
@@ -1117,8 +1132,7 @@ int oracle_query_batch(void* hv, int op, uint32_t k, const uint32_t* terms, cons
     handle* h = (handle*)hv;
     try {
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        return DISPATCH(h, query_batch_t(h->index, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof),
-                        query_batch_t(h->opt, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof));
+        return visit(h, [&](auto& idx) { return query_batch_t(idx, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof); });
     } catch (...) { return -1; }
 }
 
@@ -1128,7 +1142,7 @@ int oracle_perftest(void* hv, int op, uint32_t k, const uint32_t* terms, const u
     handle* h = (handle*)hv;
     try {
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
-        return DISPATCH(h, perftest_t(h->index, h, op, k, terms, offs, nq, runs, stats_out), perftest_t(h->opt, h, op, k, terms, offs, nq, runs, stats_out));
+        return visit(h, [&](auto& idx) { return perftest_t(idx, h, op, k, terms, offs, nq, runs, stats_out); });
     } catch (...) { return -1; }
 }
 

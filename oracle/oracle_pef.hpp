@@ -605,7 +605,142 @@ private:
     pef_profile* m_prof = nullptr;
 };
 
-// ---------------------------------------------------------------- positive_sequence<partitioned<strict>>
+// ---------------------------------------------------------------- uniform_partitioned_sequence
+// uniform_partitioned_sequence.hpp:113-315: partitions of exactly 2^log_partition_size elements (the last may be shorter),
+// so the partition of a position is a shift and there is no `sizes` sequence.
+template <bool STRICT>
+class uniform_enumerator {
+public:
+    typedef typename base_sequence<STRICT>::enumerator base_enum;
+    uniform_enumerator() {}
+    uniform_enumerator(const bitvec& bv, uint64_t offset, uint64_t universe, uint64_t n, pef_params const& params, pef_profile* prof)
+        : m_params(params), m_size(n), m_universe(universe), m_bv(&bv), m_prof(prof) {
+        bit_enumerator it(bv, offset);
+        m_partitions = read_gamma_nonzero(it);
+        if (m_partitions == 1) {
+            m_cur_partition = 0;
+            m_cur_begin = 0;
+            m_cur_end = n;
+            m_cur_base = it.take(pef_ceil_log2(universe));
+            uint64_t ub = 0;
+            if (n > 1) {
+                uint64_t universe_delta = read_delta(it);
+                ub = universe_delta ? universe_delta : (universe - m_cur_base - 1);
+            }
+            m_partition_enum = base_enum(*m_bv, it.position(), ub + 1, n, m_params);
+            m_cur_upper_bound = m_cur_base + ub;
+            if (m_prof) {
+                m_prof->partitions_entered += 1;
+                m_prof->algorithmic_bytes += (it.position() - offset + base_sequence<STRICT>::bitsize(m_params, ub + 1, n) + 7) / 8;
+            }
+        } else {
+            m_endpoint_bits = read_gamma(it);
+            uint64_t cur_offset = it.position();
+            m_upper_bounds = cef_enumerator(bv, cur_offset, universe, m_partitions + 1, params);
+            cur_offset += cef_bitsize(params, universe, m_partitions + 1);
+            m_endpoints_offset = cur_offset;
+            cur_offset += m_endpoint_bits * (m_partitions - 1);
+            m_sequences_offset = cur_offset;
+        }
+        m_position = size();
+        slow_move();
+    }
+    value_type move(uint64_t position) {
+        m_position = position;
+        if (m_position >= m_cur_begin && m_position < m_cur_end)
+            return value_type(m_position, m_cur_base + m_partition_enum.move(m_position - m_cur_begin).second);
+        return slow_move();
+    }
+    value_type next_geq(uint64_t lower_bound) {
+        if (lower_bound >= m_cur_base && lower_bound <= m_cur_upper_bound) {
+            auto val = m_partition_enum.next_geq(lower_bound - m_cur_base);
+            m_position = m_cur_begin + val.first;
+            return value_type(m_position, m_cur_base + val.second);
+        }
+        return slow_next_geq(lower_bound);
+    }
+    value_type next() {
+        ++m_position;
+        if (m_position < m_cur_end) return value_type(m_position, m_cur_base + m_partition_enum.next().second);
+        return slow_next();
+    }
+    uint64_t size() const { return m_size; }
+    uint64_t prev_value() const {
+        if (m_position == m_cur_begin) return m_cur_partition ? m_cur_base - 1 : 0;
+        return m_cur_base + m_partition_enum.prev_value();
+    }
+
+private:
+    value_type slow_next() {
+        if (m_position == m_size) {
+            m_partition_enum.next();
+            return value_type(m_position, m_universe);
+        }
+        switch_partition(m_cur_partition + 1);
+        return value_type(m_position, m_cur_base + m_partition_enum.move(0).second);
+    }
+    value_type slow_move() {
+        if (m_position == size()) {
+            if (m_partitions > 1) switch_partition(m_partitions - 1);
+            m_partition_enum.move(m_partition_enum.size());
+            return value_type(m_position, m_universe);
+        }
+        switch_partition(m_position >> m_params.log_partition_size);
+        return value_type(m_position, m_cur_base + m_partition_enum.move(m_position - m_cur_begin).second);
+    }
+    value_type slow_next_geq(uint64_t lower_bound) {
+        if (m_partitions == 1) return lower_bound < m_cur_base ? move(0) : move(size());
+        auto ub_it = m_upper_bounds.next_geq(lower_bound);
+        if (ub_it.first == 0) return move(0);
+        if (ub_it.first == m_upper_bounds.size()) return move(size());
+        switch_partition(ub_it.first - 1);
+        return next_geq(lower_bound);
+    }
+    void switch_partition(uint64_t partition) {
+        uint64_t endpoint = partition ? (m_bv->get_word56(m_endpoints_offset + (partition - 1) * m_endpoint_bits) & ((uint64_t(1) << m_endpoint_bits) - 1)) : 0;
+        m_cur_partition = partition;
+        m_cur_begin = partition << m_params.log_partition_size;
+        m_cur_end = std::min(size(), (partition + 1) << m_params.log_partition_size);
+        auto ub_it = m_upper_bounds.move(partition + 1);
+        m_cur_upper_bound = ub_it.second;
+        m_cur_base = m_upper_bounds.prev_value() + (partition ? 1 : 0);
+        m_partition_enum = base_enum(*m_bv, m_sequences_offset + endpoint, m_cur_upper_bound - m_cur_base + 1, m_cur_end - m_cur_begin, m_params);
+        if (m_prof) { // partition bits + endpoint + 2 x 8 B of the upper_bounds EF
+            m_prof->partitions_entered += 1;
+            m_prof->algorithmic_bytes += (base_sequence<STRICT>::bitsize(m_params, m_cur_upper_bound - m_cur_base + 1, m_cur_end - m_cur_begin) + 7) / 8 +
+                                         (m_endpoint_bits + 7) / 8 + 16;
+        }
+    }
+    pef_params m_params{};
+    uint64_t m_partitions = 0, m_endpoints_offset = 0, m_endpoint_bits = 0, m_sequences_offset = 0, m_size = 0, m_universe = 0;
+    uint64_t m_position = 0, m_cur_partition = 0, m_cur_begin = 0, m_cur_end = 0, m_cur_base = 0, m_cur_upper_bound = 0;
+    const bitvec* m_bv = nullptr;
+    cef_enumerator m_upper_bounds;
+    base_enum m_partition_enum;
+    pef_profile* m_prof = nullptr;
+};
+
+// un-partitioned sequences behind the constructor shape the partitioned ones have (profile pointer ignored:
+// A_skip is only defined for the block and partitioned layouts)
+struct plain_ef_enumerator : cef_enumerator { // compact_elias_fano as a whole-list sequence (ef_index docs)
+    plain_ef_enumerator() {}
+    plain_ef_enumerator(const bitvec& bv, uint64_t offset, uint64_t universe, uint64_t n, pef_params const& p, pef_profile*)
+        : cef_enumerator(bv, offset, universe, n, p) {}
+};
+struct plain_sef_enumerator : sef_enumerator { // strict_elias_fano with the index's own parameters (ef_index freqs)
+    plain_sef_enumerator() {}
+    plain_sef_enumerator(const bitvec& bv, uint64_t offset, uint64_t universe, uint64_t n, pef_params const& p, pef_profile*)
+        : sef_enumerator(bv, offset, universe, n, p) {}
+};
+template <bool STRICT>
+struct single_enumerator : base_sequence<STRICT>::enumerator { // indexed_sequence / strict_sequence (single_index)
+    single_enumerator() {}
+    single_enumerator(const bitvec& bv, uint64_t offset, uint64_t universe, uint64_t n, pef_params const& p, pef_profile*)
+        : base_sequence<STRICT>::enumerator(bv, offset, universe, n, p) {}
+};
+
+// ---------------------------------------------------------------- positive_sequence<Base> (positive_sequence.hpp:33-78)
+template <class Base>
 class positive_enumerator {
 public:
     positive_enumerator() {}
@@ -627,17 +762,19 @@ public:
     }
 
 private:
-    partitioned_enumerator<true> m_base;
+    Base m_base;
     uint64_t m_position = 0, m_cur = 0;
 };
 
-// ---------------------------------------------------------------- freq_index (opt)
+// ---------------------------------------------------------------- freq_index::document_enumerator (freq_index.hpp:116-173)
 struct opt_profile { pef_profile docs, freqs; uint64_t list_header_bytes = 0; };
 
-class opt_document_enumerator {
+template <class DocsEnum, class FreqsBase>
+class freq_document_enumerator {
 public:
-    opt_document_enumerator() {}
-    opt_document_enumerator(partitioned_enumerator<false> d, positive_enumerator f) : m_docs(d), m_freqs(f) { reset(); }
+    typedef positive_enumerator<FreqsBase> freqs_enum;
+    freq_document_enumerator() {}
+    freq_document_enumerator(DocsEnum d, freqs_enum f) : m_docs(d), m_freqs(f) { reset(); }
     void reset() { m_cur_pos = 0; m_cur_docid = m_docs.move(0).second; }
     void next() { auto v = m_docs.next(); m_cur_pos = v.first; m_cur_docid = v.second; }
     void next_geq(uint64_t lb) { auto v = m_docs.next_geq(lb); m_cur_pos = v.first; m_cur_docid = v.second; }
@@ -649,9 +786,10 @@ public:
 
 private:
     uint64_t m_cur_pos = 0, m_cur_docid = 0;
-    partitioned_enumerator<false> m_docs;
-    positive_enumerator m_freqs;
+    DocsEnum m_docs;
+    freqs_enum m_freqs;
 };
+typedef freq_document_enumerator<partitioned_enumerator<false>, partitioned_enumerator<true>> opt_document_enumerator;
 
 struct bit_collection {
     uint64_t m_size = 0;

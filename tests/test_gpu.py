@@ -198,8 +198,9 @@ def test_adversarial_blocks(built_lib):
             _check_against_oracle(gidx, oidx, op, queries, reference_order=True)
 
 
-def test_opt_index_partition_shapes(built_lib):
-    """opt index on the GPU: singletons, all-ones runs, bitmap partitions, long multi-partition lists, tiny lists in a
+@pytest.mark.parametrize("kind", list(d.FREQ_INDEX_KINDS))
+def test_opt_index_partition_shapes(built_lib, kind):
+    """opt / ef / single / uniform index on the GPU: singletons, all-ones runs, bitmap partitions, long multi-partition lists, tiny lists in a
     big universe (the shapes of test_partitioned_sequence.cpp) -- decode + next_geq-driven intersections."""
     N = 1 << 22
     rng = np.random.default_rng(13)
@@ -211,10 +212,10 @@ def test_opt_index_partition_shapes(built_lib):
              (np.sort(rng.choice(N, 30000, replace=False)).astype(np.uint32), rng.integers(1, 300, 30000).astype(np.uint32)),
              (np.concatenate([np.arange(100, 2100), np.sort(rng.choice(N - 10000, 3000, replace=False)) + 10000]).astype(np.uint32),
               rng.integers(1, 4, 5000).astype(np.uint32))]
-    img = d.build_index("opt", N, lists)
+    img = d.build_index(kind, N, lists)
     wand = d.build_wand(np.full(N, 100, np.uint32), lists)
-    gidx = d.Index("opt", img, wand)
-    oidx = o.Index("opt", img, wand)
+    gidx = d.Index(kind, img, wand)
+    oidx = o.Index(kind, img, wand)
     for t, (docs, freqs) in enumerate(lists):
         dd, ff = gidx[t]
         assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
@@ -223,14 +224,16 @@ def test_opt_index_partition_shapes(built_lib):
         _check_against_oracle(gidx, oidx, op, queries)
 
 
-def test_full_size_c2_opt_index(built_lib):
-    """BASELINE configs[2] shape at configs[1] scale: opt (PEF) index, ranked_and, 4096-query batch, every query vs oracle."""
+@pytest.mark.parametrize("kind", list(d.FREQ_INDEX_KINDS))
+def test_full_size_c2_opt_index(built_lib, kind):
+    """BASELINE configs[2] shape at configs[1] scale: opt (PEF) index -- and its ef / single / uniform siblings --
+    ranked_and, 4096-query batch, every query vs oracle."""
     p = d.SynthParams(seed=0xD5210002, num_docs=1000000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128,
                       clustered_every=4)
-    img, wand, postings = d.synth_build(p, "opt")
-    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
-    gidx = d.Index("opt", img, wand)
-    oidx = o.Index("opt", img, wand)
+    img, wand, postings = d.synth_build(p, kind)
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096 if kind == "opt" else 1024)
+    gidx = d.Index(kind, img, wand)
+    oidx = o.Index(kind, img, wand)
     for op in ("and", "ranked_and"):
         count, topk, tlen, _ = gidx.query_batch(op, queries)
         oc, otopk, otlen, _, _ = oidx.query_batch(op, queries)

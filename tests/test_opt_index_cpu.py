@@ -1,4 +1,5 @@
-"""The partitioned Elias-Fano ("opt") index on the CPU: product writer (host_pef.hpp) x oracle enumerators.
+"""The Elias-Fano freq_index family on the CPU -- "opt" (partitioned, the C3 configuration), "ef", "single" and
+"uniform" (index_types.hpp:18-32): product writer (host_pef.hpp) x oracle enumerators.
 
 Mirrors reference test/test_freq_index.cpp (build -> freeze -> map -> enumerate), test_generic_sequence.hpp:28-164
 (move/next and the next_geq spec the reference never runs -- SURVEY.md §4 caveat: successor for every gap
@@ -20,9 +21,17 @@ def coll(built_lib):
     return Collection(small_params(num_docs=20000, num_terms=200))
 
 
+KINDS = list(d.FREQ_INDEX_KINDS)
+
+
+@pytest.fixture(scope="module", params=KINDS)
+def kind(request):
+    return request.param
+
+
 @pytest.fixture(scope="module")
-def idx(coll):
-    return o.Index("opt", coll.index_image("opt"), coll.wand_image())
+def idx(coll, kind):
+    return o.Index(kind, coll.index_image(kind), coll.wand_image())
 
 
 def test_freeze_map_enumerate(coll, idx):
@@ -60,7 +69,8 @@ def test_move_random_access(coll, idx):
         assert np.array_equal(dd, docs[ps]) and np.array_equal(ff, freqs[ps])
 
 
-def test_shapes_partitions(built_lib):
+@pytest.mark.parametrize("kind", KINDS)
+def test_shapes_partitions(built_lib, kind):
     """singletons, tiny lists in a huge universe, dense runs (all-ones / bitmap partitions), long multi-partition lists"""
     N = 1 << 22
     rng = np.random.default_rng(13)
@@ -72,8 +82,8 @@ def test_shapes_partitions(built_lib):
              (np.sort(rng.choice(N, 30000, replace=False)).astype(np.uint32), rng.integers(1, 300, 30000).astype(np.uint32)),
              (np.concatenate([np.arange(100, 2100), np.sort(rng.choice(N - 10000, 3000, replace=False)) + 10000]).astype(np.uint32),
               rng.integers(1, 4, 5000).astype(np.uint32))]
-    img = d.build_index("opt", N, lists)
-    idx = o.Index("opt", img)
+    img = d.build_index(kind, N, lists)
+    idx = o.Index(kind, img)
     for t, (docs, freqs) in enumerate(lists):
         dd, ff = idx.enumerate(t)
         assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
@@ -81,8 +91,8 @@ def test_shapes_partitions(built_lib):
         assert list(got) == [docs[0], docs[0], docs[-1], N, N]
 
 
-def test_queries_match_brute_force(coll, idx):
-    queries = queries_for(coll, 120) + [[], [5], [5, 5], [7, 3, 7, 3]]
+def test_queries_match_brute_force(coll, idx, kind):
+    queries = queries_for(coll, 120 if kind == "opt" else 40) + [[], [5], [5, 5], [7, 3, 7, 3]]
     for q in queries:
         r = idx.query("and", q, want_matches=True)
         exp = brute_and(coll, q)
@@ -99,6 +109,16 @@ def test_queries_match_brute_force(coll, idx):
 
 def test_opt_is_smaller_than_block_indexes(coll):
     assert len(coll.index_image("opt")) < len(coll.index_image("block_optpfor"))
+    # the optimal partitioning never loses to the fixed one or to no partitioning (partitioned_sequence.hpp:36-44)
+    assert len(coll.index_image("opt")) <= len(coll.index_image("uniform"))
+    assert len(coll.index_image("opt")) <= len(coll.index_image("single"))
+
+
+def test_layouts_differ_only_in_the_sequences(coll):
+    """same header, same collection framing: the four images share params | num_docs | #lists (freq_index.hpp:234-243)"""
+    heads = {k: bytes(coll.index_image(k)[:5 + 8 + 8]) for k in KINDS}
+    assert len(set(heads.values())) == 1
+    assert len({len(coll.index_image(k)) for k in KINDS}) > 1
 
 
 def _emulate_chunk_side(bits, bit0, typ, l, base, hi, hbias, lo, count, freq):
@@ -119,13 +139,13 @@ def _emulate_chunk_side(bits, bit0, typ, l, base, hi, hbias, lo, count, freq):
     return out
 
 
-def test_upload_chunk_directory(coll):
+def test_upload_chunk_directory(coll, kind):
     """The directory built at GPU upload (host_pef.hpp::build_dir) decodes back to the raw lists with the device's
     formulas: chunks never cross a docs or freqs partition, cmax[] is each chunk's last doc-id."""
-    img = coll.index_image("opt")
+    img = coll.index_image(kind)
     for t in list(range(0, len(coll.lists), 11)) + [0, 1]:
         docs, freqs = coll.lists[t]
-        cmax, chunks, (n, dbit0, fbit0, doff, foff) = d.opt_list_directory(img, t)
+        cmax, chunks, (n, dbit0, fbit0, doff, foff) = d.opt_list_directory(img, t, kind)
         assert n == len(docs) and len(cmax) == len(chunks)
         dbits = int.from_bytes(img[doff:], "little")  # the bit vector words start at this byte; later bytes are harmless
         fbits = int.from_bytes(img[foff:], "little")
