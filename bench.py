@@ -192,6 +192,44 @@ def main():
                                                                    pt["q50"], pt["q90"], pt["q95"]),
                "host_cpus": os.cpu_count()}
         out["speedup_vs_cpu_1core"] = qps / cpu["value"]
+        # N-thread replay in the style of profile_queries.cpp:21-39: one functor copy per thread, index shared read-only,
+        # every thread runs op_perftest (1 untimed + 1 timed pass) over its own slice of the batch
+        import threading
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:  # a container may grant fewer CPUs than it shows (cgroup v2 cpu.max = "<quota> <period>" or "max <period>")
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+        except Exception:  # noqa: BLE001
+            pass
+        nthreads = max(1, min(ncores, quota or ncores, 256))
+        # bounded: ~1/16 of the single-thread sample per thread keeps this leg to tens of seconds even when the
+        # threads share memory bandwidth
+        per_thread = max(16, min(nsample // 16, len(queries)))
+        slices = [[queries[(t * per_thread + i) % len(queries)] for i in range(per_thread)] for t in range(nthreads)]
+        errs = []
+
+        def replay(sl):
+            try:
+                oidx.perftest(args.op, sl, k=10, runs=1)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        threads = [threading.Thread(target=replay, args=(sl,)) for sl in slices]
+        t0 = time.time()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        wall = time.time() - t0
+        if not errs and wall > 0:
+            mt_qps = 2.0 * nthreads * per_thread / wall
+            out["cpu_baseline_threads"] = {"value": mt_qps, "unit": "queries/s", "cores": nthreads, "kind": "port",
+                                           "sample": "%d threads x %d queries x 2 passes in %.1fs wall (all passes counted); "
+                                                     "%d logical CPUs visible, cgroup quota %s"
+                                                     % (nthreads, per_thread, wall, ncores, quota if quota else "none")}
+            out["speedup_vs_cpu_all_cores"] = qps / mt_qps
         if opath and os.path.exists(opath):
             os.remove(opath)
     if a_skip_dom is None:  # N>1 or baseline skipped: price the device's own traversal with the same pricing

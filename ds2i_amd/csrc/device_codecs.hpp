@@ -26,6 +26,11 @@ enum { CODEC_OPTPFOR = 0, CODEC_VARINT = 1, CODEC_INTERPOLATIVE = 2, CODEC_QMX =
 
 static constexpr uint32_t STAGE_DW = 128; // staging window, dwords (512 B); larger blocks fall back to global reads
 static constexpr uint32_t EXC_DW = 256;   // Simple16 exception scratch / generic out scratch
+// The exception scratch is followed by a small constant table (u16 entries) built once per workgroup by
+// s16_table_init(): [sel * 28 + k] = (low bit of field k) | (width << 8) for the 16 Simple16 layouts, then
+// [448 + sel] = number of fields of layout sel.
+static constexpr uint32_t S16_TAB_DW = 232;
+static constexpr uint32_t EXC_LDS_DW = EXC_DW + S16_TAB_DW;
 
 DS2I_DEV uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -54,6 +59,7 @@ DS2I_DEV uint32_t wave_incl_scan(uint32_t x) {
     x = dpp_add<0x118, 0xF>(x); // row_shr:8
     x = dpp_add<0x142, 0xA>(x); // row_bcast:15 -> rows 1,3
     x = dpp_add<0x143, 0xC>(x); // row_bcast:31 -> rows 2,3
+    asm volatile("" : "+v"(x)); // opaque: otherwise "scan(x) - x" is re-associated into a second, unfused DPP chain
     return x;
 }
 
@@ -245,6 +251,27 @@ DS2I_DEV uint32_t s16_value(uint32_t word, uint32_t d, uint32_t k) {
     return (word >> (28u - endbit)) & ((1u << wdt) - 1u);
 }
 
+DS2I_DEV uint16_t* s16_tab(uint32_t* exc) { return (uint16_t*)(exc + EXC_DW); }
+DS2I_DEV void s16_table_init(uint32_t* exc) {
+    uint16_t* t = s16_tab(exc);
+    for (uint32_t i = lane_id(); i < 464u; i += 64u) {
+        if (i < 448u) {
+            const uint32_t sel = i / 28u, k = i - sel * 28u;
+            const uint32_t d = S16_DESC[sel];
+            const uint32_t c0 = d & 31, w0 = (d >> 5) & 31, c1 = (d >> 10) & 31, w1 = (d >> 15) & 31, c2 = (d >> 20) & 31, w2 = d >> 25;
+            uint32_t wdt = 0, endbit = 0;
+            if (k < c0) { wdt = w0; endbit = (k + 1) * w0; }
+            else if (k < c0 + c1) { wdt = w1; endbit = c0 * w0 + (k + 1 - c0) * w1; }
+            else if (k < c0 + c1 + c2) { wdt = w2; endbit = c0 * w0 + c1 * w1 + (k + 1 - c0 - c1) * w2; }
+            t[i] = (uint16_t)((28u - endbit) | (wdt << 8)); // width 0 -> value 0 for fields a layout does not have
+        } else {
+            const uint32_t d = S16_DESC[i - 448u];
+            t[i] = (uint16_t)((d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31));
+        }
+    }
+    wave_sync();
+}
+
 // ---- OptPFor full block (128 values). Returns bytes consumed; values in v0/v1 (layout A).
 // `exc` (EXC_DW dwords) and `out` (128 dwords) are LDS scratch.
 // Fast path: the block is dword aligned and lies inside the staging window (always the case for a
@@ -265,6 +292,9 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
         return 4 * (1 + 128);
     }
     if (nexc > 128) nexc = 128; // corrupt header: stay inside the scratch arrays
+#ifdef DS2I_PROBE_NOEXC
+    nexc = 0;
+#endif
     const uint32_t total = 4 * (1 + ew + 4 * b);
     const bool fast = (((uintptr_t)p & 3) == 0) && w.covers(p, total + 4);
     const uint32_t* blk = w.st + ((uint32_t)(p - w.gbase) >> 2); // only dereferenced when fast
@@ -286,11 +316,41 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
             v1 = (uint32_t)(x1 >> (bit1 & 31)) & mask;
         }
     }
-    if (nexc) {
+    if (nexc && nexc <= 32 && ew <= 64) {
+        // Common case (<= 32 exceptions, i.e. <= 64 Simple16 fields), kept in registers: one lane per Simple16 WORD
+        // computes (count, offset); the start offsets are turned into a 64-bit mask through LDS, so the lane of field g
+        // finds its word by a masked bit count; field geometry comes from the per-workgroup table. Lanes [0, nexc)
+        // then hold the position deltas and lanes [nexc, 2 nexc) the high parts.
+        const uint16_t* tab = s16_tab(exc);
+        const uint32_t word = lane < ew ? (fast ? blk[1 + lane] : w.rd32(p + 4 + 4 * lane)) : 0u;
+        const uint32_t cnt = lane < ew ? (uint32_t)tab[448u + (word >> 28)] : 0u;
+        const uint32_t off = wave_incl_scan(cnt) - cnt; // index of my word's first field
+        out[lane] = 0;
+        if (lane < ew && off < 64u) out[off] = 1u; // words hold >= 1 field: starts are distinct
+        wave_sync();
+        const bool starts_here = out[lane] != 0u;
+        const uint64_t starts = ballot(starts_here);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+        const uint32_t widx = below - (starts_here ? 0u : 1u); // word 0 starts at field 0, so widx >= 0
+        const uint32_t wword = (uint32_t)__shfl((int)word, (int)(widx & 63u));
+        const uint32_t woff = (uint32_t)__shfl((int)off, (int)(widx & 63u));
+        const uint32_t k = lane - woff;
+        const uint32_t fe = tab[(lane < 2 * nexc && k < 28u) ? (wword >> 28) * 28u + k : 0u];
+        const uint32_t val = __builtin_amdgcn_ubfe(wword, fe & 0xFFu, fe >> 8);
+        const uint32_t hi = (uint32_t)__shfl((int)val, (int)((lane + nexc) & 63u));
+        const uint32_t lpos = wave_incl_scan(lane < nexc ? val + 1u : 0u) - 1u; // positions are delta coded
+        wave_sync();
+        out[lane] = 0;
+        out[lane + 64] = 0;
+        if (lane < nexc && lpos < 128u) out[lpos] = hi + 1u;
+        wave_sync();
+        v0 |= out[lane] << b;
+        v1 |= out[lane + 64] << b;
+        wave_sync();
+    } else if (nexc) {
         const uint32_t need = 2 * nexc;
         if (ew <= 64) {
-            // one lane per Simple16 WORD computes (count, offset); then one lane per VALUE finds its word with a
-            // prefix-max over start markers and extracts its field -- no per-word serial loop
+            // general form of the above for > 64 fields: batches of 64 through the exc[] scratch
             const uint32_t word = lane < ew ? (fast ? blk[1 + lane] : w.rd32(p + 4 + 4 * lane)) : 0u;
             const uint32_t d = S16_DESC[word >> 28];
             const uint32_t cnt = lane < ew ? (d & 31) + ((d >> 10) & 31) + ((d >> 20) & 31) : 0u;

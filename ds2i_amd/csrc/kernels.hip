@@ -18,6 +18,9 @@
 
 using namespace ds2i_dev;
 
+#ifndef DS2I_WPE2
+#define DS2I_WPE2 8
+#endif
 namespace {
 
 template <int TMAX, bool META_IN_LDS = true>
@@ -25,7 +28,7 @@ struct Lds {
     uint32_t docs[TMAX][128];
     uint32_t freqs[TMAX][128];
     uint32_t meta[META_IN_LDS ? TMAX : 1][META_IN_LDS ? M_WORDS : 1];
-    uint32_t exc[EXC_DW];
+    uint32_t exc[EXC_LDS_DW]; // + the Simple16 field table (device_codecs.hpp)
     uint32_t st[STAGE_DW];
     uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring; row 0 unused
                             // by the conjunctive kernel and reused as ord/ub by the daat kernel)
@@ -43,6 +46,7 @@ DS2I_DEV CtxT<CODEC_T, META> make_ctx(LDS& L, const BatchArgs& a) {
     c.freqs = &L.freqs[0][0];
     bind_meta(c.meta, &L.meta[0][0]);
     c.exc = L.exc;
+    s16_table_init(L.exc);
     c.win.st = L.st;
     c.win.gbase = a.arena;
     c.win.nbytes = 0;
@@ -101,7 +105,7 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
     }
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T>
-__global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, (TMAX <= 2 ? DS2I_WPE2 : 1)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
