@@ -204,9 +204,9 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         nthreads = max(1, min(ncores, quota or ncores, 256))
-        # bounded: ~1/16 of the single-thread sample per thread keeps this leg to tens of seconds even when the
+        # bounded: a quarter of the single-thread sample per thread keeps this leg to tens of seconds even when the
         # threads share memory bandwidth
-        per_thread = max(16, min(nsample // 16, len(queries)))
+        per_thread = max(16, min(nsample // 4, len(queries)))
         slices = [[queries[(t * per_thread + i) % len(queries)] for i in range(per_thread)] for t in range(nthreads)]
         errs = []
 

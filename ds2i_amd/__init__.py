@@ -4,6 +4,11 @@ The package is a thin ctypes mirror of the C ABI in include/ds2i_hip.h and
 include/ds2i_build.h (libds2i_hip.so, built in-tree by ds2i_amd/build.py).
 All query results come from the HIP kernels; there is no CPU fallback.
 """
+import os as _os
+
+# see capi.cpp (ds2i_hip_more_hw_queues): must be in the environment before the HIP runtime initialises
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .api import (  # noqa: F401
     CODECS, BLOCK_CODECS, FREQ_INDEX_KINDS, OPS, Ds2iError, Index, Batch, lib, library_path,
     encode_block, encode_vbyte, encode_posting_list, build_index, build_wand,

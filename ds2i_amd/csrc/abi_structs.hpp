@@ -65,6 +65,10 @@ struct BatchArgs {
     // the final k-th score (AND results are a subset of OR results), used as a pruning floor from the first posting
     const float* seed_topk;    // nq*k or null
     const uint32_t* seed_len;  // nq
+    // block-synchronous wand / maxscore / ranked_or: the parts of a split query publish their k-th score here (float
+    // bits; scores are >= 0 so the bit patterns order like the values) and adopt the maximum as their floor: the final
+    // k-th score of the union is >= the k-th score of any part
+    unsigned int* q_floor;     // nq or null
     Stats* stats;
 };
 

@@ -87,6 +87,7 @@ struct ds2i_hip_index {
 struct ds2i_hip_batch {
     ds2i_hip_batch* seed = nullptr; // wand / maxscore: ranked_and pass over the same queries (pruning floor)
     uint32_t* d_single = nullptr;   // ids of one-term queries answered by the seed pass
+    unsigned int* d_qfloor = nullptr; // per-query shared pruning floor of the disjunctive kernel
     uint32_t nsingle = 0;
     ds2i_hip_index* idx = nullptr;
     int op = 0;
@@ -152,6 +153,11 @@ void free_index(ds2i_hip_index* x) {
 extern "C" {
 
 const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
+
+// The four LDS classes of a batch run on four streams; with the HIP default of 4 hardware queues two of them end up
+// sharing one (the null stream owns a queue) and serialise. Ask for more before the runtime initialises; an
+// explicit setting of the user wins.
+__attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 int ds2i_hip_device_count(void) {
     int n = 0;
@@ -359,6 +365,7 @@ void ds2i_hip_batch_free(ds2i_hip_batch* b) {
     ds2i_hip_batch_free(b->seed);
     (void)hipSetDevice(b->idx->device);
     (void)hipFree(b->d_qterms);
+    (void)hipFree(b->d_qfloor);
     (void)hipFree(b->d_qoff);
     for (auto& o : b->d_order) (void)hipFree(o);
     (void)hipFree(b->d_count);
@@ -378,8 +385,9 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     if (base_op < DS2I_OP_AND || base_op > DS2I_OP_RANKED_OR)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
     const bool conj = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
-    if ((op & DS2I_OP_REFERENCE_ORDER) && !conj)
-        return ds2i_set_error(DS2I_EINVAL, "DS2I_OP_REFERENCE_ORDER only applies to and / and_freq / ranked_and");
+    const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
+    if ((op & DS2I_OP_REFERENCE_ORDER) && !conj && !disj_topk)
+        return ds2i_set_error(DS2I_EINVAL, "DS2I_OP_REFERENCE_ORDER does not apply to or / or_freq");
     const bool ranked = base_op >= DS2I_OP_RANKED_AND;
     if (ranked && !idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
     if (ranked && (k == 0 || k > DS2I_HIP_MAX_K)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1,64]");
@@ -464,7 +472,10 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     std::vector<std::pair<double, uint32_t>> cls[NCLS];
     b->q_unit_off.assign(nq + 1, 0);
     std::vector<uint32_t> split_queries, single_queries;
-    const bool seeded = (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE) && nq;
+    // ranked_or takes the seed only in its block-synchronous form: its reference-order traversal stays the unpruned
+    // exhaustive OR of queries.hpp:404-476 (the oracle the reference tests wand / maxscore against)
+    const bool seeded = nq && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
+                               (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
@@ -507,7 +518,12 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             // top-k (its own pruning threshold), the merge is exact
             const uint32_t N = (uint32_t)idx->num_docs;
             uint32_t parts = 1;
-            if (nt && N > 1) parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / target)), std::min<double>(N, 1024.0));
+            // every part re-seeks its lists (the parts of a query share their pruning floor through q_floor), and the
+            // many-list classes pay that per list: they want coarser parts than the one/two-list class (measured on
+            // the GOV2-scale batch: best at 4x the conjunctive granularity overall)
+            static const double disj_scale[NCLS] = {16.0, 4.0, 2.0, 2.0};
+            const double dtarget = std::max(48.0, all_cost / (unit_factor * disj_scale[c] * resident));
+            if (nt && N > 1) parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));
             const uint32_t width = (N + parts - 1) / parts;
             parts = width ? (N + width - 1) / width : 1;
             if (parts > 1) split_queries.push_back(q);
@@ -561,6 +577,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         HIP_OK(hipMalloc((void**)&b->d_matches, 4 * (size_t)(b->match_off[nq] ? b->match_off[nq] : 1)));
         HIP_OK(upload((void**)&b->d_match_off, b->match_off.data(), b->match_off.size() * 8));
     }
+    if (disj_topk && !(op & DS2I_OP_REFERENCE_ORDER)) HIP_OK(hipMalloc((void**)&b->d_qfloor, 4 * (size_t)(nq ? nq : 1)));
     if (seeded) {
         int rc = ds2i_hip_batch_prepare(idx, DS2I_OP_RANKED_AND, k, terms, query_offsets, nq, 0, &b->seed);
         if (rc) return rc;
@@ -584,6 +601,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     }
     hipStream_t s0 = idx->stream[0];
     HIP_OK(hipMemsetAsync(idx->d_stats, 0, NCLS * sizeof(Stats), s0));
+    if (b->d_qfloor) HIP_OK(hipMemsetAsync(b->d_qfloor, 0, 4 * (size_t)(b->nq ? b->nq : 1), s0));
     // ev[0] start (s0); class c kernel on stream c between ev[1+2c], ev[2+2c]; ev[1+2*NCLS] end (s0).
     // Heavier LDS classes are enqueued first so their few workgroups are not starved by class 0.
     HIP_OK(hipEventRecord(idx->ev[0], s0));
@@ -618,6 +636,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.unit_freq_sum = b->d_unit_freq_sum;
             a.seed_topk = b->seed ? b->seed->d_topk : nullptr;
             a.seed_len = b->seed ? b->seed->d_topk_len : nullptr;
+            a.q_floor = b->d_qfloor;
             a.stats = idx->d_stats + c;
             HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }

@@ -369,11 +369,11 @@ DS2I_DEV void sort_ord(Lds<TMAX>& L, uint32_t n, Key key) {
     wave_sync();
 }
 
-template <int OP, int TMAX>
+template <int OP, int TMAX, int CODEC_T = -1>
 __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     __shared__ Lds<TMAX> L;
     const uint32_t lane = lane_id();
-    Ctx cx = make_ctx<-1, MetaLds>(L, a);
+    CtxT<CODEC_T, MetaLds> cx = make_ctx<CODEC_T, MetaLds>(L, a);
     constexpr bool RANKED = OP >= OP_RANKED_AND;
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         // a unit of these operators is a doc-id range [blk_begin, blk_end) of the query (whole range when
@@ -566,6 +566,226 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
     cx.flush_stats(a.stats);
 }
 
+// ------------------------------------------------------------------ block-synchronous disjunctive top-k
+// wand / maxscore / ranked_or all return the top-k of the UNION of the query's lists (queries.hpp:200-319, 404-476,
+// 478-591; the reference's own ranked test holds them equal, test_ranked_queries.cpp:39-57). The document-at-a-time
+// traversals of the reference (k_daat above) advance one document per step; here a step is a WINDOW of doc-ids:
+//   * lists are ordered by max score, upper_bounds[] are the prefix sums and the first `non_ess` lists are
+//     non-essential exactly as in maxscore_query (queries.hpp:529-547): a document that occurs in them only cannot
+//     enter the heap. The threshold starts at the ranked_and seed (every AND result is an OR result).
+//   * every essential list keeps one decoded block; the window is [lo, min of their block_max], so all postings of
+//     the essential lists inside the window sit in LDS. Each posting is a candidate, owned by the first essential list
+//     that contains it (later lists mark their copy as a duplicate);
+//   * a candidate's max-score bound (lists it was found in + all non-essential lists) is tested first, the survivors
+//     are scored exactly: essential lists by position, non-essential lists probed from the highest bound down while
+//     score + upper_bound can still enter (queries.hpp:553-564), 128 candidates at a time.
+template <int TMAX>
+struct LdsOr : Lds<TMAX, true> {
+    uint32_t lord[16];   // list slots by increasing max score
+    float lub[16];       // upper_bounds (prefix sums of max scores in that order)
+    uint32_t nomore[16]; // list has no posting >= this doc-id
+    uint8_t dup[TMAX][128];
+};
+
+template <int TMAX, int CODEC_T>
+__global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
+    __shared__ LdsOr<TMAX> L;
+    const uint32_t lane = lane_id();
+    CtxT<CODEC_T, MetaLds> cx = make_ctx<CODEC_T, MetaLds>(L, a);
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
+        const uint32_t uid = a.order[tkt];
+        const Unit u = a.units[uid];
+        const uint32_t q = u.q;
+        const bool whole = u.nparts == 1;
+        const uint32_t N = whole ? a.num_docs : u.blk_end; // the unit's doc-id range is [lo, N)
+        uint32_t lo = whole ? 0u : u.blk_begin;
+        const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
+        TopK tk;
+        tk.init(a.k);
+        if (nt == 0 || nt > (uint32_t)TMAX || N == 0) {
+            if (whole) { if (lane == 0) a.out_count[q] = 0; store_topk(a.out_topk, a.out_topk_len, a.k, q, tk); }
+            else { if (lane == 0) { a.unit_count[uid] = 0; a.unit_freq_sum[uid] = 0; } store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk); }
+            continue;
+        }
+        for (uint32_t i = 0; i < nt; ++i) cx.bind(i, a.qterms[t0 + i]);
+        cx.s_bytes += 4ull * nt; // max_term_weight[term]
+        if (a.seed_topk && a.seed_len[q] >= a.k) { // see k_daat: ranked_and's k-th score, relaxed by 1e-5
+            const float kth = a.seed_topk[(size_t)q * a.k + a.k - 1];
+            tk.floor = __uint_as_float(uniform(__float_as_uint(kth * (1.0f - 1.0e-5f))));
+        }
+        if (lane == 0) {
+            for (uint32_t i = 0; i < nt; ++i) { L.lord[i] = i; L.nomore[i] = 0xFFFFFFFFu; }
+            for (uint32_t i = 1; i < nt; ++i) { // stable insertion sort by max score (queries.hpp:529-533)
+                const uint32_t v = L.lord[i];
+                const float kv = __uint_as_float(L.meta[v][M_MAXW]);
+                uint32_t j = i;
+                while (j > 0 && kv < __uint_as_float(L.meta[L.lord[j - 1]][M_MAXW])) { L.lord[j] = L.lord[j - 1]; --j; }
+                L.lord[j] = v;
+            }
+            float acc = 0.f;
+            for (uint32_t i = 0; i < nt; ++i) {
+                const float mw = __uint_as_float(L.meta[L.lord[i]][M_MAXW]);
+                acc = i ? acc + mw : mw;
+                L.lub[i] = acc;
+            }
+        }
+        wave_sync();
+        auto ubf = [&](uint32_t i) { return __uint_as_float(uniform(__float_as_uint(L.lub[i]))); };
+        auto slot_at = [&](uint32_t p) { return uniform(L.lord[p]); };
+        auto maxw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_MAXW)); };
+        auto qw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_QW)); };
+        uint32_t non_ess = 0;
+        auto update_non_ess = [&]() { while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
+        update_non_ess();
+        // positions list x on the first block whose block_max >= d; false when the list has no posting >= d
+        auto seek = [&](uint32_t x, uint32_t d, bool may_go_back) -> bool {
+            if (d >= uniform(L.nomore[x])) return false;
+            const uint32_t cur = cx.m(x, M_CUR);
+            uint32_t from;
+            if (cur == 0xFFFFFFFFu) from = 0;
+            else if (d > cx.m(x, M_BMAX)) from = cur + 1;
+            else if (may_go_back && d < uniform(L.docs[x][0])) from = 0; // a non-essential list may have been moved ahead
+            else return true;
+            uint32_t blk;
+            { PT_BEGIN(cx); blk = cx.find_block(x, from, d); PT_END(cx, PH_FIND); }
+            if (blk >= cx.m(x, M_NB)) {
+                if (lane == 0) L.nomore[x] = d;
+                wave_sync();
+                return false;
+            }
+            cx.s_bm_examined += 1;
+            cx.s_bytes += 4;
+            if (blk != cur) cx.decode_docs(x, blk);
+            return true;
+        };
+        const bool shared_floor = !whole && a.q_floor;
+        auto adopt_floor = [&]() { // another part of this query may have raised the bar
+            const float f = __uint_as_float(uniform(__hip_atomic_load(a.q_floor + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            if (f > tk.floor) { tk.floor = f; update_non_ess(); }
+        };
+        while (non_ess < nt && lo < N) {
+            ++cx.s_rounds;
+            if (shared_floor) adopt_floor();
+            if (non_ess >= nt) break;
+            // ---- window: one block of every essential list
+            uint32_t hi = N - 1, live = 0; // live: bit x = essential list x has postings in or after the window
+            for (uint32_t p = non_ess; p < nt; ++p) {
+                const uint32_t x = slot_at(p);
+                if (!seek(x, lo, false)) continue;
+                live |= 1u << x;
+                const uint32_t bm = cx.m(x, M_BMAX);
+                hi = bm < hi ? bm : hi;
+                if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
+            }
+            if (!live) break;
+            wave_sync();
+            for (uint32_t p = non_ess; p < nt; ++p) { // ---- owner list e: its postings in [lo, hi] not owned earlier
+                if (p < non_ess) continue;             // became non-essential during this window
+                const uint32_t e = slot_at(p);
+                if (!((live >> e) & 1u)) continue;
+                const uint32_t c0 = L.docs[e][lane], c1 = L.docs[e][lane + 64];
+                bool v0 = c0 >= lo && c0 <= hi && !L.dup[e][lane];
+                bool v1 = c1 >= lo && c1 <= hi && !L.dup[e][lane + 64];
+                if (!(ballot(v0) | ballot(v1))) continue;
+                uint32_t fm0 = 0, fm1 = 0; // lists (beyond e) each candidate occurs in
+                const float ub_ne = non_ess ? ubf(non_ess - 1) : 0.f;
+                float pb0 = maxw(e) + ub_ne, pb1 = pb0;
+                for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
+                    const uint32_t x = slot_at(p2);
+                    if (!((live >> x) & 1u)) continue;
+                    PT_BEGIN(cx);
+                    uint32_t q0, q1;
+                    const bool f0 = member_bsearch(L.docs[x], c0, v0, q0);
+                    const bool f1 = member_bsearch(L.docs[x], c1, v1, q1);
+                    const float mx = maxw(x);
+                    if (f0) { L.pos[x][lane] = (uint8_t)q0; L.dup[x][q0] = 1; fm0 |= 1u << x; pb0 += mx; }
+                    if (f1) { L.pos[x][lane + 64] = (uint8_t)q1; L.dup[x][q1] = 1; fm1 |= 1u << x; pb1 += mx; }
+                    PT_END(cx, PH_MEMBER);
+                }
+                wave_sync();
+                // max-score bound first: nothing below it is decoded, gathered or scored
+                bool s0 = v0 && tk.would_enter(pb0), s1 = v1 && tk.would_enter(pb1);
+                uint64_t b0 = ballot(s0), b1 = ballot(s1);
+                if (!(b0 | b1)) continue;
+                const uint32_t ns = (uint32_t)(__builtin_popcountll(b0) + __builtin_popcountll(b1));
+                cx.s_bytes += 4ull * ns;
+                cx.s_scored += ns;
+                const float nl0 = s0 ? a.norm_lens[c0] : 0.f, nl1 = s1 ? a.norm_lens[c1] : 0.f;
+                float sc0 = 0.f, sc1 = 0.f;
+                if (!cx.m(e, M_FDEC)) cx.decode_freqs(e);
+                {
+                    const float w = qw(e);
+                    if (s0) sc0 = w * doc_term_weight(L.freqs[e][lane], nl0);
+                    if (s1) sc1 = w * doc_term_weight(L.freqs[e][lane + 64], nl1);
+                }
+                for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
+                    const uint32_t x = slot_at(p2);
+                    const bool h0 = s0 && ((fm0 >> x) & 1u), h1 = s1 && ((fm1 >> x) & 1u);
+                    if (!(ballot(h0) | ballot(h1))) continue;
+                    if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
+                    const float w = qw(x);
+                    if (h0) sc0 += w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0);
+                    if (h1) sc1 += w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1);
+                }
+                // non-essential lists, highest upper bound first; a candidate stops as soon as it cannot enter
+                for (uint32_t p2 = non_ess; p2-- > 0;) {
+                    const float ubp = ubf(p2);
+                    s0 = s0 && tk.would_enter(sc0 + ubp);
+                    s1 = s1 && tk.would_enter(sc1 + ubp);
+                    bool r0 = s0, r1 = s1; // still to be looked up in list x
+                    if (!(ballot(r0) | ballot(r1))) break;
+                    const uint32_t x = slot_at(p2);
+                    for (;;) {
+                        const uint64_t rb0 = ballot(r0), rb1 = ballot(r1);
+                        if (!(rb0 | rb1)) break;
+                        const uint32_t amin = rb0 ? bcast(c0, (uint32_t)__builtin_ctzll(rb0)) : bcast(c1, (uint32_t)__builtin_ctzll(rb1));
+                        if (!seek(x, amin, true)) break; // nothing >= amin in list x
+                        const uint32_t bm = cx.m(x, M_BMAX);
+                        const bool w0 = r0 && c0 <= bm, w1 = r1 && c1 <= bm;
+                        uint32_t q0, q1;
+                        const bool f0 = member_bsearch(L.docs[x], c0, w0, q0);
+                        const bool f1 = member_bsearch(L.docs[x], c1, w1, q1);
+                        if (ballot(f0) | ballot(f1)) {
+                            if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
+                            const float w = qw(x);
+                            if (f0) sc0 += w * doc_term_weight(L.freqs[x][q0], nl0);
+                            if (f1) sc1 += w * doc_term_weight(L.freqs[x][q1], nl1);
+                        }
+                        r0 = r0 && !w0;
+                        r1 = r1 && !w1;
+                    }
+                }
+                bool inserted = false;
+                for (int half = 0; half < 2; ++half) {
+                    const bool al = half ? s1 : s0;
+                    const float sc = half ? sc1 : sc0;
+                    uint64_t todo = ballot(al && tk.would_enter(sc));
+                    while (todo) {
+                        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        inserted |= tk.insert(__uint_as_float(bcast(__float_as_uint(sc), src)));
+                    }
+                }
+                if (inserted) {
+                    update_non_ess(); // queries.hpp:568-574
+                    if (shared_floor && tk.n >= tk.k && lane == 0)
+                        __hip_atomic_fetch_max(a.q_floor + q, __float_as_uint(tk.threshold()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (hi == 0xFFFFFFFFu) break;
+            lo = hi + 1;
+        }
+        if (whole) {
+            if (lane == 0) { a.out_count[q] = tk.n; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
+            store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+        } else {
+            if (lane == 0) { a.unit_count[uid] = tk.n; a.unit_freq_sum[uid] = 0; }
+            store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
+        }
+    }
+    cx.flush_stats(a.stats);
+}
+
 // ------------------------------------------------------------------ list decode
 // One wave per 128-posting block of ONE list; writes absolute doc-ids and freqs.
 __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
@@ -662,11 +882,22 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);
         break;
+    // the ranked disjunctive operators get the same two codec specialisations (BASELINE configs[3] runs them on
+    // block_optpfor); or / or_freq and the reference-order conjunctions stay on the runtime-dispatch instantiation
     case OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
     case OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
-    case OP_WAND: hipLaunchKernelGGL((k_daat<OP_WAND, TMAX>), g, b, 0, s, a); break;
-    case OP_MAXSCORE: hipLaunchKernelGGL((k_daat<OP_MAXSCORE, TMAX>), g, b, 0, s, a); break;
-    case OP_RANKED_OR: hipLaunchKernelGGL((k_daat<OP_RANKED_OR, TMAX>), g, b, 0, s, a); break;
+    // wand / maxscore / ranked_or: the block-synchronous disjunctive kernel (identical results by definition)
+    case OP_WAND:
+    case OP_MAXSCORE:
+    case OP_RANKED_OR:
+        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, 0, s, a);
+        break;
+    // reference-order (one document per step) traversals of the same operators: op | OP_REFERENCE_ORDER
+    case 0x100 | OP_WAND: hipLaunchKernelGGL((k_daat<OP_WAND, TMAX>), g, b, 0, s, a); break;
+    case 0x100 | OP_MAXSCORE: hipLaunchKernelGGL((k_daat<OP_MAXSCORE, TMAX>), g, b, 0, s, a); break;
+    case 0x100 | OP_RANKED_OR: hipLaunchKernelGGL((k_daat<OP_RANKED_OR, TMAX>), g, b, 0, s, a); break;
     // reference-order (one candidate per step) conjunctive traversal: op | OP_REFERENCE_ORDER
     case 0x100 | OP_AND: hipLaunchKernelGGL((k_daat<OP_AND, TMAX>), g, b, 0, s, a); break;
     case 0x100 | OP_AND_FREQ: hipLaunchKernelGGL((k_daat<OP_AND_FREQ, TMAX>), g, b, 0, s, a); break;

@@ -80,6 +80,18 @@ def test_query_ops_match_oracle(coll, queries, images, codec, op):
     _check_against_oracle(gidx, oidx, op, queries)
 
 
+@pytest.mark.parametrize("codec", ["block_optpfor", "block_mixed", "opt"])
+@pytest.mark.parametrize("op", ["wand", "maxscore", "ranked_or"])
+def test_reference_order_disjunctive_traversals(coll, queries, images, codec, op):
+    """wand / maxscore / ranked_or also exist as the reference's one-document-per-step traversals (k_daat,
+    DS2I_OP_REFERENCE_ORDER); the default is the block-synchronous kernel. Both must equal the oracle."""
+    gidx = d.Index(codec, images[0][codec], images[1])
+    oidx = o.Index(codec, images[0][codec], images[1])
+    _check_against_oracle(gidx, oidx, op, queries, reference_order=True)
+    for k in (1, 3, 64):
+        _check_against_oracle(gidx, oidx, op, queries[:40], k=k)
+
+
 @pytest.mark.parametrize("op", ["and", "and_freq", "ranked_and"])
 def test_reference_order_kernel_and_algorithmic_bytes(coll, queries, images, op):
     """The one-candidate-per-step GPU traversal decodes exactly the blocks the reference decodes."""
