@@ -30,6 +30,10 @@ WORKLOADS = {
     # BASELINE.json metric ("GOV2-scale"): 25M docs, ~1.0 B postings (SURVEY.md §8(d) C3/C4 shape)
     "gov2": dict(num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
                  seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config)"),
+    # BASELINE.json configs[4] ("ClueWeb09-B-scale"): 50M docs, ~3.5 B postings; meant for --codec block_mixed and
+    # --gpus 8 (every rank holds a replica and answers its own batch, so one rank alone runs the per-GPU work)
+    "cw09": dict(num_docs=50_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
+                 seed=0xD5210005, label="synthetic ClueWeb09-B-scale 50M-doc Zipf (configs[4])"),
 }
 NCLS = 4  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -44,7 +48,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2"])
+    ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2", "cw09"])
     ap.add_argument("--op", default="ranked_and")
     ap.add_argument("--codec", default="block_optpfor")
     ap.add_argument("--batch", type=int, default=4096)

@@ -79,6 +79,22 @@ DS2I_DEV uint32_t wave_incl_max_scan(uint32_t x) {
     return x;
 }
 
+template <int CTRL, int ROW_MASK>
+DS2I_DEV uint32_t dpp_min(uint32_t x) {
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return x < t ? x : t;
+}
+// wave64 inclusive prefix minimum (unsigned)
+DS2I_DEV uint32_t wave_incl_min_scan(uint32_t x) {
+    x = dpp_min<0x111, 0xF>(x);
+    x = dpp_min<0x112, 0xF>(x);
+    x = dpp_min<0x114, 0xF>(x);
+    x = dpp_min<0x118, 0xF>(x);
+    x = dpp_min<0x142, 0xA>(x);
+    x = dpp_min<0x143, 0xC>(x);
+    return x;
+}
+
 // ---- unaligned global loads (lists are byte-aligned on disk; gfx950 under HSA runs
 // in unaligned-access mode, the compiler emits one global_load_dword per memcpy)
 DS2I_DEV uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -192,23 +208,32 @@ struct BitReader {
 DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p, uint32_t sum, uint32_t n,
                                               uint32_t* out, uint32_t* stk) {
     uint32_t consumed = 0;
-    if (lane_id() == 0) {
+    const uint32_t lane = lane_id();
+    // A subtree whose bounds coincide (low == high) costs the stream no bits and all its prefix sums equal the bound
+    // (read_int(1) reads nothing, interpolative_coding.hpp:109-122): lane 0 skips it in O(1) and leaves its slots
+    // "undefined"; afterwards every undefined slot takes the next defined value to its right (prefix sums are
+    // non-decreasing, so that is a suffix minimum). Dense runs -- the blocks this codec is chosen for -- collapse to
+    // a handful of serial steps.
+    out[lane] = 0xFFFFFFFFu;
+    out[lane + 64] = 0xFFFFFFFFu;
+    wave_sync();
+    if (lane == 0) {
         if (sum == 0xFFFFFFFFu) {
             consumed = vbyte_decode(w, p, sum);
             p += consumed;
         }
         out[n - 1] = sum;
-        if (n > 1) {
+        if (n > 1 && sum != 0) {
             BitReader br{&w, p, 0, 0, 0};
             int sp = 0;
             uint32_t o = 0, c = n - 1, low = 0, high = sum;
             for (;;) {
-                while (c > 0) {
+                while (c > 0 && high != low) {
                     uint32_t h = c >> 1;
                     uint32_t val = low + br.read_int(high - low + 1);
                     out[o + h] = val;
                     uint32_t rc = c - h - 1;
-                    if (rc) {
+                    if (rc && high != val) {
                         stk[3 * sp] = ((o + h + 1) << 8) | rc;
                         stk[3 * sp + 1] = val;
                         stk[3 * sp + 2] = high;
@@ -228,6 +253,16 @@ DS2I_DEV uint32_t interpolative_decode_prefix(const Window& w, const uint8_t* p,
             consumed += (br.pos + 7) >> 3;
         }
     }
+    wave_sync();
+    // suffix minimum over out[0..127]: lane L scans element 127-L (upper half) and 63-L (lower half)
+    uint32_t a = out[127u - lane], b = out[63u - lane];
+    a = wave_incl_min_scan(a);
+    b = wave_incl_min_scan(b);
+    const uint32_t upper_min = bcast(a, 63);
+    b = b < upper_min ? b : upper_min;
+    wave_sync();
+    out[127u - lane] = a;
+    out[63u - lane] = b;
     wave_sync();
     return bcast(consumed, 0);
 }

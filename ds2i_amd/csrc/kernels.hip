@@ -865,21 +865,25 @@ template <int TMAX>
 static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
     dim3 g(grid), b(64);
     switch (op) {
-    // the conjunctive kernels are specialised for block_optpfor (the benchmark codec); every other
-    // codec goes through the runtime-dispatch instantiation (CODEC_T = -1)
+    // the conjunctive kernels are specialised for block_optpfor (the benchmark codec), the freq_index family and
+    // block_mixed (configs[4]; its three block types stay a run-time switch, QMX drops out); block_varint /
+    // block_interpolative / block_qmx go through the runtime-dispatch instantiation (CODEC_T = -1)
     case OP_AND:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF>), g, b, 0, s, a);
+        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_AND_FREQ:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
+        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_RANKED_AND:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
+        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);
         break;
     // the ranked disjunctive operators get the same two codec specialisations (BASELINE configs[3] runs them on
@@ -892,6 +896,7 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
     case OP_RANKED_OR:
         if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, 0, s, a);
+        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, 0, s, a);
         break;
     // reference-order (one document per step) traversals of the same operators: op | OP_REFERENCE_ORDER
