@@ -120,6 +120,9 @@ def main():
     batch = d.Batch(idx, args.op, queries, k=10)
 
     # ---------------------------------------------------------------- timed region
+    # The timed steps run the uninstrumented kernels (statistics are a compile-time option, like the reference's
+    # block_profiler); one extra untimed, instrumented step afterwards collects the block / byte counters.
+    batch.set_instrumented(False)
     for _ in range(args.warmup):
         batch.run()
     barrier()
@@ -133,6 +136,10 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sh.max_over_ranks(dist, elapsed)
     count, topk, tlen, _ = batch.fetch()
+    batch.set_instrumented(True)
+    batch.run()
+    count_i, topk_i, tlen_i, _ = batch.fetch()
+    assert np.array_equal(count, count_i) and np.array_equal(tlen, tlen_i), "instrumented / uninstrumented kernels disagree"
 
     if rank != 0:
         if dist is not None:

@@ -75,6 +75,7 @@ def lib():
         L.ds2i_hip_batch_fetch_matches.argtypes = [vp, vp, vp]
         L.ds2i_hip_batch_free.argtypes = [vp]
         L.ds2i_hip_batch_free.restype = None
+        L.ds2i_hip_batch_set_instrumented.argtypes = [vp, C.c_int]
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
         # build side
@@ -256,6 +257,10 @@ class Batch:
         _check(lib().ds2i_hip_batch_prepare(index._h, self.op, k, _ptr(terms), _ptr(offs), self.nq,
                                             1 if want_matches else 0, C.byref(self._h)))
         self.k = k if (self.op & 0xFF) in _RANKED else max(k, 1)
+
+    def set_instrumented(self, on):
+        """Statistics counters on (default) / off -- see ds2i_hip_batch_set_instrumented."""
+        _check(lib().ds2i_hip_batch_set_instrumented(self._h, 1 if on else 0))
 
     def run(self):
         st = Stats()

@@ -88,6 +88,7 @@ struct ds2i_hip_batch {
     ds2i_hip_batch* seed = nullptr; // wand / maxscore: ranked_and pass over the same queries (pruning floor)
     uint32_t* d_single = nullptr;   // ids of one-term queries answered by the seed pass
     unsigned int* d_qfloor = nullptr; // per-query shared pruning floor of the disjunctive kernel
+    bool instrument = true;           // collect ds2i_hip_stats counters (instrumented kernel instantiations)
     uint32_t nsingle = 0;
     ds2i_hip_index* idx = nullptr;
     int op = 0;
@@ -594,6 +595,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     HIP_OK(hipSetDevice(idx->device));
     double seed_ms = 0;
     if (b->seed) { // block-synchronous ranked_and first: its k-th score seeds the pruning floor of every unit
+        b->seed->instrument = b->instrument;
         ds2i_hip_stats ss;
         int rc = ds2i_hip_batch_run(b->seed, &ss);
         if (rc) return rc;
@@ -637,7 +639,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.seed_topk = b->seed ? b->seed->d_topk : nullptr;
             a.seed_len = b->seed ? b->seed->d_topk_len : nullptr;
             a.q_floor = b->d_qfloor;
-            a.stats = idx->d_stats + c;
+            a.stats = b->instrument ? idx->d_stats + c : nullptr;
             HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }
         HIP_OK(hipEventRecord(idx->ev[2 + 2 * c], s));
@@ -668,7 +670,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1 + 2 * NCLS]));
     for (int c = 0; c < NCLS; ++c) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], idx->ev[1 + 2 * c], idx->ev[2 + 2 * c]));
-    HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
+    if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, idx->d_stats, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     if (stats) {
         stats->kernel_ms = ms + seed_ms;
         stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;
@@ -682,6 +684,12 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             stats->rounds += b->cls_stats[c].rounds;
         }
     }
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_set_instrumented(ds2i_hip_batch* b, int on) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_set_instrumented: null batch");
+    b->instrument = on != 0;
     return DS2I_OK;
 }
 

@@ -11,6 +11,8 @@
 //   decode_docs()   292-319
 // Exhaustion sentinel: docid == num_docs (115,130).
 #pragma once
+#include <type_traits>
+
 #include "abi_structs.hpp"
 #include "device_codecs.hpp"
 #include "device_pef.hpp"
@@ -54,7 +56,15 @@ struct MetaReg {
     DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = x; }
 };
 
-template <int CODEC_T, class META = MetaLds>
+// a counter that compiles to nothing (uninstrumented kernels)
+struct NullCounter {
+    DS2I_DEV NullCounter& operator+=(unsigned long long) { return *this; }
+    DS2I_DEV NullCounter& operator++() { return *this; }
+    DS2I_DEV NullCounter& operator=(unsigned long long) { return *this; }
+    DS2I_DEV operator unsigned long long() const { return 0; }
+};
+
+template <int CODEC_T, class META = MetaLds, bool STATS = true>
 struct CtxT {
     uint32_t* docs;  // [TMAX][128]
     uint32_t* freqs; // [TMAX][128]
@@ -67,9 +77,12 @@ struct CtxT {
     int codec;
     uint32_t num_docs;
     DS2I_DEV bool is_pef() const { return CODEC_T == CODEC_PEF || (CODEC_T < 0 && codec == CODEC_PEF); }
-    // per-wave statistics (wave-uniform)
-    uint32_t s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
-    unsigned long long s_bytes;
+    // per-wave statistics (wave-uniform). Like the reference's block_profiler they are a compile-time option
+    // (block_posting_list.hpp:316-318 `if (Profile)`): the counters live in SGPRs, and the <=2-list kernel at
+    // 8 waves/SIMD has 72 of them, so the uninstrumented instantiation spills less (+3 % / +15 % queries/s at
+    // GOV2-scale / configs[1]).
+    typename std::conditional<STATS, uint32_t, NullCounter>::type s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
+    typename std::conditional<STATS, unsigned long long, NullCounter>::type s_bytes;
     unsigned long long s_phase[PH_COUNT];
 
     DS2I_DEV uint32_t* D(uint32_t s) const { return docs + 128 * s; }
@@ -88,7 +101,7 @@ struct CtxT {
         for (int i = 0; i < PH_COUNT; ++i) s_phase[i] = 0;
     }
     DS2I_DEV void flush_stats(Stats* st) {
-        if (st && lane_id() == 0) {
+        if (STATS && st && lane_id() == 0) {
             atomicAdd(&st->docs_blocks, (unsigned long long)s_docs_blocks);
             atomicAdd(&st->freqs_blocks, (unsigned long long)s_freqs_blocks);
             atomicAdd(&st->block_max_examined, (unsigned long long)s_bm_examined);

@@ -39,9 +39,9 @@ struct Lds {
 DS2I_DEV void bind_meta(MetaLds& m, uint32_t* lds_meta) { m.p = lds_meta; }
 template <int T> DS2I_DEV void bind_meta(MetaReg<T>&, uint32_t*) {}
 
-template <int CODEC_T, class META, class LDS>
-DS2I_DEV CtxT<CODEC_T, META> make_ctx(LDS& L, const BatchArgs& a) {
-    CtxT<CODEC_T, META> c;
+template <int CODEC_T, class META, bool STATS = true, class LDS>
+DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
+    CtxT<CODEC_T, META, STATS> c;
     c.docs = &L.docs[0][0];
     c.freqs = &L.freqs[0][0];
     bind_meta(c.meta, &L.meta[0][0]);
@@ -104,7 +104,7 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
             if (!body(i_)) break;                                    \
     }
 
-template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T>
+template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
 __global__ void __launch_bounds__(64, (TMAX <= 2 ? DS2I_WPE2 : 1)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? DS2I_WPE2 : 1)) k_conjunctive
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
     __shared__ Lds<TMAX, !REG> L;
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T, META> cx = make_ctx<CODEC_T, META>(L, a);
+    CtxT<CODEC_T, META, STATS> cx = make_ctx<CODEC_T, META, STATS>(L, a);
     // one work unit per (single-wave) workgroup, costliest units first: the hardware dispatcher
     // interleaves the workgroups of the concurrently running LDS classes as resources free up
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
@@ -869,19 +869,25 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
     // block_mixed (configs[4]; its three block types stay a run-time switch, QMX drops out); block_varint /
     // block_interpolative / block_qmx go through the runtime-dispatch instantiation (CODEC_T = -1)
     case OP_AND:
-        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_AND_FREQ:
-        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_RANKED_AND:
-        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);

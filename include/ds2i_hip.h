@@ -116,6 +116,11 @@ int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t
 int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
                            const uint32_t* query_offsets, uint32_t nq, int want_matches, ds2i_hip_batch** out);
 int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats);
+/* Statistics are an instrumentation option like the reference's block_profiler (`template <bool Profile>`,
+ * block_posting_list.hpp:316-318): with on = 0 the conjunctive operators on block_optpfor / opt run kernels compiled
+ * without the counters (faster; ds2i_hip_stats then carries kernel_ms only and the per-class counters keep the values
+ * of the last instrumented run). Default: on. */
+int ds2i_hip_batch_set_instrumented(ds2i_hip_batch* b, int on);
 /* per kernel class of the last run (class 0: <=2 distinct terms, 1: 3..4, 2: 5..8, 3: 9..16 -- four
  * template instantiations with different LDS footprints, launched concurrently on four streams) */
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);

@@ -92,6 +92,30 @@ def test_reference_order_disjunctive_traversals(coll, queries, images, codec, op
         _check_against_oracle(gidx, oidx, op, queries[:40], k=k)
 
 
+@pytest.mark.parametrize("codec", ["block_optpfor", "opt", "block_qmx"])
+@pytest.mark.parametrize("op", ["and", "and_freq", "ranked_and", "wand"])
+def test_uninstrumented_kernels_give_the_same_results(coll, queries, images, codec, op):
+    """ds2i_hip_batch_set_instrumented(0): kernels compiled without the statistics counters (block_optpfor / opt
+    conjunctive operators; a no-op elsewhere) return exactly what the instrumented ones return."""
+    gidx = d.Index(codec, images[0][codec], images[1])
+    b = d.Batch(gidx, op, queries, k=10)
+    st = b.run()
+    ref = b.fetch()
+    b.set_instrumented(False)
+    st2 = b.run()
+    got = b.fetch()
+    ranked = op in ("ranked_and", "wand")
+    for i, (x, y) in enumerate(zip(ref, got)):  # count, topk, topk_len, freq_sum (top-k only defined for ranked ops)
+        if (ranked and i < 3) or (not ranked and i in (0, 3)):
+            assert np.array_equal(x, y), i
+    assert st2.kernel_ms > 0
+    b.set_instrumented(True)
+    st3 = b.run()
+    if op != "wand":  # the parts of a split wand query race for the shared floor: same results, varying work
+        assert st3.docs_blocks_decoded == st.docs_blocks_decoded and st3.algorithmic_bytes == st.algorithmic_bytes
+    b.close()
+
+
 @pytest.mark.parametrize("op", ["and", "and_freq", "ranked_and"])
 def test_reference_order_kernel_and_algorithmic_bytes(coll, queries, images, op):
     """The one-candidate-per-step GPU traversal decodes exactly the blocks the reference decodes."""
