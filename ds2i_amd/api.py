@@ -76,6 +76,17 @@ def lib():
         L.ds2i_hip_batch_free.argtypes = [vp]
         L.ds2i_hip_batch_free.restype = None
         L.ds2i_hip_batch_set_instrumented.argtypes = [vp, C.c_int]
+        L.ds2i_hip_batch_enable_block_profile.argtypes = [vp]
+        L.ds2i_hip_batch_block_profile.argtypes = [vp, vp, C.c_uint64, u64p]
+        L.ds2i_hybrid_default_model.argtypes = [vp]
+        L.ds2i_hybrid_default_model.restype = None
+        L.ds2i_hybrid_create.argtypes = [C.c_uint64, vp, C.POINTER(vp)]
+        L.ds2i_hybrid_add_posting_list.argtypes = [vp, C.c_uint64, vp, vp, vp]
+        L.ds2i_hybrid_analyse.argtypes = [vp, C.c_int, u64p, u64p]
+        L.ds2i_hybrid_freeze.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(C.c_double), u64p,
+                                         C.POINTER(C.c_double), u64p]
+        L.ds2i_hybrid_free.argtypes = [vp]
+        L.ds2i_hybrid_free.restype = None
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
         # build side
@@ -189,6 +200,60 @@ def build_wand(doc_sizes, lists):
         L.ds2i_wand_free(w)
 
 
+class HybridModel(C.Structure):
+    """MI355X decode cost per 128-value block, wave-level instructions (ds2i_hybrid_model)."""
+    _fields_ = [(n, C.c_float) for n in ("pfor_base", "pfor_exc", "pfor_exc_many", "varint", "interp_base", "interp_node")]
+
+    @classmethod
+    def default(cls):
+        m = cls()
+        lib().ds2i_hybrid_default_model(C.byref(m))
+        return m
+
+
+class HybridBuilder:
+    """block_mixed space/time optimiser (ds2i_hybrid_*; reference optimal_hybrid_index.cpp)."""
+
+    def __init__(self, num_docs, model=None):
+        self._h = C.c_void_p()
+        _check(lib().ds2i_hybrid_create(num_docs, C.byref(model) if model is not None else None, C.byref(self._h)))
+
+    def add_posting_list(self, docs, freqs, access=None):
+        d = np.ascontiguousarray(docs, dtype=np.uint32)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        a = None
+        if access is not None:
+            a = np.ascontiguousarray(access, dtype=np.uint32).reshape(-1)
+            assert a.size == 2 * ((len(d) + 127) // 128)
+        _check(lib().ds2i_hybrid_add_posting_list(self._h, len(d), _ptr(d), _ptr(f), _ptr(a) if a is not None else None))
+
+    def analyse(self, threads=0):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        _check(lib().ds2i_hybrid_analyse(self._h, threads, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def freeze(self, budget_bytes=None, threads=0):
+        """-> (image bytes, dict(rate, space, model_time, type_counts))"""
+        h = C.c_void_p()
+        rate, t, space = C.c_double(), C.c_double(), C.c_uint64()
+        tc = (C.c_uint64 * 6)()
+        budget = 0xFFFFFFFFFFFFFFFF if budget_bytes is None else int(budget_bytes)
+        _check(lib().ds2i_hybrid_freeze(self._h, budget, threads, C.byref(h), C.byref(rate), C.byref(space), C.byref(t), tc))
+        return _take_blob(h), {"rate": rate.value, "space": space.value, "model_time": t.value,
+                               "type_counts": {"docs": list(tc[0:3]), "freqs": list(tc[3:6])}}
+
+    def close(self):
+        if self._h:
+            lib().ds2i_hybrid_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def opt_list_directory(image, term, kind="opt"):
     """The chunk directory the GPU upload builds for one list of a freq_index image (inspection / tests)."""
     hc, hk = C.c_void_p(), C.c_void_p()
@@ -261,6 +326,18 @@ class Batch:
     def set_instrumented(self, on):
         """Statistics counters on (default) / off -- see ds2i_hip_batch_set_instrumented."""
         _check(lib().ds2i_hip_batch_set_instrumented(self._h, 1 if on else 0))
+
+    def enable_block_profile(self):
+        """Start counting per-block decodes (block indexes; instrumented runs accumulate)."""
+        _check(lib().ds2i_hip_batch_enable_block_profile(self._h))
+
+    def block_profile(self):
+        """uint32[total_blocks, 2]: (docs decodes, freqs decodes) per block, lists in index order."""
+        tot = C.c_uint64()
+        _check(lib().ds2i_hip_batch_block_profile(self._h, None, 0, C.byref(tot)))
+        out = np.zeros((max(tot.value, 1), 2), dtype=np.uint32)
+        _check(lib().ds2i_hip_batch_block_profile(self._h, _ptr(out), out.size, C.byref(tot)))
+        return out[:tot.value]
 
     def run(self):
         st = Stats()

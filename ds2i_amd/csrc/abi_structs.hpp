@@ -14,7 +14,8 @@ struct QTerm {
     float q_weight;
     float max_weight; // q_weight * max_term_weight[term]
     uint32_t term;    // block indexes: term id ; opt index: number of chunks of the list
-    uint64_t aux0;    // opt index: absolute bit offset of the list's docs sequence (after its gamma header)
+    uint64_t aux0;    // opt index: absolute bit offset of the list's docs sequence (after its gamma header);
+                      // block indexes: number of blocks of all preceding lists (access-profile base)
     uint64_t aux1;    // opt index: absolute bit offset of the list's freqs sequence
 };
 
@@ -69,6 +70,7 @@ struct BatchArgs {
     // bits; scores are >= 0 so the bit patterns order like the values) and adopt the maximum as their floor: the final
     // k-th score of the union is >= the k-th score of any part
     unsigned int* q_floor;     // nq or null
+    unsigned int* block_profile; // block indexes: 2 counters per block of the index (docs / freqs decodes) or null
     Stats* stats;
 };
 

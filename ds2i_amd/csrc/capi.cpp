@@ -74,6 +74,8 @@ struct ds2i_hip_index {
     std::vector<uint32_t> list_n;
     std::vector<uint32_t> list_nb;  // blocks (block indexes) / chunks (opt index) per list
     std::vector<uint64_t> list_aux0, list_aux1; // opt index: docs / freqs sequence bit offsets
+    std::vector<uint64_t> list_blk_base;        // block indexes: blocks of all preceding lists (access profile)
+    uint64_t total_blocks = 0;
     uint8_t* d_bits0 = nullptr;     // opt index: docs bit vector
     uint8_t* d_bits1 = nullptr;     // opt index: freqs bit vector
     uint64_t extra_bytes = 0;
@@ -89,6 +91,7 @@ struct ds2i_hip_batch {
     uint32_t* d_single = nullptr;   // ids of one-term queries answered by the seed pass
     unsigned int* d_qfloor = nullptr; // per-query shared pruning floor of the disjunctive kernel
     bool instrument = true;           // collect ds2i_hip_stats counters (instrumented kernel instantiations)
+    unsigned int* d_prof = nullptr;   // block access profile (2 counters per block of the index), optional
     uint32_t nsingle = 0;
     ds2i_hip_index* idx = nullptr;
     int op = 0;
@@ -280,6 +283,11 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     for (uint64_t t = 0; t < V; ++t)
         std::memcpy(arena.data() + x->list_off[t], view.lists + view.list_offsets[t],
                     view.list_offsets[t + 1] - view.list_offsets[t]);
+    x->list_blk_base.resize(V);
+    for (uint64_t t = 0; t < V; ++t) {
+        x->list_blk_base[t] = x->total_blocks;
+        x->total_blocks += x->list_nb[t];
+    }
     }
     HIP_OK(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -343,7 +351,7 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     a.term.list_end = idx->list_end[term];
     a.term.n = (uint32_t)len;
     a.term.term = idx->kind >= DS2I_OPT ? idx->list_nb[term] : term;
-    a.term.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[term] : 0;
+    a.term.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[term] : idx->list_blk_base[term];
     a.term.aux1 = idx->kind >= DS2I_OPT ? idx->list_aux1[term] : 0;
     a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
     a.num_docs = (uint32_t)idx->num_docs;
@@ -363,10 +371,12 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
 
 void ds2i_hip_batch_free(ds2i_hip_batch* b) {
     if (!b) return;
+    if (b->seed && b->seed->d_prof == b->d_prof) b->seed->d_prof = nullptr; // shared with the owner
     ds2i_hip_batch_free(b->seed);
     (void)hipSetDevice(b->idx->device);
     (void)hipFree(b->d_qterms);
     (void)hipFree(b->d_qfloor);
+    (void)hipFree(b->d_prof);
     (void)hipFree(b->d_qoff);
     for (auto& o : b->d_order) (void)hipFree(o);
     (void)hipFree(b->d_count);
@@ -431,7 +441,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             qt.list_end = idx->list_end[p.first];
             qt.n = idx->list_n[p.first];
             qt.term = idx->kind >= DS2I_OPT ? idx->list_nb[p.first] : p.first;
-            qt.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[p.first] : 0;
+            qt.aux0 = idx->kind >= DS2I_OPT ? idx->list_aux0[p.first] : idx->list_blk_base[p.first];
             qt.aux1 = idx->kind >= DS2I_OPT ? idx->list_aux1[p.first] : 0;
             qt.q_weight = 0.f;
             qt.max_weight = 0.f;
@@ -639,6 +649,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.seed_topk = b->seed ? b->seed->d_topk : nullptr;
             a.seed_len = b->seed ? b->seed->d_topk_len : nullptr;
             a.q_floor = b->d_qfloor;
+            a.block_profile = b->instrument ? b->d_prof : nullptr;
             a.stats = b->instrument ? idx->d_stats + c : nullptr;
             HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }
@@ -684,6 +695,34 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             stats->rounds += b->cls_stats[c].rounds;
         }
     }
+    return DS2I_OK;
+}
+
+// GPU-side counterpart of profile_queries.cpp: per-block decode counts of the batch (input of the block_mixed
+// optimiser, ds2i_hybrid_*). Counting happens in instrumented runs only and accumulates over runs.
+int ds2i_hip_batch_enable_block_profile(ds2i_hip_batch* b) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_enable_block_profile: null batch");
+    ds2i_hip_index* idx = b->idx;
+    if (idx->kind >= DS2I_OPT) return ds2i_set_error(DS2I_EINVAL, "the block access profile exists for block indexes only");
+    HIP_OK(hipSetDevice(idx->device));
+    const size_t bytes = 8 * (size_t)(idx->total_blocks ? idx->total_blocks : 1);
+    if (!b->d_prof) HIP_OK(hipMalloc((void**)&b->d_prof, bytes));
+    HIP_OK(hipMemset(b->d_prof, 0, bytes));
+    if (b->seed) { // the seed pass decodes blocks too; it shares the buffer (freed by the owner only)
+        if (b->seed->d_prof && b->seed->d_prof != b->d_prof) (void)hipFree(b->seed->d_prof);
+        b->seed->d_prof = b->d_prof;
+    }
+    return DS2I_OK;
+}
+int ds2i_hip_batch_block_profile(ds2i_hip_batch* b, uint32_t* counts, uint64_t capacity, uint64_t* total_blocks) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_block_profile: null batch");
+    ds2i_hip_index* idx = b->idx;
+    if (total_blocks) *total_blocks = idx->total_blocks;
+    if (!counts) return DS2I_OK;
+    if (!b->d_prof) return ds2i_set_error(DS2I_EINVAL, "block profile not enabled on this batch");
+    if (capacity < 2 * idx->total_blocks) return ds2i_set_error(DS2I_EINVAL, "counts buffer too small (2 per block)");
+    HIP_OK(hipSetDevice(idx->device));
+    HIP_OK(hipMemcpy(counts, b->d_prof, 8 * (size_t)idx->total_blocks, hipMemcpyDeviceToHost));
     return DS2I_OK;
 }
 

@@ -11,6 +11,7 @@
 #include "host_encode.hpp"
 #include "host_index.hpp"
 #include "host_pef.hpp"
+#include "host_hybrid.hpp"
 #include "host_synth.hpp"
 
 using namespace ds2i_host;
@@ -19,6 +20,9 @@ struct ds2i_blob { bytes_t data; };
 struct ds2i_builder {
     std::unique_ptr<block_index_builder> b;   // kinds 0..4
     std::unique_ptr<opt_index_builder> opt;   // kinds 5..8 (DS2I_OPT / EF / SINGLE / UNIFORM)
+};
+struct ds2i_hybrid {
+    std::unique_ptr<hybrid_index_builder> b;
 };
 struct ds2i_wand_builder {
     std::vector<float> norm_lens, max_w;
@@ -266,5 +270,64 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
     return 0;
     DS2I_CATCH
 }
+
+
+// ---------------------------------------------------------------- block_mixed optimiser (host_hybrid.hpp)
+void ds2i_hybrid_default_model(ds2i_hybrid_model* m) {
+    if (!m) return;
+    hybrid_model d;
+    m->pfor_base = d.pfor_base; m->pfor_exc = d.pfor_exc; m->pfor_exc_many = d.pfor_exc_many;
+    m->varint = d.varint; m->interp_base = d.interp_base; m->interp_node = d.interp_node;
+}
+int ds2i_hybrid_create(uint64_t num_docs, const ds2i_hybrid_model* model, ds2i_hybrid** out) {
+    if (!out) return ds2i_set_error(-1, "ds2i_hybrid_create: null argument");
+    DS2I_TRY
+    hybrid_model m;
+    if (model) {
+        m.pfor_base = model->pfor_base; m.pfor_exc = model->pfor_exc; m.pfor_exc_many = model->pfor_exc_many;
+        m.varint = model->varint; m.interp_base = model->interp_base; m.interp_node = model->interp_node;
+    }
+    auto* h = new ds2i_hybrid;
+    h->b.reset(new hybrid_index_builder(num_docs, m));
+    *out = h;
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_hybrid_add_posting_list(ds2i_hybrid* h, uint64_t n, const uint32_t* docs, const uint32_t* freqs, const uint32_t* access) {
+    if (!h || !docs || !freqs) return ds2i_set_error(-1, "ds2i_hybrid_add_posting_list: null argument");
+    DS2I_TRY
+    h->b->add_posting_list(n, docs, freqs, access);
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_hybrid_analyse(ds2i_hybrid* h, int threads, uint64_t* min_space, uint64_t* max_space) {
+    if (!h) return ds2i_set_error(-1, "ds2i_hybrid_analyse: null argument");
+    DS2I_TRY
+    if (!h->b->analysed()) h->b->analyse(threads);
+    if (min_space) *min_space = h->b->min_space();
+    if (max_space) *max_space = h->b->max_space();
+    return 0;
+    DS2I_CATCH
+}
+int ds2i_hybrid_freeze(ds2i_hybrid* h, uint64_t budget_bytes, int threads, ds2i_blob** image, double* rate, uint64_t* space,
+                       double* model_time, uint64_t type_counts[6]) {
+    if (!h || !image) return ds2i_set_error(-1, "ds2i_hybrid_freeze: null argument");
+    DS2I_TRY
+    if (!h->b->analysed()) h->b->analyse(threads);
+    if (budget_bytes < h->b->min_space()) return ds2i_set_error(-1, "budget below the smallest possible index");
+    const double r = h->b->solve(budget_bytes);
+    uint64_t s = 0;
+    double t = 0;
+    h->b->evaluate(r, s, t);
+    auto* blob = new ds2i_blob;
+    h->b->freeze(r, threads, blob->data, type_counts);
+    *image = blob;
+    if (rate) *rate = r;
+    if (space) *space = s;
+    if (model_time) *model_time = t;
+    return 0;
+    DS2I_CATCH
+}
+void ds2i_hybrid_free(ds2i_hybrid* h) { delete h; }
 
 } // extern "C"

@@ -20,7 +20,7 @@
 namespace ds2i_dev {
 
 enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
-       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PAD2,
+       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PBASE /* first block of the list in the access profile */,
        M_WORDS }; // 24 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
@@ -76,6 +76,7 @@ struct CtxT {
     const uint8_t* bits1;
     int codec;
     uint32_t num_docs;
+    unsigned int* block_profile; // 2 counters per block (docs, freqs decodes) or null; instrumented kernels only
     DS2I_DEV bool is_pef() const { return CODEC_T == CODEC_PEF || (CODEC_T < 0 && codec == CODEC_PEF); }
     // per-wave statistics (wave-uniform). Like the reference's block_profiler they are a compile-time option
     // (block_posting_list.hpp:316-318 `if (Profile)`): the counters live in SGPRs, and the <=2-list kernel at
@@ -283,6 +284,7 @@ struct CtxT {
         }
         wave_sync();
         ++s_docs_blocks;
+        if (STATS && block_profile && lane == 0) atomicAdd(block_profile + 2ull * (m(s, M_PBASE) + b), 1u);
         s_bytes += 4 + consumed; // endpoint + docs part
         PT_END(*this, PH_DOCS);
     }
@@ -310,6 +312,7 @@ struct CtxT {
         setm(s, M_FDEC, 1);
         wave_sync();
         ++s_freqs_blocks;
+        if (STATS && block_profile && lane == 0) atomicAdd(block_profile + 2ull * (m(s, M_PBASE) + m(s, M_CUR)) + 1, 1u);
         s_bytes += consumed;
         PT_END(*this, PH_FREQS);
     }
@@ -351,6 +354,7 @@ struct CtxT {
         setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
         setm(s, M_BMAX, 0);
         setm(s, M_FDEC, 0);
+        if (STATS) setm(s, M_PBASE, (uint32_t)t.aux0);
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
@@ -471,7 +475,7 @@ typedef CtxT<-1, MetaLds> Ctx;
 DS2I_DEV float doc_term_weight(uint32_t freq, float norm_len) {
     const float b = 0.5f, k1 = 1.2f;
     float f = (float)freq;
-    return f / (f + k1 * (1.0f - b + b * norm_len));
+    return f / (f + k1 * (1.0f - b + b * norm_len)); // IEEE division: a v_rcp_f32 shortcut measured no gain
 }
 
 // ---- top-k scores (topk_queue, queries.hpp:152-197), k <= 64: lane j keeps the j-th

@@ -55,6 +55,7 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
     c.bits1 = a.bits1;
     c.codec = a.codec;
     c.num_docs = a.num_docs;
+    c.block_profile = a.block_profile;
     c.init_stats();
     return c;
 }

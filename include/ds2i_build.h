@@ -62,6 +62,28 @@ int ds2i_opt_list_directory(const void* opt_image, size_t bytes, uint32_t term, 
 int ds2i_freq_list_directory(int kind, const void* image, size_t bytes, uint32_t term, ds2i_blob** cmax,
                              ds2i_blob** chunks, uint64_t info[5]);
 
+/* block_mixed space/time optimiser (reference optimal_hybrid_index.cpp + mixed_block.hpp:119-150).
+ * For every block: OptPFor with each usable b, VarInt-G8IU, interpolative -> (bytes, model time x (access + 1));
+ * globally: minimise the summed time subject to summed payload bytes <= budget (lower convex hull per block +
+ * one Lagrange multiplier). The time model is the MI355X kernels' instruction cost per block (defaults measured with
+ * rocprofv3), the access counts come from ds2i_hip_batch_block_profile (2 per block, list by list) or NULL. */
+typedef struct ds2i_hybrid ds2i_hybrid;
+typedef struct ds2i_hybrid_model {
+    float pfor_base, pfor_exc, pfor_exc_many, varint, interp_base, interp_node;
+} ds2i_hybrid_model;
+void ds2i_hybrid_default_model(ds2i_hybrid_model* m);
+int ds2i_hybrid_create(uint64_t num_docs, const ds2i_hybrid_model* model /* NULL = default */, ds2i_hybrid** out);
+int ds2i_hybrid_add_posting_list(ds2i_hybrid* h, uint64_t n, const uint32_t* docs, const uint32_t* freqs,
+                                 const uint32_t* access /* 2 * ceil(n/128) counters or NULL */);
+/* computes every block's candidates; min_space / max_space = payload bytes of the smallest / fastest index */
+int ds2i_hybrid_analyse(ds2i_hybrid* h, int threads, uint64_t* min_space, uint64_t* max_space);
+/* encodes the block_mixed image for the budget (payload bytes; pass UINT64_MAX for the fastest index).
+ * rate = bytes spent per unit of model time saved at the optimum, type_counts = full blocks by
+ * {docs pfor, docs varint, docs interpolative, freqs pfor, freqs varint, freqs interpolative} */
+int ds2i_hybrid_freeze(ds2i_hybrid* h, uint64_t budget_bytes, int threads, ds2i_blob** image, double* rate,
+                       uint64_t* space, double* model_time, uint64_t type_counts[6]);
+void ds2i_hybrid_free(ds2i_hybrid* h);
+
 /* synthetic collection */
 uint64_t ds2i_synth_list_upper_bound(const ds2i_synth_params* p, uint32_t term);
 int ds2i_synth_list(const ds2i_synth_params* p, uint32_t term, uint32_t* docs, uint32_t* freqs, uint64_t capacity,

@@ -121,6 +121,14 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats);
  * without the counters (faster; ds2i_hip_stats then carries kernel_ms only and the per-class counters keep the values
  * of the last instrumented run). Default: on. */
 int ds2i_hip_batch_set_instrumented(ds2i_hip_batch* b, int on);
+
+/* Block access profile of a batch on a block index (the GPU-side profile_queries.cpp, reference
+ * profile_queries.cpp:21-95): after enable, every instrumented run adds, for each 128-posting block of the index,
+ * the number of docs-part and freqs-part decodes. counts receives 2 x total_blocks values, blocks numbered list by
+ * list in index order (block b of list t at 2 * (sum_{u<t} ceil(n_u/128) + b)). Pass counts = NULL to query
+ * total_blocks only. Input of the block_mixed optimiser (ds2i_hybrid_*, ds2i_build.h). */
+int ds2i_hip_batch_enable_block_profile(ds2i_hip_batch* b);
+int ds2i_hip_batch_block_profile(ds2i_hip_batch* b, uint32_t* counts, uint64_t capacity, uint64_t* total_blocks);
 /* per kernel class of the last run (class 0: <=2 distinct terms, 1: 3..4, 2: 5..8, 3: 9..16 -- four
  * template instantiations with different LDS footprints, launched concurrently on four streams) */
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);

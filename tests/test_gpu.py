@@ -346,3 +346,44 @@ def test_queries_cli_and_cpp_adaptor(coll, queries, images, tmp_path):
     assert "Unsupported query type: bogus" in r.stderr
     r = subprocess.run([tool, "no_such_index", "and", str(idx_path)], input=log, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "ERROR: Unknown type" in r.stderr  # queries.cpp:149-151
+
+
+def test_block_profile_and_hybrid_optimiser(coll, queries, images):
+    """GPU block-access profile (ds2i_hip_batch_block_profile) -> block_mixed optimiser (ds2i_hybrid_*) -> the
+    optimised index answers every operator like the oracle, and its profile-weighted model time is lower than the
+    fixed-policy index's at the same size."""
+    codec = "block_mixed"
+    gidx = d.Index(codec, images[0][codec], images[1])
+    b = d.Batch(gidx, "ranked_and", queries, k=10)
+    b.enable_block_profile()
+    st = b.run()
+    prof = b.block_profile()
+    nb_all = sum((len(dd) + 127) // 128 for dd, _ in coll.lists)
+    assert prof.shape == (nb_all, 2)
+    assert int(prof[:, 0].sum()) == st.docs_blocks_decoded and int(prof[:, 1].sum()) == st.freqs_blocks_decoded
+    st2 = b.run()  # accumulates
+    assert int(b.block_profile()[:, 0].sum()) == 2 * st.docs_blocks_decoded
+    b.close()
+    # wand profile includes its ranked_and seed pass
+    bw = d.Batch(gidx, "wand", queries, k=10)
+    bw.enable_block_profile()
+    bw.run()
+    assert int(bw.block_profile().sum()) > 0
+    bw.close()
+
+    hb = d.HybridBuilder(coll.num_docs)
+    base = 0
+    for docs, freqs in coll.lists:
+        nb = (len(docs) + 127) // 128
+        hb.add_posting_list(docs, freqs, prof[base:base + nb])
+        base += nb
+    lo, hi = hb.analyse()
+    img, info = hb.freeze(int(lo + 0.5 * (hi - lo)))
+    assert info["space"] <= int(lo + 0.5 * (hi - lo))
+    g2 = d.Index(codec, img, images[1])
+    o2 = o.Index(codec, img, images[1])
+    for t in range(0, len(coll.lists), 9):
+        dd, ff = g2[t]
+        assert np.array_equal(dd, coll.lists[t][0]) and np.array_equal(ff, coll.lists[t][1])
+    for op in ALL_OPS:
+        _check_against_oracle(g2, o2, op, queries)
