@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mixed-policy", default="optimised", choices=["optimised", "fixed"],
+                    help="block_mixed only: ds2i_hybrid optimiser (default) or the fixed per-block size policy")
     ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2", "cw09"])
     ap.add_argument("--op", default="ranked_and")
     ap.add_argument("--codec", default="block_optpfor")
@@ -110,7 +112,14 @@ def main():
     img = wand = None
     if rank == 0:
         t0 = time.time()
-        img, wand, postings = d.synth_build(p, args.codec, threads)
+        if args.codec == "block_mixed" and args.mixed_policy == "optimised":
+            # block_mixed images come out of the space/time optimiser (the reference builds them with
+            # optimal_hybrid_index.cpp): MI355X decode-time model, uniform access, budget halfway between the
+            # smallest and the fastest index
+            img, wand, postings, tc = d.synth_build_hybrid(p, budget_frac=0.5, threads=threads)
+            log("block_mixed optimiser: full blocks by type (pfor, varint, interpolative) docs %s freqs %s" % (tc["docs"], tc["freqs"]))
+        else:
+            img, wand, postings = d.synth_build(p, args.codec, threads)
         log("built %s index: %d postings, %.1f MB, %.1fs" % (wl, postings, len(img) / 1e6, time.time() - t0))
     img = sh.share_bytes(dist, rank, img, f_idx)
     wand = sh.share_bytes(dist, rank, wand, f_wand)

@@ -85,6 +85,7 @@ def lib():
         L.ds2i_hybrid_analyse.argtypes = [vp, C.c_int, u64p, u64p]
         L.ds2i_hybrid_freeze.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(C.c_double), u64p,
                                          C.POINTER(C.c_double), u64p]
+        L.ds2i_synth_build_hybrid.argtypes = [vp, C.c_int, vp, vp, C.c_double, C.POINTER(vp), C.POINTER(vp), u64p, u64p]
         L.ds2i_hybrid_free.argtypes = [vp]
         L.ds2i_hybrid_free.restype = None
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
@@ -252,6 +253,18 @@ class HybridBuilder:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def synth_build_hybrid(p, budget_frac=0.5, threads=0, access=None, model=None):
+    """The synthetic collection as an optimised block_mixed index -> (index image, wand image, postings, type_counts)."""
+    hi, hw = C.c_void_p(), C.c_void_p()
+    n = C.c_uint64()
+    tc = (C.c_uint64 * 6)()
+    a = None if access is None else np.ascontiguousarray(access, dtype=np.uint32).reshape(-1)
+    _check(lib().ds2i_synth_build_hybrid(C.byref(p), threads, C.byref(model) if model is not None else None,
+                                         _ptr(a) if a is not None else None, float(budget_frac), C.byref(hi), C.byref(hw),
+                                         C.byref(n), tc))
+    return _take_blob(hi), _take_blob(hw), n.value, {"docs": list(tc[0:3]), "freqs": list(tc[3:6])}
 
 
 def opt_list_directory(image, term, kind="opt"):

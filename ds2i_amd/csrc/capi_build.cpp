@@ -266,7 +266,7 @@ int ds2i_synth_build(const ds2i_synth_params* pp, int codec, int threads, ds2i_b
         wand_freeze(norm_lens, max_w, wb->data);
         *wand_image = wb;
     }
-    if (total_postings) *total_postings = postings.load();
+    if (total_postings) *total_postings = postings;
     return 0;
     DS2I_CATCH
 }
@@ -329,5 +329,75 @@ int ds2i_hybrid_freeze(ds2i_hybrid* h, uint64_t budget_bytes, int threads, ds2i_
     DS2I_CATCH
 }
 void ds2i_hybrid_free(ds2i_hybrid* h) { delete h; }
+
+// The synthetic collection through the optimiser: lists are regenerated (pure functions of seed and term) for the
+// analysis pass and again for the encoding pass, so a GOV2- / ClueWeb-scale collection never sits in memory raw.
+// budget = min_space + budget_frac * (max_space - min_space).
+int ds2i_synth_build_hybrid(const ds2i_synth_params* pp, int threads, const ds2i_hybrid_model* model, const uint32_t* access,
+                            double budget_frac, ds2i_blob** index_image, ds2i_blob** wand_image, uint64_t* total_postings,
+                            uint64_t type_counts[6]) {
+    if (!pp || !index_image || !(budget_frac >= 0.0 && budget_frac <= 1.0))
+        return ds2i_set_error(-1, "ds2i_synth_build_hybrid: bad argument");
+    DS2I_TRY
+    const synth_params p = to_params(pp);
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    hybrid_model m;
+    if (model) {
+        m.pfor_base = model->pfor_base; m.pfor_exc = model->pfor_exc; m.pfor_exc_many = model->pfor_exc_many;
+        m.varint = model->varint; m.interp_base = model->interp_base; m.interp_node = model->interp_node;
+    }
+    const uint32_t V = p.num_terms;
+    std::vector<uint32_t> sizes;
+    synth_doc_sizes(p, sizes);
+    std::vector<float> norm_lens;
+    compute_norm_lens(sizes.data(), p.num_docs, norm_lens);
+    std::vector<uint32_t>().swap(sizes);
+    // pass 0: list lengths (block numbering of `access`), max term weights
+    std::vector<float> max_w(V, 0.f);
+    std::vector<uint64_t> len(V, 0);
+    {
+        std::atomic<uint32_t> next(0);
+        auto worker = [&]() {
+            std::vector<uint32_t> d, f;
+            for (;;) {
+                const uint32_t t = next.fetch_add(1);
+                if (t >= V) break;
+                len[t] = synth_list(p, t, d, f);
+                max_w[t] = list_max_weight(norm_lens.data(), len[t], d.data(), f.data());
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    hybrid_index_builder hb(p.num_docs, m);
+    uint64_t base = 0, postings = 0;
+    for (uint32_t t = 0; t < V; ++t) {
+        const uint64_t blocks = ceil_div(len[t], (uint64_t)BLOCK);
+        hb.add_virtual_list(access ? access + 2 * base : nullptr, blocks);
+        base += blocks;
+        postings += len[t];
+    }
+    hb.set_provider([&](size_t t, std::vector<uint32_t>& d, std::vector<uint32_t>& f) {
+        const uint64_t n = synth_list(p, (uint32_t)t, d, f);
+        d.resize(n);
+        f.resize(n);
+    });
+    hb.analyse(threads);
+    const uint64_t lo = hb.min_space(), hi = hb.max_space();
+    const uint64_t budget = lo + (uint64_t)(budget_frac * double(hi - lo));
+    const double rate = hb.solve(budget);
+    auto* ib = new ds2i_blob;
+    hb.freeze(rate, threads, ib->data, type_counts);
+    *index_image = ib;
+    if (wand_image) {
+        auto* wb = new ds2i_blob;
+        wand_freeze(norm_lens, max_w, wb->data);
+        *wand_image = wb;
+    }
+    if (total_postings) *total_postings = postings;
+    return 0;
+    DS2I_CATCH
+}
 
 } // extern "C"

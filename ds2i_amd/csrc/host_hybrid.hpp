@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <functional>
 #include <thread>
 
 #include "host_encode.hpp"
@@ -135,6 +136,17 @@ public:
         m_lists.push_back(std::move(L));
     }
 
+    // A list that is not stored but regenerated on demand (large synthetic collections): provider(t, docs, freqs)
+    // must return the same postings every time it is called for list t.
+    typedef std::function<void(size_t, std::vector<uint32_t>&, std::vector<uint32_t>&)> provider_t;
+    void add_virtual_list(const uint32_t* access, uint64_t blocks) {
+        list_t L;
+        L.is_virtual = true;
+        if (access) L.access.assign(access, access + 2 * blocks);
+        m_lists.push_back(std::move(L));
+    }
+    void set_provider(provider_t p) { m_provider = std::move(p); }
+
     // computes every block's hull (threaded). Afterwards min_space()/max_space() are known.
     void analyse(int threads) {
         const size_t V = m_lists.size();
@@ -146,7 +158,11 @@ public:
                 const size_t t = next.fetch_add(1);
                 if (t >= V) break;
                 list_t& L = m_lists[t];
-                const uint64_t n = L.docs.size(), blocks = ceil_div(n, (uint64_t)BLOCK);
+                std::vector<uint32_t> vd, vf;
+                if (L.is_virtual) m_provider(t, vd, vf);
+                const std::vector<uint32_t>& D = L.is_virtual ? vd : L.docs;
+                const std::vector<uint32_t>& F = L.is_virtual ? vf : L.freqs;
+                const uint64_t n = D.size(), blocks = ceil_div(n, (uint64_t)BLOCK);
                 L.hull_off.assign(2 * blocks + 1, 0);
                 L.hull.clear();
                 uint32_t last_doc = uint32_t(-1), block_base = 0;
@@ -154,9 +170,9 @@ public:
                 for (uint64_t b = 0; b < blocks; ++b) {
                     const uint32_t cur = ((b + 1) * BLOCK <= n) ? BLOCK : (uint32_t)(n % BLOCK);
                     for (uint32_t i = 0; i < cur; ++i, ++k) {
-                        dbuf[i] = L.docs[k] - last_doc - 1;
-                        last_doc = L.docs[k];
-                        fbuf[i] = L.freqs[k] - 1;
+                        dbuf[i] = D[k] - last_doc - 1;
+                        last_doc = D[k];
+                        fbuf[i] = F[k] - 1;
                     }
                     hybrid_block_points(dbuf, last_doc - block_base - (cur - 1), cur, L.access.empty() ? 0 : L.access[2 * b], m_model, hull);
                     L.hull.insert(L.hull.end(), hull.begin(), hull.end());
@@ -216,8 +232,12 @@ public:
                 const size_t t = next.fetch_add(1);
                 if (t >= V) break;
                 list_t const& L = m_lists[t];
+                std::vector<uint32_t> vd, vf;
+                if (L.is_virtual) m_provider(t, vd, vf);
+                const std::vector<uint32_t>& D = L.is_virtual ? vd : L.docs;
+                const std::vector<uint32_t>& F = L.is_virtual ? vf : L.freqs;
                 bytes_t& out = enc[t];
-                const uint32_t n = (uint32_t)L.docs.size();
+                const uint32_t n = (uint32_t)D.size();
                 vbyte_encode(n, out);
                 const uint64_t blocks = ceil_div((uint64_t)n, (uint64_t)BLOCK);
                 const size_t begin_maxs = out.size(), begin_endpoints = begin_maxs + 4 * blocks,
@@ -228,9 +248,9 @@ public:
                 for (uint64_t b = 0; b < blocks; ++b) {
                     const uint32_t cur = ((b + 1) * BLOCK <= n) ? BLOCK : (n % BLOCK);
                     for (uint32_t i = 0; i < cur; ++i, ++k) {
-                        dbuf[i] = L.docs[k] - last_doc - 1;
-                        last_doc = L.docs[k];
-                        fbuf[i] = L.freqs[k] - 1;
+                        dbuf[i] = D[k] - last_doc - 1;
+                        last_doc = D[k];
+                        fbuf[i] = F[k] - 1;
                     }
                     std::memcpy(&out[begin_maxs + 4 * b], &last_doc, 4);
                     for (int side = 0; side < 2; ++side) {
@@ -264,6 +284,7 @@ public:
 private:
     struct list_t {
         std::vector<uint32_t> docs, freqs, access;
+        bool is_virtual = false;
         std::vector<hybrid_point> hull;  // concatenated hulls
         std::vector<uint32_t> hull_off;  // 2 * blocks + 1 offsets (docs block 0, freqs block 0, docs block 1, ...)
     };
@@ -277,6 +298,7 @@ private:
     uint64_t m_num_docs;
     hybrid_model m_model;
     std::vector<list_t> m_lists;
+    provider_t m_provider;
     bool m_analysed = false;
 };
 

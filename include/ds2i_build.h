@@ -95,6 +95,12 @@ int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t*
 int ds2i_synth_build(const ds2i_synth_params* p, int codec, int threads, ds2i_blob** index_image,
                      ds2i_blob** wand_image, uint64_t* total_postings);
 
+/* the synthetic collection encoded by the block_mixed optimiser (lists regenerated for each pass):
+ * payload budget = smallest + budget_frac * (fastest - smallest); access = 2 counters per block or NULL (uniform) */
+int ds2i_synth_build_hybrid(const ds2i_synth_params* p, int threads, const ds2i_hybrid_model* model, const uint32_t* access,
+                            double budget_frac, ds2i_blob** index_image, ds2i_blob** wand_image, uint64_t* total_postings,
+                            uint64_t type_counts[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,20 @@ def test_queries_on_optimised_index_match_brute_force(coll):
         exp = brute_and(coll, q)
         assert r["count"] == len(exp) and np.array_equal(r["matches"], exp)
         np.testing.assert_allclose(idx.query("ranked_and", q)["topk"], brute_ranked(coll, q, 10, True, "size"), rtol=RTOL)
+
+
+def test_synth_build_hybrid_equals_the_raw_collection(built_lib):
+    """the streaming form (lists regenerated per pass) encodes exactly the synthetic collection"""
+    p = small_params(num_docs=20000, num_terms=64)
+    img, wand, postings, tc = d.synth_build_hybrid(p, budget_frac=0.5)
+    img_ref, wand_ref, postings_ref = d.synth_build(p, "block_mixed")
+    assert postings == postings_ref and bytes(wand) == bytes(wand_ref)
+    idx = o.Index("block_mixed", img)
+    for t in range(0, p.num_terms, 5):
+        docs, freqs = d.synth_list(p, t)
+        dd, ff = idx.enumerate(t)
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs)
+    assert sum(tc["docs"]) > 0
+    lo = d.synth_build_hybrid(p, budget_frac=0.0)[0]
+    hi = d.synth_build_hybrid(p, budget_frac=1.0)[0]
+    assert len(lo) <= len(img) <= len(hi)
