@@ -106,7 +106,13 @@ def test_uninstrumented_kernels_give_the_same_results(coll, queries, images, cod
     got = b.fetch()
     ranked = op in ("ranked_and", "wand")
     for i, (x, y) in enumerate(zip(ref, got)):  # count, topk, topk_len, freq_sum (top-k only defined for ranked ops)
-        if (ranked and i < 3) or (not ranked and i in (0, 3)):
+        if op == "wand" and i == 1:
+            # the parts of a split query race for the shared floor, which decides in what order a document's term
+            # scores are added: same top-k up to float re-association
+            f = np.isfinite(x)
+            assert np.array_equal(f, np.isfinite(y))
+            np.testing.assert_allclose(x[f], y[f], rtol=1e-6)
+        elif (ranked and i < 3) or (not ranked and i in (0, 3)):
             assert np.array_equal(x, y), i
     assert st2.kernel_ms > 0
     b.set_instrumented(True)
