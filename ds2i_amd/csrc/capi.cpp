@@ -590,7 +590,31 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     }
     if (disj_topk && !(op & DS2I_OP_REFERENCE_ORDER)) HIP_OK(hipMalloc((void**)&b->d_qfloor, 4 * (size_t)(nq ? nq : 1)));
     if (seeded) {
-        int rc = ds2i_hip_batch_prepare(idx, DS2I_OP_RANKED_AND, k, terms, query_offsets, nq, 0, &b->seed);
+        // The seed is the ranked_and top-k of a SUB-query: any k documents' partial scores bound the final k-th
+        // score from below. One- and two-term queries use all their terms (the one-term answer is final); longer
+        // queries use their two shortest lists -- the full conjunction of 5+ terms is usually too small to give k
+        // documents, while the rarest pair is cheap to intersect and carries the largest term weights.
+        const char* sv = std::getenv("DS2I_SEED_TERMS");
+        const size_t seed_terms = sv && std::atoi(sv) > 0 ? (size_t)std::atoi(sv) : 2;
+        std::vector<uint32_t> sterms, soffs(nq + 1, 0);
+        std::vector<uint32_t> dt;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint32_t* qb = terms + query_offsets[q];
+            const uint32_t* qe = terms + query_offsets[q + 1];
+            dt.assign(qb, qe);
+            std::sort(dt.begin(), dt.end());
+            dt.erase(std::unique(dt.begin(), dt.end()), dt.end());
+            if (dt.size() > seed_terms && dt.size() > 2) {
+                std::stable_sort(dt.begin(), dt.end(), [&](uint32_t x, uint32_t y) { return idx->list_n[x] < idx->list_n[y]; });
+                dt.resize(std::max<size_t>(2, seed_terms));
+                for (const uint32_t* p = qb; p != qe; ++p) // keep multiplicities: the query term weight counts them
+                    if (std::find(dt.begin(), dt.end(), *p) != dt.end()) sterms.push_back(*p);
+            } else {
+                sterms.insert(sterms.end(), qb, qe);
+            }
+            soffs[q + 1] = (uint32_t)sterms.size();
+        }
+        int rc = ds2i_hip_batch_prepare(idx, DS2I_OP_RANKED_AND, k, sterms.data(), soffs.data(), nq, 0, &b->seed);
         if (rc) return rc;
         b->nsingle = (uint32_t)single_queries.size();
         HIP_OK(upload((void**)&b->d_single, single_queries.data(), single_queries.size() * 4));

@@ -588,11 +588,11 @@ struct LdsOr : Lds<TMAX, true> {
     uint8_t dup[TMAX][128];
 };
 
-template <int TMAX, int CODEC_T>
+template <int TMAX, int CODEC_T, bool STATS = true>
 __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
     __shared__ LdsOr<TMAX> L;
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T, MetaLds> cx = make_ctx<CODEC_T, MetaLds>(L, a);
+    CtxT<CODEC_T, MetaLds, STATS> cx = make_ctx<CODEC_T, MetaLds, STATS>(L, a);
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
         const Unit u = a.units[uid];
@@ -901,7 +901,8 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
     case OP_WAND:
     case OP_MAXSCORE:
     case OP_RANKED_OR:
-        if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, 0, s, a);

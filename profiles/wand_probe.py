@@ -11,3 +11,7 @@ for op in ("wand", "maxscore"):
     for i in range(3):
         t0 = time.perf_counter(); st = b.run(); t1 = time.perf_counter()
         print(op, "run wall %.1f ms, stats.kernel_ms %.1f" % (1e3 * (t1 - t0), st.kernel_ms), [round(b.class_stats(c)[0].kernel_ms, 1) for c in range(4)], [b.class_stats(c)[1] for c in range(4)], flush=True)
+    for c in range(4):
+        st, nqc = b.class_stats(c)
+        s = st.as_dict()
+        print("   class %d: %d queries %.1f ms docs %d freqs %d bm %d scored %d rounds %d" % (c, nqc, s["kernel_ms"], s["docs_blocks_decoded"], s["freqs_blocks_decoded"], s["block_max_examined"], s["postings_scored"], s["rounds"]))
