@@ -397,8 +397,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
     const bool conj = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
     const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-    if ((op & DS2I_OP_REFERENCE_ORDER) && !conj && !disj_topk)
-        return ds2i_set_error(DS2I_EINVAL, "DS2I_OP_REFERENCE_ORDER does not apply to or / or_freq");
+
     const bool ranked = base_op >= DS2I_OP_RANKED_AND;
     if (ranked && !idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
     if (ranked && (k == 0 || k > DS2I_HIP_MAX_K)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1,64]");

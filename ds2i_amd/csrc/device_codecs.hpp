@@ -327,9 +327,6 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
         return 4 * (1 + 128);
     }
     if (nexc > 128) nexc = 128; // corrupt header: stay inside the scratch arrays
-#ifdef DS2I_PROBE_NOEXC
-    nexc = 0;
-#endif
     const uint32_t total = 4 * (1 + ew + 4 * b);
     const bool fast = (((uintptr_t)p & 3) == 0) && w.covers(p, total + 4);
     const uint32_t* blk = w.st + ((uint32_t)(p - w.gbase) >> 2); // only dereferenced when fast

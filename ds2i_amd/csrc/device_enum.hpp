@@ -186,8 +186,8 @@ struct CtxT {
         const uint8_t* lend = ptr(s, M_END_LO);
         const uint32_t cur = m(s, M_CUR);
         const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
-        uint32_t ep, bmax, base, next_ep;
-        const uint8_t* p;
+        uint32_t ep = 0, bmax = 0, base = 0, next_ep = 0;
+        const uint8_t* p = nullptr;
         bool have = false;
         if constexpr (META::NPF > 0) {
             if (s < (uint32_t)META::NPF && cur != 0xFFFFFFFFu && meta.pf_blk[s < (uint32_t)META::NPF ? s : 0] == b) { // the bytes are already in registers

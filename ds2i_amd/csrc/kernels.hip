@@ -18,9 +18,6 @@
 
 using namespace ds2i_dev;
 
-#ifndef DS2I_WPE2
-#define DS2I_WPE2 8
-#endif
 namespace {
 
 template <int TMAX, bool META_IN_LDS = true>
@@ -106,7 +103,7 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
     }
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
-__global__ void __launch_bounds__(64, (TMAX <= 2 ? DS2I_WPE2 : 1)) k_conjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
@@ -588,7 +585,10 @@ struct LdsOr : Lds<TMAX, true> {
     uint8_t dup[TMAX][128];
 };
 
-template <int TMAX, int CODEC_T, bool STATS = true>
+// MODE 0: top-k (wand / maxscore / ranked_or). MODE 1: or_query (count of the union, queries.hpp:88-131): every list is
+// essential, owned candidates are counted. MODE 2: or_query<with_freqs>: additionally every freq of the window is
+// summed (the reference touches them all).
+template <int TMAX, int CODEC_T, bool STATS = true, int MODE = 0>
 __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
     __shared__ LdsOr<TMAX> L;
     const uint32_t lane = lane_id();
@@ -603,14 +603,20 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         TopK tk;
         tk.init(a.k);
+        unsigned long long count = 0, fsum = 0;
         if (nt == 0 || nt > (uint32_t)TMAX || N == 0) {
-            if (whole) { if (lane == 0) a.out_count[q] = 0; store_topk(a.out_topk, a.out_topk_len, a.k, q, tk); }
-            else { if (lane == 0) { a.unit_count[uid] = 0; a.unit_freq_sum[uid] = 0; } store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk); }
+            if (whole) {
+                if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
+                if (MODE == 0) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+            } else {
+                if (lane == 0) { a.unit_count[uid] = 0; a.unit_freq_sum[uid] = 0; }
+                if (MODE == 0) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
+            }
             continue;
         }
         for (uint32_t i = 0; i < nt; ++i) cx.bind(i, a.qterms[t0 + i]);
-        cx.s_bytes += 4ull * nt; // max_term_weight[term]
-        if (a.seed_topk && a.seed_len[q] >= a.k) { // see k_daat: ranked_and's k-th score, relaxed by 1e-5
+        if (MODE == 0) cx.s_bytes += 4ull * nt; // max_term_weight[term]
+        if (MODE == 0 && a.seed_topk && a.seed_len[q] >= a.k) { // see k_daat: ranked_and's k-th score, relaxed by 1e-5
             const float kth = a.seed_topk[(size_t)q * a.k + a.k - 1];
             tk.floor = __uint_as_float(uniform(__float_as_uint(kth * (1.0f - 1.0e-5f))));
         }
@@ -636,7 +642,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         auto maxw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_MAXW)); };
         auto qw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_QW)); };
         uint32_t non_ess = 0;
-        auto update_non_ess = [&]() { while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
+        auto update_non_ess = [&]() { if (MODE == 0) while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
         update_non_ess();
         // positions list x on the first block whose block_max >= d; false when the list has no posting >= d
         auto seek = [&](uint32_t x, uint32_t d, bool may_go_back) -> bool {
@@ -659,7 +665,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             if (blk != cur) cx.decode_docs(x, blk);
             return true;
         };
-        const bool shared_floor = !whole && a.q_floor;
+        const bool shared_floor = MODE == 0 && !whole && a.q_floor;
         auto adopt_floor = [&]() { // another part of this query may have raised the bar
             const float f = __uint_as_float(uniform(__hip_atomic_load(a.q_floor + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
             if (f > tk.floor) { tk.floor = f; update_non_ess(); }
@@ -680,6 +686,20 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             }
             if (!live) break;
             wave_sync();
+            if (MODE == 2) { // every freq of every list inside the window
+                unsigned long long fs = 0;
+                for (uint32_t p = 0; p < nt; ++p) {
+                    const uint32_t x = slot_at(p);
+                    if (!((live >> x) & 1u)) continue;
+                    const uint32_t c0 = L.docs[x][lane], c1 = L.docs[x][lane + 64];
+                    const bool i0 = c0 >= lo && c0 <= hi, i1 = c1 >= lo && c1 <= hi;
+                    if (!(ballot(i0) | ballot(i1))) continue;
+                    if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
+                    fs += (unsigned long long)(i0 ? L.freqs[x][lane] : 0u) + (i1 ? L.freqs[x][lane + 64] : 0u);
+                }
+                for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                fsum += fs;
+            }
             for (uint32_t p = non_ess; p < nt; ++p) { // ---- owner list e: its postings in [lo, hi] not owned earlier
                 if (p < non_ess) continue;             // became non-essential during this window
                 const uint32_t e = slot_at(p);
@@ -688,6 +708,18 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                 bool v0 = c0 >= lo && c0 <= hi && !L.dup[e][lane];
                 bool v1 = c1 >= lo && c1 <= hi && !L.dup[e][lane + 64];
                 if (!(ballot(v0) | ballot(v1))) continue;
+                if (MODE != 0) { // or_query: count the owned candidates, mark their copies in the later lists
+                    count += (unsigned long long)(__builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1)));
+                    for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
+                        const uint32_t x = slot_at(p2);
+                        if (!((live >> x) & 1u)) continue;
+                        uint32_t q0, q1;
+                        if (member_bsearch(L.docs[x], c0, v0, q0)) L.dup[x][q0] = 1;
+                        if (member_bsearch(L.docs[x], c1, v1, q1)) L.dup[x][q1] = 1;
+                    }
+                    wave_sync();
+                    continue;
+                }
                 uint32_t fm0 = 0, fm1 = 0; // lists (beyond e) each candidate occurs in
                 const float ub_ne = non_ess ? ubf(non_ess - 1) : 0.f;
                 float pb0 = maxw(e) + ub_ne, pb1 = pb0;
@@ -777,11 +809,11 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             lo = hi + 1;
         }
         if (whole) {
-            if (lane == 0) { a.out_count[q] = tk.n; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
-            store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+            if (lane == 0) { a.out_count[q] = MODE == 0 ? tk.n : count; if (a.out_freq_sum) a.out_freq_sum[q] = fsum; }
+            if (MODE == 0) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
         } else {
-            if (lane == 0) { a.unit_count[uid] = tk.n; a.unit_freq_sum[uid] = 0; }
-            store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
+            if (lane == 0) { a.unit_count[uid] = MODE == 0 ? tk.n : count; a.unit_freq_sum[uid] = fsum; }
+            if (MODE == 0) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
     }
     cx.flush_stats(a.stats);
@@ -895,8 +927,10 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
         break;
     // the ranked disjunctive operators get the same two codec specialisations (BASELINE configs[3] runs them on
     // block_optpfor); or / or_freq and the reference-order conjunctions stay on the runtime-dispatch instantiation
-    case OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
-    case OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
+    case OP_OR: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 1>), g, b, 0, s, a); break;
+    case OP_OR_FREQ: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 2>), g, b, 0, s, a); break;
+    case 0x100 | OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
+    case 0x100 | OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
     // wand / maxscore / ranked_or: the block-synchronous disjunctive kernel (identical results by definition)
     case OP_WAND:
     case OP_MAXSCORE:

@@ -46,7 +46,7 @@ enum ds2i_hip_op {
     DS2I_OP_WAND = 5,       /* wand_query         queries.hpp:200-319 */
     DS2I_OP_MAXSCORE = 6,   /* maxscore_query     queries.hpp:478-591 */
     DS2I_OP_RANKED_OR = 7,  /* ranked_or_query    queries.hpp:404-476 */
-    /* OR this flag into and / and_freq / ranked_and / wand / maxscore / ranked_or to run the reference's
+    /* OR this flag into any operator to run the reference's
        one-document-per-step traversal on the GPU instead of the block-synchronous kernel (same results; used to
        cross-check and to count the reference traversal's algorithmic bytes on the device). */
     DS2I_OP_REFERENCE_ORDER = 0x100

@@ -81,15 +81,16 @@ def test_query_ops_match_oracle(coll, queries, images, codec, op):
 
 
 @pytest.mark.parametrize("codec", ["block_optpfor", "block_mixed", "opt"])
-@pytest.mark.parametrize("op", ["wand", "maxscore", "ranked_or"])
+@pytest.mark.parametrize("op", ["wand", "maxscore", "ranked_or", "or", "or_freq"])
 def test_reference_order_disjunctive_traversals(coll, queries, images, codec, op):
     """wand / maxscore / ranked_or also exist as the reference's one-document-per-step traversals (k_daat,
     DS2I_OP_REFERENCE_ORDER); the default is the block-synchronous kernel. Both must equal the oracle."""
     gidx = d.Index(codec, images[0][codec], images[1])
     oidx = o.Index(codec, images[0][codec], images[1])
     _check_against_oracle(gidx, oidx, op, queries, reference_order=True)
-    for k in (1, 3, 64):
-        _check_against_oracle(gidx, oidx, op, queries[:40], k=k)
+    if op not in ("or", "or_freq"):
+        for k in (1, 3, 64):
+            _check_against_oracle(gidx, oidx, op, queries[:40], k=k)
 
 
 @pytest.mark.parametrize("codec", ["block_optpfor", "opt", "block_qmx"])
