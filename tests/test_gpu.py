@@ -394,3 +394,44 @@ def test_block_profile_and_hybrid_optimiser(coll, queries, images):
         assert np.array_equal(dd, coll.lists[t][0]) and np.array_equal(ff, coll.lists[t][1])
     for op in ALL_OPS:
         _check_against_oracle(g2, o2, op, queries)
+
+
+def test_gov2_scale_properties(built_lib):
+    """BASELINE metric scale (25 M docs; the 8192 most frequent terms of the GOV2-scale synthetic collection, ~1 B
+    postings): size-independent properties over a 1024-query batch + the oracle on a 48-query sample."""
+    p = d.SynthParams(seed=0xD5210004, num_docs=25_000_000, num_terms=8192, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
+                      clustered_every=4)
+    img, wand, postings = d.synth_build(p, "block_optpfor")
+    assert postings > 900_000_000
+    queries = d.synth_queries(0x51E21, p.num_terms, 1024)
+    gidx = d.Index("block_optpfor", img, wand)
+    and_count, _, _, _ = gidx.query_batch("and", queries)
+    rc, rtopk, rlen, _ = gidx.query_batch("ranked_and", queries, k=10)
+    # ranked_and returns min(k, |AND|) scores, sorted descending; a second run is identical
+    assert np.array_equal(rlen, np.minimum(and_count, 10).astype(np.uint32)) and np.array_equal(rc, rlen)
+    for i in range(len(queries)):
+        assert np.all(np.diff(rtopk[i, :rlen[i]]) <= 0)
+    rc2, rtopk2, rlen2, _ = gidx.query_batch("ranked_and", queries, k=10)
+    assert np.array_equal(rtopk, rtopk2) and np.array_equal(rlen, rlen2)
+    # or >= and; wand == maxscore == ranked_or (test_ranked_queries.cpp:39-57), and they dominate ranked_and
+    or_count, _, _, _ = gidx.query_batch("or", queries[:256])
+    assert np.all(or_count >= and_count[:256])
+    _, wt, wl, _ = gidx.query_batch("wand", queries, k=10)
+    _, mt, ml, _ = gidx.query_batch("maxscore", queries, k=10)
+    _, ot, ol, _ = gidx.query_batch("ranked_or", queries[:256], k=10)
+    assert np.array_equal(wl, ml) and np.array_equal(wl[:256], ol)
+    f = np.isfinite(wt)
+    np.testing.assert_allclose(wt[f], mt[f], rtol=RTOL)
+    f = np.isfinite(ot)
+    np.testing.assert_allclose(wt[:256][f], ot[f], rtol=RTOL)
+    both = np.minimum(wl, rlen)
+    for i in range(len(queries)):
+        assert np.all(wt[i, :both[i]] >= rtopk[i, :both[i]] * (1 - RTOL))
+    # the oracle on a sample (shortest queries first would be cheap; take a spread)
+    sample = queries[::21][:48]
+    oidx = o.Index("block_optpfor", img, wand)
+    oc, otk, otl, _, _ = oidx.query_batch("ranked_and", sample, k=10)
+    idxs = list(range(0, len(queries), 21))[:48]
+    assert np.array_equal(rlen[idxs], otl)
+    f = np.isfinite(otk)
+    np.testing.assert_allclose(rtopk[idxs][f], otk[f], rtol=RTOL)
