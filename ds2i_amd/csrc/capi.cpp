@@ -491,7 +491,7 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
     // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
     const char* uf = std::getenv("DS2I_UNIT_FACTOR");
-    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : 8.0;
+    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : 16.0;
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = class_of(nt);
@@ -530,8 +530,8 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
             uint32_t parts = 1;
             // every part re-seeks its lists (the parts of a query share their pruning floor through q_floor), and the
             // many-list classes pay that per list: they want coarser parts than the one/two-list class (measured on
-            // the GOV2-scale batch: best at 4x the conjunctive granularity overall)
-            static const double disj_scale[NCLS] = {16.0, 4.0, 2.0, 2.0};
+            // the GOV2-scale batch)
+            static const double disj_scale[NCLS] = {8.0, 2.0, 1.0, 1.0};
             const double dtarget = std::max(48.0, all_cost / (unit_factor * disj_scale[c] * resident));
             if (nt && N > 1) parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));
             const uint32_t width = (N + parts - 1) / parts;
