@@ -379,6 +379,42 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
         v0 |= out[lane] << b;
         v1 |= out[lane + 64] << b;
         wave_sync();
+    } else if (nexc && nexc <= 64 && ew <= 64) {
+        // 33..64 exceptions (65..128 fields): the same scheme with two fields per lane (g and g + 64). The position
+        // deltas are fields [0, nexc), all in the first slot; the high part of exception e is field e + nexc.
+        const uint16_t* tab = s16_tab(exc);
+        const uint32_t word = lane < ew ? (fast ? blk[1 + lane] : w.rd32(p + 4 + 4 * lane)) : 0u;
+        const uint32_t cnt = lane < ew ? (uint32_t)tab[448u + (word >> 28)] : 0u;
+        const uint32_t off = wave_incl_scan(cnt) - cnt;
+        out[lane] = 0;
+        out[lane + 64] = 0;
+        if (lane < ew && off < 128u) out[off] = 1u;
+        wave_sync();
+        const bool st0 = out[lane] != 0u, st1 = out[lane + 64] != 0u;
+        const uint64_t m0 = ballot(st0), m1 = ballot(st1);
+        const uint32_t below0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        const uint32_t below1 = (uint32_t)__builtin_popcountll(m0) +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        const uint32_t widx0 = below0 - (st0 ? 0u : 1u), widx1 = below1 - (st1 ? 0u : 1u);
+        const uint32_t wword0 = (uint32_t)__shfl((int)word, (int)(widx0 & 63u)), woff0 = (uint32_t)__shfl((int)off, (int)(widx0 & 63u));
+        const uint32_t wword1 = (uint32_t)__shfl((int)word, (int)(widx1 & 63u)), woff1 = (uint32_t)__shfl((int)off, (int)(widx1 & 63u));
+        const uint32_t k0 = lane - woff0, k1 = lane + 64u - woff1;
+        const uint32_t fe0 = tab[k0 < 28u ? (wword0 >> 28) * 28u + k0 : 0u];
+        const uint32_t fe1 = tab[(lane + 64u < 2 * nexc && k1 < 28u) ? (wword1 >> 28) * 28u + k1 : 0u];
+        const uint32_t val0 = __builtin_amdgcn_ubfe(wword0, fe0 & 0xFFu, fe0 >> 8);
+        const uint32_t val1 = __builtin_amdgcn_ubfe(wword1, fe1 & 0xFFu, fe1 >> 8);
+        const uint32_t hidx = lane + nexc; // field holding the high part of exception `lane`
+        const uint32_t h0 = (uint32_t)__shfl((int)val0, (int)(hidx & 63u)), h1 = (uint32_t)__shfl((int)val1, (int)(hidx & 63u));
+        const uint32_t hi = hidx < 64u ? h0 : h1;
+        const uint32_t lpos = wave_incl_scan(lane < nexc ? val0 + 1u : 0u) - 1u;
+        wave_sync();
+        out[lane] = 0;
+        out[lane + 64] = 0;
+        if (lane < nexc && lpos < 128u) out[lpos] = hi + 1u;
+        wave_sync();
+        v0 |= out[lane] << b;
+        v1 |= out[lane + 64] << b;
+        wave_sync();
     } else if (nexc) {
         const uint32_t need = 2 * nexc;
         if (ew <= 64) {

@@ -435,3 +435,32 @@ def test_gov2_scale_properties(built_lib):
     assert np.array_equal(rlen[idxs], otl)
     f = np.isfinite(otk)
     np.testing.assert_allclose(rtopk[idxs][f], otk[f], rtol=RTOL)
+
+
+@pytest.mark.parametrize("codec", ["block_optpfor", "block_mixed"])
+def test_optpfor_exception_count_sweep(built_lib, codec):
+    """One block per exception count 0..110: exercises the three OptPFor exception paths of the device decoder
+    (<= 32 exceptions in registers, 33..64 two fields per lane, > 64 batched through LDS), in docs gaps and freqs."""
+    rng = np.random.default_rng(99)
+    nblk = 111
+    freqs = rng.integers(1, 5, 128 * nblk).astype(np.uint32)
+    gaps = rng.integers(1, 5, 128 * nblk).astype(np.uint64)
+    for k in range(nblk):
+        pos = rng.choice(128, k, replace=False) + 128 * k
+        freqs[pos] = 1 + (1 << 10) + rng.integers(0, 1 << 9, k).astype(np.uint32)
+        pos = rng.choice(128, k, replace=False) + 128 * k
+        gaps[pos] = 1 + (1 << 9) + rng.integers(0, 1 << 8, k)
+    docs = (np.cumsum(gaps) - 1).astype(np.uint32)
+    N = int(docs[-1]) + 10
+    other = np.sort(rng.choice(N, 3000, replace=False)).astype(np.uint32)
+    lists = [(docs, freqs), (other, rng.integers(1, 9, len(other)).astype(np.uint32))]
+    img = d.build_index(codec, N, lists)
+    if codec == "block_optpfor":  # the sweep really produces the exception counts it is meant to
+        blob = d.encode_block(codec, (freqs[128 * 50:128 * 51] - 1).astype(np.uint32))
+        assert ((int.from_bytes(blob[:4], "little") >> 16) & 0x3FF) == 50
+    gidx = d.Index(codec, img)
+    oidx = o.Index(codec, img)
+    dd, ff = gidx[0]
+    assert np.array_equal(dd, docs) and np.array_equal(ff, freqs)
+    for op in ("and", "and_freq", "or_freq"):
+        _check_against_oracle(gidx, oidx, op, [[0, 1], [0], [1, 0]])
