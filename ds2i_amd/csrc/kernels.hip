@@ -642,10 +642,12 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         auto maxw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_MAXW)); };
         auto qw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_QW)); };
         uint32_t non_ess = 0;
-        auto update_non_ess = [&]() { if (MODE == 0) while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
+        auto update_non_ess = [&]() __attribute__((always_inline)) { if (MODE == 0) while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
         update_non_ess();
         // positions list x on the first block whose block_max >= d; false when the list has no posting >= d
-        auto seek = [&](uint32_t x, uint32_t d, bool may_go_back) -> bool {
+        // always_inline: left to the inliner, the lambda (it contains the block decoder) becomes a real call once the
+        // decoder grows, and the call ABI costs this kernel half its throughput
+        auto seek = [&](uint32_t x, uint32_t d, bool may_go_back) __attribute__((always_inline)) -> bool {
             if (d >= uniform(L.nomore[x])) return false;
             const uint32_t cur = cx.m(x, M_CUR);
             uint32_t from;
@@ -666,7 +668,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             return true;
         };
         const bool shared_floor = MODE == 0 && !whole && a.q_floor;
-        auto adopt_floor = [&]() { // another part of this query may have raised the bar
+        auto adopt_floor = [&]() __attribute__((always_inline)) { // another part of this query may have raised the bar
             const float f = __uint_as_float(uniform(__hip_atomic_load(a.q_floor + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
             if (f > tk.floor) { tk.floor = f; update_non_ess(); }
         };

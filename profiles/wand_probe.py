@@ -7,6 +7,7 @@ idx = d.Index("block_optpfor", img, wand)
 queries = d.synth_queries(0x51E21, p.num_terms, 4096)
 for op in ("wand", "maxscore"):
     t0 = time.perf_counter(); b = d.Batch(idx, op, queries, k=10); t1 = time.perf_counter()
+    if os.environ.get("PROBE_UNINSTRUMENTED"): b.set_instrumented(False)
     print(op, "prepare %.1f ms" % (1e3 * (t1 - t0)))
     for i in range(3):
         t0 = time.perf_counter(); st = b.run(); t1 = time.perf_counter()

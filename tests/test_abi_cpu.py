@@ -51,3 +51,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "liboracle" not in txt and '"oracle/' not in txt, f
+
+
+def test_device_code_has_no_function_calls(built_lib, tmp_path):
+    """Every device function is meant to be inlined into its kernel: a lambda the inliner leaves as a real call costs
+    the call ABI (register save / restore) on the hot path -- it once halved the disjunctive kernel's throughput."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    fat, elf = str(tmp_path / "fat.bin"), str(tmp_path / "dev.elf")
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, ds2i_amd.library_path(), os.devnull])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
+    dis = subprocess.run([tools[2], "-d", "--no-show-raw-insn", elf], capture_output=True, text=True, check=True).stdout
+    assert "k_conjunctive" in dis and "k_disjunctive" in dis
+    assert dis.count("s_swappc_b64") == 0 and dis.count("s_call_b64") == 0
