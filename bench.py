@@ -259,11 +259,16 @@ def main():
         src = "oracle-counted reference traversal (A_skip)"
     achieved = a_skip_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None  # PMC counters cannot be collected inside this process: taken from the committed rocprofv3 passes
+    valu_issue = None
     tj = args.traffic_json or os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % wl)
     if os.path.exists(tj) and args.op == "ranked_and" and args.codec == "block_optpfor" and dom == 0:
-        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+        tjson = json.load(open(tj))
+        traffic = tjson.get("hbm_bytes_per_launch")
+        # the binding resource of this path is vector-instruction issue, not bandwidth: carry the
+        # measured figure of the committed counter pass next to the HBM roofline
+        valu_issue = (tjson.get("valu_issue") or {}).get("frac")
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_issue_frac": valu_issue,
                        "kernel": "%s<%s,TMAX=%d>" % ("k_conjunctive" if args.op in ("and", "and_freq", "ranked_and") else "k_daat",
                                                      args.op, (2, 4, 8, 16)[dom]),
                        "kernel_ms": dom_ms, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
