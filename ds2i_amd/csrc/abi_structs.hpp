@@ -71,6 +71,7 @@ struct BatchArgs {
     // k-th score of the union is >= the k-th score of any part
     unsigned int* q_floor;     // nq or null
     unsigned int* block_profile; // block indexes: 2 counters per block of the index (docs / freqs decodes) or null
+    const void* skip;            // block indexes: interleaved {block_max, block end offset} per block (uint2) or null
     Stats* stats;
 };
 

@@ -74,8 +74,9 @@ struct ds2i_hip_index {
     std::vector<uint32_t> list_n;
     std::vector<uint32_t> list_nb;  // blocks (block indexes) / chunks (opt index) per list
     std::vector<uint64_t> list_aux0, list_aux1; // opt index: docs / freqs sequence bit offsets
-    std::vector<uint64_t> list_blk_base;        // block indexes: blocks of all preceding lists (access profile)
+    std::vector<uint64_t> list_blk_base;        // block indexes: blocks of all preceding lists (access profile, skip table)
     uint64_t total_blocks = 0;
+    uint8_t* d_skip = nullptr;                  // block indexes: interleaved {block_max, block end offset} per block
     uint8_t* d_bits0 = nullptr;     // opt index: docs bit vector
     uint8_t* d_bits1 = nullptr;     // opt index: freqs bit vector
     uint64_t extra_bytes = 0;
@@ -142,6 +143,7 @@ void free_index(ds2i_hip_index* x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
     if (x->d_arena) (void)hipFree(x->d_arena);
+    if (x->d_skip) (void)hipFree(x->d_skip);
     if (x->d_norm_lens) (void)hipFree(x->d_norm_lens);
     if (x->d_bits0) (void)hipFree(x->d_bits0);
     if (x->d_bits1) (void)hipFree(x->d_bits1);
@@ -295,6 +297,38 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     x->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_OK(hipMalloc((void**)&x->d_arena, x->arena_bytes));
     HIP_OK(hipMemcpy(x->d_arena, arena.data(), x->arena_bytes, hipMemcpyHostToDevice));
+    if (!freq_layout && x->total_blocks) {
+        // Interleaved skip table (auxiliary, like the list-offset table): entry b of a list = {block_max[b], byte offset
+        // where block b ends inside the list's blocks area}. The probe of find_block_info() that locates a block then
+        // also delivers its four table words, which saves the dependent table load of a non-sequential decode.
+        std::vector<uint32_t> skip;
+        try {
+            skip.resize(2 * x->total_blocks);
+        } catch (std::bad_alloc const&) {
+            return ds2i_set_error(DS2I_ENOMEM, "out of host memory staging the skip table");
+        }
+        for (uint64_t t = 0; t < V; ++t) {
+            const uint8_t* lp = view.lists + view.list_offsets[t];
+            const uint64_t len = view.list_offsets[t + 1] - view.list_offsets[t];
+            uint32_t n = 0;
+            const uint32_t vl = host_vbyte(lp, len, n);
+            const uint64_t nb = x->list_nb[t];
+            const uint8_t* maxs = lp + vl;
+            const uint8_t* eps = maxs + 4 * nb;
+            const uint64_t data_len = len - vl - (8 * nb - 4);
+            uint32_t* out = skip.data() + 2 * x->list_blk_base[t];
+            for (uint64_t b = 0; b < nb; ++b) {
+                uint32_t mx, ep = (uint32_t)data_len;
+                std::memcpy(&mx, maxs + 4 * b, 4);
+                if (b + 1 < nb) std::memcpy(&ep, eps + 4 * b, 4);
+                out[2 * b] = mx;
+                out[2 * b + 1] = ep;
+            }
+        }
+        HIP_OK(hipMalloc((void**)&x->d_skip, 8 * x->total_blocks));
+        HIP_OK(hipMemcpy(x->d_skip, skip.data(), 8 * x->total_blocks, hipMemcpyHostToDevice));
+        x->extra_bytes += 8 * x->total_blocks;
+    }
     if (freq_layout) {
         const uint64_t b0 = oview.docs_bits.nbytes, b1 = oview.freqs_bits.nbytes;
         HIP_OK(hipMalloc((void**)&x->d_bits0, b0 + 4096));
@@ -673,6 +707,7 @@ int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             a.seed_len = b->seed ? b->seed->d_topk_len : nullptr;
             a.q_floor = b->d_qfloor;
             a.block_profile = b->instrument ? b->d_prof : nullptr;
+            a.skip = std::getenv("DS2I_NO_SKIPTAB") ? nullptr : idx->d_skip;
             a.stats = b->instrument ? idx->d_stats + c : nullptr;
             HIP_OK(ds2i_launch_batch(b->op, c, &a, b->ncls[c], s));
         }

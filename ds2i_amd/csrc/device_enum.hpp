@@ -39,6 +39,7 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
 //           v_readfirstlane, and the compiler can CSE the pointer arithmetic.
 struct MetaLds {
     static constexpr int NPF = 0; // prefetch slots
+    static constexpr bool SKIPTAB = true; // use the interleaved skip table (find_block_info)
     uint32_t* p;
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return uniform(p[s * M_WORDS + f]); }
     DS2I_DEV void set(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) p[s * M_WORDS + f] = v; }
@@ -48,6 +49,9 @@ struct MetaReg {
     // prefetch slots: both lists of the <=2-list kernel; none with 3-4 lists, where the extra VGPRs cost more
     // occupancy than the prefetch wins (measured)
     static constexpr int NPF = TMAX <= 2 ? TMAX : 0;
+    // the interleaved skip table saves the table round trip of a non-sequential decode; the <=2-list kernel decodes
+    // sequentially through its prefetch and cannot afford the extra state (72 SGPRs)
+    static constexpr bool SKIPTAB = TMAX > 2;
     // software prefetch of each list's NEXT sequential block (issued right after a block is decoded, consumed by the
     // next decode of that list if it is indeed block+1): table words + 512 B of block bytes, per lane
     uint32_t pf_blk[NPF], pf_tab[NPF], pf_w0[NPF], pf_w1[NPF];
@@ -77,6 +81,7 @@ struct CtxT {
     int codec;
     uint32_t num_docs;
     unsigned int* block_profile; // 2 counters per block (docs, freqs decodes) or null; instrumented kernels only
+    const uint2* skip;           // block indexes: {block_max[b], end offset of block b} per block of the index, or null
     DS2I_DEV bool is_pef() const { return CODEC_T == CODEC_PEF || (CODEC_T < 0 && codec == CODEC_PEF); }
     // per-wave statistics (wave-uniform). Like the reference's block_profiler they are a compile-time option
     // (block_posting_list.hpp:316-318 `if (Profile)`): the counters live in SGPRs, and the <=2-list kernel at
@@ -171,7 +176,11 @@ struct CtxT {
         s_bytes += ((bcast(ev, PC_SPANS) >> 16) + cnt * ((packed >> 18) & 63u) + 7) >> 3;
     }
 
-    DS2I_DEV void decode_docs(uint32_t s, uint32_t b) {
+    // table words of one block: byte offset of its start / of the next block's start (relative to the blocks area),
+    // its block_max and the first doc-id it can hold
+    struct BlockInfo { uint32_t ep, next_ep, bmax, base; };
+
+    DS2I_DEV void decode_docs(uint32_t s, uint32_t b, const BlockInfo* pre = nullptr) {
         PT_BEGIN(*this);
         if (is_pef()) {
             decode_docs_pef(s, b);
@@ -203,6 +212,17 @@ struct CtxT {
                 bmax = bcast(meta.pf_tab[s], 1);
                 next_ep = bcast(meta.pf_tab[s], 3);
             }
+        }
+        if (!have && pre) { // the caller's find_block_info() already fetched the table words with its probe
+            have = true;
+            ep = pre->ep;
+            bmax = pre->bmax;
+            base = pre->base;
+            next_ep = pre->next_ep;
+            uint32_t hint = next_ep - ep;
+            if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+            p = data + ep;
+            win.load(p, hint);
         }
         if (!have) {
         // Table words come from ONE unconditional load with a per-lane address (lane 0: endpoint[b-1], 1: block_max[b],
@@ -354,7 +374,7 @@ struct CtxT {
         setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
         setm(s, M_BMAX, 0);
         setm(s, M_FDEC, 0);
-        if (STATS) setm(s, M_PBASE, (uint32_t)t.aux0);
+        if (STATS || META::SKIPTAB) setm(s, M_PBASE, (uint32_t)t.aux0);
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
@@ -403,6 +423,57 @@ struct CtxT {
         if (!hit) return nb;
         uint32_t blk = lo + (uint32_t)__builtin_ctzll(hit);
         return blk < hi ? blk : nb;
+    }
+
+    // find_block over the interleaved skip table: the probe that locates the block also returns its table words (the
+    // entry of the block before it rides in the neighbouring lane), so the decode that follows needs no table load.
+    // Same result as find_block(); `info` is valid iff the returned block < nb.
+    DS2I_DEV uint32_t find_block_info(uint32_t s, uint32_t from, uint32_t lb, BlockInfo& info) {
+        const uint32_t nb = m(s, M_NB);
+        const uint32_t lane = lane_id();
+        if (from >= nb) return nb;
+        const uint2* tab = skip + m(s, M_PBASE);
+        auto finish = [&](uint2 e, uint32_t first_idx, uint64_t hit) -> uint32_t { // lane j holds entry first_idx + j
+            const uint32_t f = (uint32_t)__builtin_ctzll(hit);
+            const uint32_t blk = first_idx + f;
+            info.bmax = bcast(e.x, f);
+            info.next_ep = bcast(e.y, f);
+            const uint32_t pf = f ? f - 1 : 0;
+            const uint32_t pmax = bcast(e.x, pf), pend = bcast(e.y, pf);
+            info.base = blk ? pmax + 1u : 0u;
+            info.ep = blk ? pend : 0u;
+            return blk;
+        };
+        {   // entries from-1 .. from+62 (lane 0 = the block before `from`, never a candidate itself)
+            const uint32_t first = from ? from - 1 : 0;
+            const uint32_t idx = first + lane;
+            uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+            if (idx < nb) e = tab[idx];
+            uint64_t hit = ballot(idx >= from && idx < nb && e.x >= lb);
+            if (hit) return finish(e, first, hit);
+            if (first + 64 >= nb) return nb;
+        }
+        uint32_t lo = (from ? from - 1 : 0) + 64, hi = nb; // answer in [lo, hi) or none
+        while (hi - lo > 63) {
+            const uint32_t stride = (hi - lo + 63) / 64;
+            uint32_t idx = lo + (lane + 1) * stride - 1;
+            if (idx >= hi) idx = hi - 1;
+            const uint32_t v = tab[idx].x;
+            uint64_t hit = ballot(v >= lb);
+            if (!hit) return nb;
+            const uint32_t f = (uint32_t)__builtin_ctzll(hit);
+            const uint32_t nhi = lo + (f + 1) * stride;
+            hi = nhi < hi ? nhi : hi;
+            lo = lo + f * stride;
+        }
+        // <= 63 candidates left: probe lo-1 .. (lo >= 64 here, so lo-1 exists)
+        const uint32_t first = lo - 1;
+        const uint32_t idx = first + lane;
+        uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+        if (idx < hi) e = tab[idx];
+        uint64_t hit = ballot(idx >= lo && idx < hi && e.x >= lb);
+        if (!hit) return nb;
+        return finish(e, first, hit);
     }
 
     // ---- next_geq (block_posting_list.hpp:124-146)

@@ -53,6 +53,7 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
     c.codec = a.codec;
     c.num_docs = a.num_docs;
     c.block_profile = a.block_profile;
+    c.skip = (const uint2*)a.skip;
     c.init_stats();
     return c;
 }
@@ -147,11 +148,13 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
             if (lo > cx.m(0, M_BMAX)) {
                 uint32_t cur = cx.m(0, M_CUR);
                 uint32_t blk;
-                { PT_BEGIN(cx); blk = cx.find_block(0, cur + 1, lo); PT_END(cx, PH_FIND); }
+                typename decltype(cx)::BlockInfo bi;
+                const bool tabbed = META::SKIPTAB && !cx.is_pef() && cx.skip;
+                { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(0, cur + 1, lo, bi) : cx.find_block(0, cur + 1, lo); PT_END(cx, PH_FIND); }
                 if (blk >= u.blk_end) break;
                 cx.s_bm_examined += blk - cur;
                 cx.s_bytes += 4ull * (blk - cur);
-                cx.decode_docs(0, blk);
+                cx.decode_docs(0, blk, tabbed ? &bi : nullptr);
             }
             uint32_t hi = cx.m(0, M_BMAX);
             const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
@@ -164,7 +167,9 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                 if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
                     uint32_t cur = cx.m(i, M_CUR);
                     uint32_t blk;
-                    { PT_BEGIN(cx); blk = cx.find_block(i, cur + 1, amin); PT_END(cx, PH_FIND); }
+                    typename decltype(cx)::BlockInfo bi;
+                    const bool tabbed = META::SKIPTAB && !cx.is_pef() && cx.skip;
+                    { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(i, cur + 1, amin, bi) : cx.find_block(i, cur + 1, amin); PT_END(cx, PH_FIND); }
                     if (blk >= cx.m(i, M_NB)) { // list i has nothing >= amin: no further match exists
                         cx.s_bm_examined += 1;
                         cx.s_bytes += 4;
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                     // a lazily bound list is positioned by one 64-ary search, not a scan from block 0
                     cx.s_bm_examined += (cur == 0xFFFFFFFFu) ? 1u : blk - cur;
                     cx.s_bytes += 4ull * ((cur == 0xFFFFFFFFu) ? 1u : blk - cur);
-                    cx.decode_docs(i, blk);
+                    cx.decode_docs(i, blk, tabbed ? &bi : nullptr);
                 }
                 PT_BEGIN(cx);
                 uint32_t bm = cx.m(i, M_BMAX);
@@ -656,7 +661,9 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             else if (may_go_back && d < uniform(L.docs[x][0])) from = 0; // a non-essential list may have been moved ahead
             else return true;
             uint32_t blk;
-            { PT_BEGIN(cx); blk = cx.find_block(x, from, d); PT_END(cx, PH_FIND); }
+            typename decltype(cx)::BlockInfo bi;
+            const bool tabbed = !cx.is_pef() && cx.skip;
+            { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(x, from, d, bi) : cx.find_block(x, from, d); PT_END(cx, PH_FIND); }
             if (blk >= cx.m(x, M_NB)) {
                 if (lane == 0) L.nomore[x] = d;
                 wave_sync();
@@ -664,7 +671,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             }
             cx.s_bm_examined += 1;
             cx.s_bytes += 4;
-            if (blk != cur) cx.decode_docs(x, blk);
+            if (blk != cur) cx.decode_docs(x, blk, tabbed ? &bi : nullptr);
             return true;
         };
         const bool shared_floor = MODE == 0 && !whole && a.q_floor;
