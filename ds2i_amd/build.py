@@ -11,7 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libds2i_hip.so")
 ARCH = "gfx950"
 
-DEVICE_SRCS = ["kernels.hip"]
+# kernels.hip is compiled five times: once per list-count class (-DDS2I_TU_TMAX=n: the query kernels of that class)
+# and once for everything else; the translation units are built in parallel
+DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16)] + [("kernels.hip", "kernels.hip", [])]
 HOST_SRCS = ["capi.cpp", "capi_build.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
@@ -38,18 +40,26 @@ def build(verbose=False, force=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
-    objs = []
-    for src in DEVICE_SRCS + HOST_SRCS:
+    objs, jobs = [], []
+    for src, name, defs in DEVICE_UNITS + [(h, h, []) for h in HOST_SRCS]:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(objdir, src + ".o")
+        obj = os.path.join(objdir, name + ".o")
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):
-            cmd = [hipcc, "--offload-arch=" + ARCH] + COMMON + extra + ["-c", sp, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH] + COMMON + extra + defs + ["-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd[1:1] = ["-x", "hip"]
+            jobs.append(cmd)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
     if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
         if verbose:

@@ -903,8 +903,13 @@ struct Batch {
     BatchArgs a;
 };
 
+// The file is compiled once per list-count class (-DDS2I_TU_TMAX=2|4|8|16: only launch_t<TMAX> and the kernels it
+// instantiates) and once without the macro (everything else): five translation units that build.py compiles in
+// parallel -- the kernel templates are by far the slowest part of the build.
 template <int TMAX>
-static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
+hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
+#if defined(DS2I_TU_TMAX)
+{
     dim3 g(grid), b(64);
     switch (op) {
     // the conjunctive kernels are specialised for block_optpfor (the benchmark codec), the freq_index family and
@@ -962,9 +967,18 @@ static hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_
     }
     return hipGetLastError();
 }
+template hipError_t launch_t<DS2I_TU_TMAX>(int, const BatchArgs&, unsigned, hipStream_t);
+#else
+;
+extern template hipError_t launch_t<2>(int, const BatchArgs&, unsigned, hipStream_t);
+extern template hipError_t launch_t<4>(int, const BatchArgs&, unsigned, hipStream_t);
+extern template hipError_t launch_t<8>(int, const BatchArgs&, unsigned, hipStream_t);
+extern template hipError_t launch_t<16>(int, const BatchArgs&, unsigned, hipStream_t);
+#endif
 
 } // namespace ds2i_launch
 
+#if !defined(DS2I_TU_TMAX)
 extern "C" {
 
 // tmax_class: 0 -> TMAX 2, 1 -> TMAX 4, 2 -> TMAX 8, 3 -> TMAX 16 (LDS footprint per wave grows with TMAX)
@@ -1011,3 +1025,4 @@ hipError_t ds2i_launch_calib_read(const uint32_t* base, unsigned long long ndw, 
 size_t ds2i_sizeof_batch_args() { return sizeof(BatchArgs); }
 size_t ds2i_sizeof_decode_args() { return sizeof(DecodeArgs); }
 }
+#endif // !DS2I_TU_TMAX

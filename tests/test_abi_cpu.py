@@ -62,10 +62,20 @@ def test_device_code_has_no_function_calls(built_lib, tmp_path):
     tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
     if not all(os.path.exists(t) for t in tools):
         pytest.skip("ROCm LLVM tools not found")
-    fat, elf = str(tmp_path / "fat.bin"), str(tmp_path / "dev.elf")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, ds2i_amd.library_path(), os.devnull])
-    subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
-    dis = subprocess.run([tools[2], "-d", "--no-show-raw-insn", elf], capture_output=True, text=True, check=True).stdout
-    assert "k_conjunctive" in dis and "k_disjunctive" in dis
-    assert dis.count("s_swappc_b64") == 0 and dis.count("s_call_b64") == 0
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert len(starts) >= 5  # one code object per translation unit of kernels.hip (ds2i_amd/build.py)
+    seen = ""
+    for i, st in enumerate(starts):
+        part, elf = str(tmp_path / ("bundle%d.bin" % i)), str(tmp_path / ("dev%d.elf" % i))
+        open(part, "wb").write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
+        dis = subprocess.run([tools[2], "-d", "--no-show-raw-insn", elf], capture_output=True, text=True, check=True).stdout
+        assert dis.count("s_swappc_b64") == 0 and dis.count("s_call_b64") == 0, i
+        seen += "".join(sorted(set(re.findall(r"k_(?:conjunctive|disjunctive|daat|merge|decode_list)", dis))))
+    for k in ("k_conjunctive", "k_disjunctive", "k_daat", "k_merge", "k_decode_list"):
+        assert k in seen
