@@ -464,3 +464,32 @@ def test_optpfor_exception_count_sweep(built_lib, codec):
     assert np.array_equal(dd, docs) and np.array_equal(ff, freqs)
     for op in ("and", "and_freq", "or_freq"):
         _check_against_oracle(gidx, oidx, op, [[0, 1], [0], [1, 0]])
+
+
+def test_bench_contract(built_lib):
+    """bench.py prints ONE JSON line with the contract's keys (driver contract + roofline + cpu_baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["unit"] == "queries/s"
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert "workload" in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
