@@ -3,13 +3,16 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run with one rank per GPU. A "step" = one pass of the hot path (ranked_and, k=10)
-over one 4096-query batch per GPU, with the index, the prepared query terms and the output buffers
-already resident in HBM. Rank 0 prints ONE JSON line.
+over one FRESH 4096-query batch per GPU, end to end through the public pipelined ABI (SURVEY.md §8(d)
+"Timing": host-side query normalisation and planning + H2D of the terms + kernels + D2H of the results;
+only the index is resident in HBM). K distinct batches are timed, `--depth` of them in flight.
+Rank 0 prints ONE JSON line.
 
   value        whole-job queries/s = (queries all ranks processed) / max-over-ranks wall time
-  roofline     dominant kernel (k_conjunctive<ranked>, <=4-term class): algorithmic bytes (the reference
-               traversal's A_skip, SURVEY.md §8(d), counted by the instrumented oracle) / that kernel's
-               mean hipEvent duration, against the 8 TB/s HBM peak
+  kernel_resident_qps  the same kernels over ONE prepared batch re-run K times (round 1's figure), beside it
+  roofline     the class kernel with the most GPU time: algorithmic bytes (the reference traversal's A_skip,
+               SURVEY.md §8(d), counted by the instrumented oracle) / that kernel's mean hipEvent duration
+               over the launches of the timed region, against the 8 TB/s HBM peak
   cpu_baseline the oracle (CPU restatement of the reference path, oracle/) driven like op_perftest
                (queries.cpp:13-62) on ONE host core over a bounded sample of the same batch -- the only
                place this file touches oracle/.
@@ -35,7 +38,7 @@ WORKLOADS = {
     "cw09": dict(num_docs=50_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
                  seed=0xD5210005, label="synthetic ClueWeb09-B-scale 50M-doc Zipf (configs[4])"),
 }
-NCLS = 4  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16
+NCLS = 5  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16, more
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -55,6 +58,10 @@ def main():
     ap.add_argument("--codec", default="block_optpfor")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle", action="store_true", help="skip every oracle leg (A_skip profile, parity sample, cpu baseline)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipelined timed region")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = every rank its own 4096-query batches; strong = one stream of batches cut into N slices")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 --pmc derived HBM bytes per launch (profiles/*.json)")
     args = ap.parse_args()
 
@@ -123,157 +130,256 @@ def main():
         log("built %s index: %d postings, %.1f MB, %.1fs" % (wl, postings, len(img) / 1e6, time.time() - t0))
     img = sh.share_bytes(dist, rank, img, f_idx)
     wand = sh.share_bytes(dist, rank, wand, f_wand)
-    # each rank: full index replica in its GPU's HBM, its own 4096-query batch (weak scaling, no collective)
-    queries = d.synth_queries(0x51E21 + rank, p.num_terms, args.batch)
+    # each rank: full index replica in its GPU's HBM; no data-path collective.
+    #   weak (default): every rank answers its own stream of 4096-query batches
+    #   strong: ONE stream of 4096-query batches for the whole job; rank r answers slice r of every batch
+    #           (sharding.query_slice) and rank 0 gathers the results (sharding.gather_concat)
+    nbatches = args.steps + args.warmup
+    strong = args.scaling == "strong"
+    all_queries = [d.synth_queries(0x51E21 + (0 if strong else 1000003 * rank) + 7919 * i, p.num_terms, args.batch) for i in range(nbatches)]
+    if strong:
+        lo_, hi_ = sh.query_slice(args.batch, rank, world)
+        my_queries = [q[lo_:hi_] for q in all_queries]
+    else:
+        my_queries = all_queries
+    flat = [d.flatten_queries(q) for q in my_queries]  # the query log is read before the clock starts (queries.cpp:74-88)
+    queries = all_queries[args.warmup]                  # first timed batch: oracle profile / cpu baseline / parity sample
+    t0 = time.time()
     idx = d.Index(args.codec, img, wand, device=local_rank)
-    batch = d.Batch(idx, args.op, queries, k=10)
+    log("index upload + upload-time tables (list offsets, skip table, block-max weights): %.2fs, %.1f MB in HBM"
+        % (time.time() - t0, idx.device_bytes() / 1e6))
+    pipe = d.Pipeline(idx, depth=args.depth)
 
-    # ---------------------------------------------------------------- timed region
-    # The timed steps run the uninstrumented kernels (statistics are a compile-time option, like the reference's
-    # block_profiler); one extra untimed, instrumented step afterwards collects the block / byte counters.
-    batch.set_instrumented(False)
-    for _ in range(args.warmup):
-        batch.run()
+    # ---------------------------------------------------------------- timed region (SURVEY.md §8(d) "Timing")
+    # Every step is a FRESH batch through the public pipelined ABI: host-side query normalisation + BM25 query weights
+    # + work-unit planning, H2D of the plan, kernels, merge, D2H of the results. Nothing is pre-staged. `depth` batches
+    # are in flight: the host plans batch i+1 while batch i runs. The kernels are the uninstrumented instantiations
+    # (statistics are a compile-time option, like the reference's block_profiler).
+    def run_stream(first, n, collect):
+        tickets, results, cls_ms = [], [], [[0.0, 0] for _ in range(NCLS)]
+        def reap():
+            r = pipe.wait(tickets.pop(0))
+            if collect:
+                results.append(r)
+                for c in range(NCLS):
+                    st, nqc = pipe.class_stats(c)
+                    if nqc:
+                        cls_ms[c][0] += st.kernel_ms
+                        cls_ms[c][1] += 1
+        for i in range(first, first + n):
+            if len(tickets) == args.depth:
+                reap()
+            tickets.append(pipe.submit(args.op, flat[i], k=10))
+        while tickets:
+            reap()
+        return results, cls_ms
+
+    run_stream(0, args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    kern_ms = [0.0] * NCLS
-    for _ in range(args.steps):
-        st = batch.run()
-        for c in range(NCLS):
-            kern_ms[c] += batch.class_stats(c)[0].kernel_ms
+    results, cls_ms = run_stream(args.warmup, args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sh.max_over_ranks(dist, elapsed)
-    count, topk, tlen, _ = batch.fetch()
+    count, topk, tlen = results[0]
+
+    # ---- untimed extras: kernel-resident rate (one prepared batch re-run, round-1's figure) and the instrumented pass
+    batch = d.Batch(idx, args.op, my_queries[args.warmup], k=10)
+    batch.set_instrumented(False)
+    batch.run()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    res_ms = [0.0] * NCLS
+    for _ in range(args.steps):
+        batch.run()
+        for c in range(NCLS):
+            res_ms[c] += batch.class_stats(c)[0].kernel_ms
+    torch.cuda.synchronize()
+    resident_s = (time.perf_counter() - t1) / args.steps
+    count_r, topk_r, tlen_r, _ = batch.fetch()
+    assert np.array_equal(count, count_r) and np.array_equal(tlen, tlen_r) and np.array_equal(topk, topk_r), \
+        "pipelined / prepared-batch results disagree"
     batch.set_instrumented(True)
     batch.run()
     count_i, topk_i, tlen_i, _ = batch.fetch()
     assert np.array_equal(count, count_i) and np.array_equal(tlen, tlen_i), "instrumented / uninstrumented kernels disagree"
+    if strong:  # the gathered answer of the first timed batch must be the whole batch, in order
+        g_count = sh.gather_concat(dist, rank, world, count)
+        g_topk = sh.gather_concat(dist, rank, world, topk)
+        assert g_count.shape[0] == args.batch and g_topk.shape[0] == args.batch
+        count, topk, tlen = g_count, g_topk, sh.gather_concat(dist, rank, world, tlen)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_q = args.batch * world * args.steps
+    per_rank_q = (hi_ - lo_) if strong else args.batch
+    total_q = (args.batch if strong else args.batch * world) * args.steps
     qps = total_q / elapsed
     cls_stats = [batch.class_stats(c) for c in range(NCLS)]
-    dom = max(range(NCLS), key=lambda c: cls_stats[c][0].algorithmic_bytes)
+    mean_ms = [cls_ms[c][0] / cls_ms[c][1] if cls_ms[c][1] else 0.0 for c in range(NCLS)]
+    dom = max(range(NCLS), key=lambda c: cls_ms[c][0])  # provisional: re-chosen below by algorithmic bytes when the oracle ran
     for c in range(NCLS):
-        log("class %d: %d queries, kernel %.3f ms/step, %s" % (c, cls_stats[c][1], kern_ms[c] / args.steps, cls_stats[c][0].as_dict()))
+        log("class %d: %d queries, kernel %.3f ms/launch in the pipelined region (%.3f ms alone), %s"
+            % (c, cls_stats[c][1], mean_ms[c], res_ms[c] / args.steps, cls_stats[c][0].as_dict()))
         pc = batch.phase_cycles(c)
         if pc["total"]:
             log("   phase cycles (diagnostic build): " + ", ".join("%s %.1f%%" % (k, 100.0 * v / pc["total"]) for k, v in pc.items()))
-    dom_ms = kern_ms[dom] / args.steps
+    dom_ms = mean_ms[dom]
     out = {
         "metric": "queries/sec (%s, %s)" % (args.op, args.codec), "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "mean_us_per_query": 1e6 * elapsed / (args.batch * args.steps),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+        "mean_us_per_query": 1e6 / qps,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+        "timing": "end-to-end over %d distinct batches through ds2i_hip_pipeline_submit/wait (host planning + H2D + kernels + D2H), "
+                  "%d in flight" % (args.steps, args.depth),
+        "kernel_resident_qps": per_rank_q * world / resident_s,  # one prepared batch re-run (rank 0's rate x ranks)
+        "end_to_end_over_resident": qps / (per_rank_q * world / resident_s),
         "config": {"workload": "%s, %s, %s, batch=%d" % (W["label"], args.codec, args.op, args.batch), "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
-                   "batch_per_gpu": args.batch, "k": 10, "parallelism": "query-batch sharding x%d, index replicated" % world},
+                   "batch_per_gpu": per_rank_q, "k": 10, "parallelism": "query-batch sharding x%d (%s), index replicated" % (world, args.scaling)},
     }
 
-    # ---------------------------------------------------------------- cpu baseline + algorithmic bytes (oracle; rank 0 only)
-    a_skip_dom = None
+    # ---------------------------------------------------------------- oracle legs (rank 0 only; the only place this file touches oracle/)
+    cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3 if n <= 16 else 4
+    nterms = [len(set(q)) for q in queries]
+    a_skip_q = [None] * NCLS  # reference-traversal bytes per query of each class (SURVEY.md §8(d) A_skip)
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_oracle:
         import oracle as o
         try:
-            import tempfile
             opath = o.build(native=True, out=os.path.join(tempfile.gettempdir(), tag + "_oracle.so"))  # -O3 -march=native here
         except Exception as e:  # no compiler on the box: use the prebuilt generic library
             log("native oracle build failed (%s); using prebuilt liboracle.so" % e)
             opath = None
         oidx = o.Index(args.codec, img, wand, libpath=opath)
-        nterms = [len(set(q)) for q in queries]
-        cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3
+        # (1) algorithmic bytes: the instrumented oracle (Profile=true equivalent) over the first timed batch, per class
         cls_q = [[q for q, n in zip(queries, nterms) if cls_of(n) == c] for c in range(NCLS)]
         t0 = time.time()
         prof = [oidx.query_batch(args.op, cq, k=10, profile=True)[4] if cq else None for cq in cls_q]
         log("oracle profile pass (reference traversal A_skip): %.1fs" % (time.time() - t0))
-        a_skip_dom = prof[dom]["algorithmic_bytes"] if prof[dom] else 0
+        a_skip_q = [prof[c]["algorithmic_bytes"] / len(cls_q[c]) if prof[c] else None for c in range(NCLS)]
         out["a_skip_bytes_per_step"] = sum(pr["algorithmic_bytes"] for pr in prof if pr)
-        # parity spot check in the same run (count + top-k within 1e-5) on the sample below
+        # (2) parity spot check in the same run (count + top-k within 1e-5) on the sample the CPU baseline is timed on
         probe = queries[:64]
         t0 = time.time()
         oidx.query_batch(args.op, probe, k=10)
         per_q = (time.time() - t0) / len(probe)
         nsample = int(max(64, min(len(queries), 15.0 / (3 * per_q))))
+        if not strong:
+            nsample = min(nsample, len(count))
         sample = queries[:nsample]
         oc, otopk, otlen, _, _ = oidx.query_batch(args.op, sample, k=10)
         assert np.array_equal(count[:nsample], oc), "GPU/oracle count mismatch"
         fin = np.isfinite(otopk)
         np.testing.assert_allclose(topk[:nsample][fin], otopk[fin], rtol=1e-5)
-        pt = oidx.perftest(args.op, sample, k=10, runs=2)
-        cpu = {"value": 1e6 / pt["avg"], "unit": "queries/s", "cores": 1, "kind": "port",
-               "sample": "first %d of the %d-query batch, op_perftest: 1 untimed + 2 timed passes, %.1fs timed; "
-                         "mean %.1f us q50 %.1f q90 %.1f q95 %.1f" % (nsample, len(queries), pt["seconds"], pt["avg"],
-                                                                   pt["q50"], pt["q90"], pt["q95"]),
-               "host_cpus": os.cpu_count()}
-        out["speedup_vs_cpu_1core"] = qps / cpu["value"]
-        # N-thread replay in the style of profile_queries.cpp:21-39: one functor copy per thread, index shared read-only,
-        # every thread runs op_perftest (1 untimed + 1 timed pass) over its own slice of the batch
-        import threading
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        quota = None
-        try:  # a container may grant fewer CPUs than it shows (cgroup v2 cpu.max = "<quota> <period>" or "max <period>")
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                quota = max(1, int(int(q) / int(per)))
-        except Exception:  # noqa: BLE001
-            pass
-        nthreads = max(1, min(ncores, quota or ncores, 256))
-        # bounded: a quarter of the single-thread sample per thread keeps this leg to tens of seconds even when the
-        # threads share memory bandwidth
-        per_thread = max(16, min(nsample // 4, len(queries)))
-        slices = [[queries[(t * per_thread + i) % len(queries)] for i in range(per_thread)] for t in range(nthreads)]
-        errs = []
-
-        def replay(sl):
+        if not args.no_cpu_baseline and world == 1:
+            # (3) cpu_baseline: the oracle driven like op_perftest (queries.cpp:13-62) on ONE core
+            pt = oidx.perftest(args.op, sample, k=10, runs=2)
+            cpu_model = "unknown"
             try:
-                oidx.perftest(args.op, sl, k=10, runs=1)
-            except Exception as e:  # noqa: BLE001
-                errs.append(e)
+                cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:  # noqa: BLE001
+                pass
+            cpu = {"value": 1e6 / pt["avg"], "unit": "queries/s", "cores": 1, "kind": "port",
+                   "sample": "first %d of the %d-query batch, op_perftest: 1 untimed + 2 timed passes, %.1fs timed; "
+                             "mean %.1f us q50 %.1f q90 %.1f q95 %.1f" % (nsample, len(queries), pt["seconds"], pt["avg"],
+                                                                       pt["q50"], pt["q90"], pt["q95"]),
+                   "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+            out["speedup_vs_cpu_1core"] = qps / cpu["value"]
+            # N-thread replay in the style of profile_queries.cpp:21-39: one functor copy per thread, index shared
+            # read-only, every thread runs op_perftest (1 untimed + 1 timed pass) over its own slice of the batch.
+            # N = the CPUs this process may actually use (affinity mask, cgroup quota), i.e. physical cores when the
+            # container is granted them.
+            import threading
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            quota = None
+            try:  # cgroup v2 cpu.max = "<quota> <period>" or "max <period>"
+                qv, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if qv != "max":
+                    quota = max(1, int(int(qv) / int(per)))
+            except Exception:  # noqa: BLE001
+                pass
+            nthreads = max(1, min(ncores, quota or ncores, 256))
+            per_thread = max(16, min(nsample // 4, len(queries)))
+            slices = [[queries[(t * per_thread + i) % len(queries)] for i in range(per_thread)] for t in range(nthreads)]
+            errs = []
 
-        threads = [threading.Thread(target=replay, args=(sl,)) for sl in slices]
-        t0 = time.time()
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        wall = time.time() - t0
-        if not errs and wall > 0:
-            mt_qps = 2.0 * nthreads * per_thread / wall
-            out["cpu_baseline_threads"] = {"value": mt_qps, "unit": "queries/s", "cores": nthreads, "kind": "port",
-                                           "sample": "%d threads x %d queries x 2 passes in %.1fs wall (all passes counted); "
-                                                     "%d logical CPUs visible, cgroup quota %s"
-                                                     % (nthreads, per_thread, wall, ncores, quota if quota else "none")}
-            out["speedup_vs_cpu_all_cores"] = qps / mt_qps
+            def replay(sl):
+                try:
+                    oidx.perftest(args.op, sl, k=10, runs=1)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+
+            ths = [threading.Thread(target=replay, args=(sl,)) for sl in slices]
+            t0 = time.time()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            wall = time.time() - t0
+            if not errs and wall > 0:
+                mt_qps = 2.0 * nthreads * per_thread / wall
+                out["cpu_baseline_threads"] = {"value": mt_qps, "unit": "queries/s", "cores": nthreads, "kind": "port",
+                                               "cpu_model": cpu_model,
+                                               "sample": "%d threads x %d queries x 2 passes in %.1fs wall (all passes counted); "
+                                                         "%d logical CPUs visible, cgroup quota %s"
+                                                         % (nthreads, per_thread, wall, ncores, quota if quota else "none")}
+                out["speedup_vs_cpu_all_cores"] = qps / mt_qps
         if opath and os.path.exists(opath):
             os.remove(opath)
-    if a_skip_dom is None:  # N>1 or baseline skipped: price the device's own traversal with the same pricing
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    # achieved = (A_skip per query of the class, from the oracle) x (queries of that class in one launch) / (mean
+    # hipEvent duration of the class kernel over the launches of the timed region). The kernel's own traversal touches
+    # fewer bytes than that (block-max pruning skips what cannot enter the heap): device_counted_bytes.
+    kname = {"and": "k_conjunctive<false,false", "and_freq": "k_conjunctive<false,true", "ranked_and": "k_conjunctive<true,true"}
+    def kernel_name(c):
+        if c == 4:
+            return "k_daat_long<%s>" % args.op
+        if args.op in kname:
+            return "%s,TMAX=%d>" % (kname[args.op], (2, 4, 8, 16)[c])
+        return "k_disjunctive<TMAX=%d> (%s)" % ((2, 4, 8, 16)[c], args.op)
+    per_class = []
+    for c in range(NCLS):
+        nqc = cls_stats[c][1]
+        if not nqc or not mean_ms[c]:
+            continue
+        bytes_c = a_skip_q[c] * nqc if a_skip_q[c] is not None else None
+        per_class.append({"kernel": kernel_name(c), "queries": nqc, "ms_per_launch": mean_ms[c], "ms_alone": res_ms[c] / args.steps,
+                          "algorithmic_bytes": int(bytes_c) if bytes_c is not None else None,
+                          "achieved_gbs": (bytes_c / (mean_ms[c] * 1e-3) / 1e9) if bytes_c is not None else None,
+                          "device_counted_bytes": int(cls_stats[c][0].algorithmic_bytes)})
+    # dominant kernel = the class kernel that moves the most algorithmic bytes per launch. (Launch durations are not a
+    # good criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched
+    # to the length of the step by the big ones.)
+    if any(x is not None for x in a_skip_q):
+        dom = max(range(NCLS), key=lambda c: (a_skip_q[c] or 0) * cls_stats[c][1] if mean_ms[c] else -1)
+        dom_ms = mean_ms[dom]
+    if a_skip_q[dom] is not None:
+        a_skip_dom = a_skip_q[dom] * cls_stats[dom][1]
+        src = "oracle-counted reference traversal (A_skip) per query x queries in the launch"
+    else:  # oracle skipped: price the device's own (pruned) traversal with the same pricing
         a_skip_dom = cls_stats[dom][0].algorithmic_bytes
-        src = "device-counted (block-synchronous traversal, same pricing)"
-    else:
-        src = "oracle-counted reference traversal (A_skip)"
+        src = "device-counted (block-synchronous pruned traversal, same pricing)"
     achieved = a_skip_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None  # PMC counters cannot be collected inside this process: taken from the committed rocprofv3 passes
-    valu_issue = None
-    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % wl)
-    if os.path.exists(tj) and args.op == "ranked_and" and args.codec == "block_optpfor" and dom == 0:
+    # HBM traffic from PMC counters cannot be collected inside this process (rocprofv3 wraps the command): when a
+    # counter pass of the same command has been committed under profiles/, its per-launch figure is carried along and
+    # labelled as such; otherwise null.
+    traffic = None
+    traffic_src = None
+    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r02_traffic_%s_%s.json" % (wl, args.op))
+    if os.path.exists(tj) and args.codec == "block_optpfor":
         tjson = json.load(open(tj))
-        traffic = tjson.get("hbm_bytes_per_launch")
-        # the binding resource of this path is vector-instruction issue, not bandwidth: carry the
-        # measured figure of the committed counter pass next to the HBM roofline
-        valu_issue = (tjson.get("valu_issue") or {}).get("frac")
+        if tjson.get("kernel_class") == dom:
+            traffic = tjson.get("hbm_bytes_per_launch")
+            traffic_src = "committed profile: " + os.path.relpath(tj, ROOT)
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_issue_frac": valu_issue,
-                       "kernel": "%s<%s,TMAX=%d>" % ("k_conjunctive" if args.op in ("and", "and_freq", "ranked_and") else "k_daat",
-                                                     args.op, (2, 4, 8, 16)[dom]),
-                       "kernel_ms": dom_ms, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                       "kernel": kernel_name(dom), "kernel_ms": dom_ms, "kernel_ms_alone": res_ms[dom] / args.steps,
+                       "launches_timed": cls_ms[dom][1], "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
                        "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
-                       "queries_in_kernel": cls_stats[dom][1]}
+                       "queries_in_kernel": cls_stats[dom][1], "per_class": per_class}
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -16,6 +16,7 @@ FREQ_INDEX_KINDS = ["opt", "ef", "single", "uniform"]  # freq_index<...> layouts
 BLOCK_CODECS = ["block_optpfor", "block_varint", "block_interpolative", "block_qmx", "block_mixed"]
 OPS = {"and": 0, "and_freq": 1, "or": 2, "or_freq": 3, "ranked_and": 4, "wand": 5, "maxscore": 6, "ranked_or": 7}
 REFERENCE_ORDER = 0x100
+NO_COUNTERS = 0x200  # run the kernels compiled without the statistics counters (stats then carry kernel_ms only)
 _RANKED = {4, 5, 6, 7}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -76,6 +77,13 @@ def lib():
         L.ds2i_hip_batch_free.argtypes = [vp]
         L.ds2i_hip_batch_free.restype = None
         L.ds2i_hip_batch_set_instrumented.argtypes = [vp, C.c_int]
+        L.ds2i_hip_pipeline_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+        L.ds2i_hip_pipeline_destroy.argtypes = [vp]
+        L.ds2i_hip_pipeline_destroy.restype = None
+        L.ds2i_hip_pipeline_submit.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, u64p]
+        L.ds2i_hip_pipeline_wait.argtypes = [vp, C.c_uint64, vp, vp, vp, C.POINTER(Stats)]
+        L.ds2i_hip_pipeline_set_instrumented.argtypes = [vp, C.c_int]
+        L.ds2i_hip_pipeline_class_stats.argtypes = [vp, C.c_int, C.POINTER(Stats), u32p]
         L.ds2i_hip_batch_enable_block_profile.argtypes = [vp]
         L.ds2i_hip_batch_block_profile.argtypes = [vp, vp, C.c_uint64, u64p]
         L.ds2i_hybrid_default_model.argtypes = [vp]
@@ -90,6 +98,7 @@ def lib():
         L.ds2i_hybrid_free.restype = None
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
+        L.ds2i_hip_selftest_bm25.argtypes = [C.c_int, vp, vp, vp, C.c_uint32]
         # build side
         L.ds2i_blob_data.argtypes = [vp]
         L.ds2i_blob_data.restype = vp
@@ -396,6 +405,61 @@ class Batch:
             pass
 
 
+class Pipeline:
+    """Pipelined submit / wait over reusable batch slots (ds2i_hip_pipeline_*): submit() plans the batch on the host
+    and enqueues upload + kernels + result copy without waiting for the device, so the next submit() overlaps with
+    the kernels of this one. A serving loop keeps `depth` batches in flight."""
+
+    def __init__(self, index, depth=3):
+        self.index, self.depth = index, depth
+        self._h = C.c_void_p()
+        self._meta = {}
+        _check(lib().ds2i_hip_pipeline_create(index._h, depth, C.byref(self._h)))
+
+    def set_instrumented(self, on):
+        _check(lib().ds2i_hip_pipeline_set_instrumented(self._h, 1 if on else 0))
+
+    def submit(self, op, queries, k=10):
+        """queries: list of term lists, or an already flattened (terms uint32[], offsets uint32[nq+1]) pair."""
+        terms, offs = queries if isinstance(queries, tuple) else _flatten(queries)
+        nq = len(offs) - 1
+        t = C.c_uint64()
+        _check(lib().ds2i_hip_pipeline_submit(self._h, _op(op), k, _ptr(terms), _ptr(offs), nq, C.byref(t)))
+        self._meta[t.value] = (nq, k if (_op(op) & 0xFF) in _RANKED else 1)
+        return t.value
+
+    def wait(self, ticket, stats=False):
+        nq, k = self._meta.pop(ticket, (0, 1))
+        count = np.zeros(max(nq, 1), dtype=np.uint64)
+        topk = np.full((max(nq, 1), k), -np.inf, dtype=np.float32)
+        tlen = np.zeros(max(nq, 1), dtype=np.uint32)
+        st = Stats()
+        _check(lib().ds2i_hip_pipeline_wait(self._h, ticket, _ptr(count), _ptr(topk), _ptr(tlen), C.byref(st) if stats else None))
+        return (count[:nq], topk[:nq], tlen[:nq], st) if stats else (count[:nq], topk[:nq], tlen[:nq])
+
+    def class_stats(self, cls):
+        """(Stats, queries) of kernel class `cls` for the ticket collected last."""
+        st, n = Stats(), C.c_uint32()
+        _check(lib().ds2i_hip_pipeline_class_stats(self._h, cls, C.byref(st), C.byref(n)))
+        return st, n.value
+
+    def close(self):
+        if self._h:
+            lib().ds2i_hip_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def flatten_queries(queries):
+    """(terms, offsets) arrays of a query batch -- the form that crosses the C ABI."""
+    return _flatten(queries)
+
+
 class Index:
     """block_freq_index resident in one GPU's HBM (Index concept: size(), num_docs(), operator[])."""
 
@@ -435,10 +499,10 @@ class Index:
         return n.value
 
     def query_batch(self, op, queries, k=10):
-        terms, offs = _flatten(queries)
-        nq = len(queries)
+        terms, offs = queries if isinstance(queries, tuple) else _flatten(queries)
+        nq = len(offs) - 1
         count = np.zeros(max(nq, 1), dtype=np.uint64)
-        topk = np.full((max(nq, 1), k), -np.inf, dtype=np.float32)
+        topk = np.full((max(nq, 1), max(k, 1)), -np.inf, dtype=np.float32)
         tlen = np.zeros(max(nq, 1), dtype=np.uint32)
         st = Stats()
         _check(lib().ds2i_hip_query_batch(self._h, _op(op), k, _ptr(terms), _ptr(offs), nq, _ptr(count), _ptr(topk),

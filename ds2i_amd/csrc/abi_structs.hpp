@@ -17,7 +17,12 @@ struct QTerm {
     uint64_t aux0;    // opt index: absolute bit offset of the list's docs sequence (after its gamma header);
                       // block indexes: number of blocks of all preceding lists (access-profile base)
     uint64_t aux1;    // opt index: absolute bit offset of the list's freqs sequence
+    uint32_t blk_base; // blocks (chunks) of all preceding lists: index of this list's first entry in bmw[]
+    float max_bmw;     // q_weight * (max over the list's blocks of bmw[]): device-computed list bound (ranked_and pruning)
+    float suf_bmw;     // sum of max_bmw over the LATER lists of the query (enumerator order)
+    float floor1;      // one-term ranked queries: q_weight * (k-th largest bmw of the list) -- k documents reach it
 };
+static_assert(sizeof(QTerm) == 64, "QTerm is a 64-byte device record");
 
 enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_COUNT };
 struct Stats {
@@ -29,7 +34,7 @@ enum { OP_AND = 0, OP_AND_FREQ = 1, OP_OR = 2, OP_OR_FREQ = 3, OP_RANKED_AND = 4
        OP_RANKED_OR = 7, OP_REFERENCE_ORDER = 0x100 };
 
 // One schedulable piece of a query: conjunctive queries are split by ranges of blocks of their
-// shortest list (doc-id ranges), every other operator has exactly one unit per query.
+// shortest list, the disjunctive operators by doc-id ranges.
 struct Unit {
     uint32_t q;         // query id
     uint32_t blk_begin; // first block of list 0 this unit owns
@@ -70,9 +75,33 @@ struct BatchArgs {
     // bits; scores are >= 0 so the bit patterns order like the values) and adopt the maximum as their floor: the final
     // k-th score of the union is >= the k-th score of any part
     unsigned int* q_floor;     // nq or null
+    // block-synchronous ranked_and: the parts of a split query share a 256-bucket histogram of the scores that entered
+    // their heaps; the lower edge of the highest bucket with >= k documents at or above it is every part's floor
+    unsigned int* q_hist;      // nq * 256 or null
     unsigned int* block_profile; // block indexes: 2 counters per block of the index (docs / freqs decodes) or null
     const void* skip;            // block indexes: interleaved {block_max, block end offset} per block (uint2) or null
+    const float* bmw;            // per block / chunk of the index: max doc_term_weight of its postings, or null
+    uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
+    uint32_t long_stride;        // dwords of scratch per unit
     Stats* stats;
+};
+
+// upload-time pass computing bmw[] (k_block_max_weights): one wave per item = <=64 consecutive blocks of one list
+struct BmwItem {
+    uint32_t list, blk_begin;
+};
+struct BmwArgs {
+    const uint8_t* arena;
+    const uint8_t* bits0;
+    const uint8_t* bits1;
+    const float* norm_lens;
+    const QTerm* lists; // one per list of the index
+    const BmwItem* items;
+    uint32_t nitems;
+    int codec;
+    uint32_t num_docs;
+    float* bmw;             // out: one per block
+    unsigned int* list_bmw; // out: per list max (float bits; weights are >= 0 so the bit patterns order like the values)
 };
 
 struct MergeArgs {

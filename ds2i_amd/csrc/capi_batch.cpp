@@ -1,0 +1,801 @@
+// Host implementation of include/ds2i_hip.h, query half: the host part of queries.hpp (term normalisation, BM25
+// query weights, list ordering: queries.hpp:29-33, 53-56, 136-150, 357-360), work-unit planning, and the kernel
+// launches. A batch is a reusable SLOT: its pinned staging block, its device blocks and its events are allocated
+// once and only grow, so a serving loop (ds2i_hip_pipeline_*) pays no allocation per batch; everything a batch
+// uploads travels in ONE async H2D copy, everything it returns in ONE async D2H copy, and nothing in submit()
+// blocks on the device -- the host plans batch i+1 while the kernels of batch i run.
+// There is NO CPU fallback: every query result comes from the HIP kernels or the call fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "capi_internal.hpp"
+#include "host_index.hpp"
+
+using ds2i_dev::BatchArgs;
+using ds2i_dev::MergeArgs;
+using ds2i_dev::QTerm;
+using ds2i_dev::Stats;
+using ds2i_dev::Unit;
+
+extern "C" {
+hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
+                                 const unsigned long long* seed_count, float* out_topk, uint32_t* out_len,
+                                 unsigned long long* out_count, hipStream_t s);
+uint32_t ds2i_meta_words(void); // kernels.hip: dwords of enumerator state per list slot (M_WORDS)
+}
+
+struct ds2i_hip_batch {
+    ds2i_hip_index* idx = nullptr;
+    int op = 0;
+    uint32_t k = 0, nq = 0;
+    bool want_matches = false;
+    bool instrument = true;           // collect ds2i_hip_stats counters (instrumented kernel instantiations)
+    bool use_seed = false;            // wand / maxscore / ranked_or: `seed` holds this batch's ranked_and pass
+    ds2i_hip_batch* seed = nullptr;   // ranked_and pass over the same queries (pruning floor); the slot is kept for reuse
+    bool profile_on = false;          // block access profile requested (d_prof)
+    unsigned int* prof_ptr = nullptr; // where instrumented runs count block decodes (the owner's d_prof; a seed borrows it)
+    // ---- host plan (vectors keep their capacity between uses of the slot)
+    std::vector<QTerm> qterms;
+    std::vector<uint32_t> qnbs, qoff, qnb0, scratch_u32;
+    std::vector<double> qcost;
+    std::vector<Unit> units;
+    std::vector<uint32_t> q_unit_off, split_queries, single_queries, order[NCLS];
+    std::vector<float> unit_cost;
+    std::vector<unsigned long long> match_off;
+    std::vector<uint32_t> seed_terms, seed_offs;
+    uint32_t ncls[NCLS] = {};  // units per kernel class
+    uint32_t nqcls[NCLS] = {}; // queries per kernel class
+    uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
+    // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_order[NCLS] = {},
+           o_match_off = 0, up_bytes = 0;
+    // ---- one result block (d_out -> pinned mirror h_out)
+    size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
+    // ---- device-only scratch: per-unit partial results of split queries + the shared floors
+    size_t o_unit_count = 0, o_unit_topk = 0, o_unit_topk_len = 0, o_unit_freq_sum = 0, o_qfloor = 0, scr_bytes = 0;
+    DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long;
+    PinBuf h_up, h_out;
+    hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
+    bool uploaded = false, launched = false;
+    float cls_ms[NCLS] = {};
+    Stats cls_stats[NCLS] = {};
+    double total_ms = 0;
+};
+
+namespace {
+
+inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+int ensure_events(ds2i_hip_batch* b) {
+    if (b->ev_up) return DS2I_OK;
+    HIP_OK(hipEventCreate(&b->ev_up));
+    HIP_OK(hipEventCreate(&b->ev_clear));
+    HIP_OK(hipEventCreate(&b->ev_done));
+    for (int c = 0; c < NCLS; ++c) {
+        HIP_OK(hipEventCreate(&b->ev_c0[c]));
+        HIP_OK(hipEventCreate(&b->ev_c1[c]));
+    }
+    return DS2I_OK;
+}
+
+// units in decreasing cost order. The order only steers the dispatcher (big units first, small ones fill the tail), so
+// a counting sort on the float's exponent and top mantissa bits replaces the comparison sort: O(n), stable.
+void order_by_cost(const std::vector<float>& cost, const std::vector<uint32_t>& ids, std::vector<uint32_t>& out,
+                   std::vector<uint32_t>& tmp) {
+    const int BITS = 14; // 8 exponent bits + 6 mantissa bits of a positive float
+    const size_t NB = size_t(1) << BITS;
+    tmp.assign(NB + 1, 0);
+    auto key = [&](uint32_t id) -> uint32_t {
+        uint32_t bits;
+        const float c = cost[id] > 0.f ? cost[id] : 0.f;
+        std::memcpy(&bits, &c, 4);
+        return (uint32_t)(NB - 1) - (bits >> (31 - BITS)); // descending
+    };
+    for (uint32_t id : ids) ++tmp[key(id) + 1];
+    for (size_t i = 0; i < NB; ++i) tmp[i + 1] += tmp[i];
+    out.resize(ids.size());
+    for (uint32_t id : ids) out[tmp[key(id)]++] = id;
+}
+
+// ---------------------------------------------------------------- plan: host half of the query operators
+int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
+               int want_matches) {
+    ds2i_hip_index* idx = b->idx;
+    if (!query_offsets || (!terms && nq && query_offsets[nq] > 0))
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
+    const int base_op = op & 0xFF;
+    if (base_op < DS2I_OP_AND || base_op > DS2I_OP_RANKED_OR || (op & ~(0xFF | DS2I_OP_REFERENCE_ORDER | DS2I_OP_NO_COUNTERS)))
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
+    const bool conj = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
+    const bool ranked = base_op >= DS2I_OP_RANKED_AND;
+    if (ranked && !idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
+    if (ranked && (k == 0 || k > DS2I_HIP_MAX_K)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1,64]");
+    if (!ranked) k = 1; // and / or return counts only: k is ignored, no top-k is produced or copied
+
+    b->op = op;
+    b->k = k;
+    b->nq = nq;
+    b->want_matches = want_matches && (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ);
+    b->uploaded = b->launched = false;
+
+    auto& qterms = b->qterms;
+    auto& qnbs = b->qnbs;
+    auto& qoff = b->qoff;
+    auto& qcost = b->qcost;
+    auto& qnb0 = b->qnb0;
+    qterms.clear();
+    qnbs.clear();
+    qoff.assign(nq + 1, 0);
+    qcost.assign(nq, 0.0);
+    qnb0.assign(nq, 0);
+    b->match_off.assign(nq + 1, 0);
+    b->long_terms = 0;
+    std::vector<uint32_t>& t = b->scratch_u32;
+    std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
+    const bool split_ok = conj && !(op & DS2I_OP_REFERENCE_ORDER);
+    double total_cost[NCLS] = {};
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (query_offsets[q + 1] < query_offsets[q])
+            return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
+        t.assign(terms + query_offsets[q], terms + query_offsets[q + 1]);
+        std::sort(t.begin(), t.end()); // queries.hpp:31 / 139
+        tf.clear();
+        for (size_t i = 0; i < t.size(); ++i) {
+            if (t[i] >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+            if (i == 0 || t[i] != t[i - 1]) tf.emplace_back(t[i], 1u);
+            else tf.back().second += 1;
+        }
+        if (tf.size() > DS2I_HIP_MAX_TERMS_LONG)
+            return ds2i_set_error(DS2I_ETOOLONG, "query has more than DS2I_HIP_MAX_TERMS_LONG distinct terms");
+        const size_t begin = qterms.size();
+        for (auto const& p : tf) {
+            QTerm qt = ds2i_make_qterm(idx, p.first);
+            if (ranked) {
+                qt.q_weight = ds2i_host::bm25::query_term_weight(p.second, qt.n, idx->num_docs);
+                qt.max_weight = qt.q_weight * idx->max_term_weight[p.first];
+                qt.max_bmw = idx->d_bmw ? qt.q_weight * idx->list_bmw[p.first] : std::numeric_limits<float>::infinity();
+            }
+            qterms.push_back(qt);
+            qnbs.push_back(idx->list_nb[p.first]);
+        }
+        double cost = 0;
+        if (conj) { // sort by increasing frequency (queries.hpp:53-56, 357-360); stable insertion sort of <= a few lists
+            for (size_t i = begin + 1; i < qterms.size(); ++i) {
+                const QTerm v = qterms[i];
+                const uint32_t vn = qnbs[i];
+                size_t j = i;
+                while (j > begin && v.n < qterms[j - 1].n) {
+                    qterms[j] = qterms[j - 1];
+                    qnbs[j] = qnbs[j - 1];
+                    --j;
+                }
+                qterms[j] = v;
+                qnbs[j] = vn;
+            }
+            if (!tf.empty()) {
+                const double n0 = qterms[begin].n;
+                qnb0[q] = qnbs[begin];
+                cost = qnb0[q] * (ranked ? 2.0 : 1.0);
+                for (size_t i = begin + 1; i < qterms.size(); ++i) cost += std::min<double>(qnbs[i], n0);
+                // a one-term ranked query scans its block weights (64 per probe) and decodes about k blocks
+                if (ranked && idx->d_bmw && tf.size() == 1) cost = qnb0[q] / 16.0 + 4.0 * k;
+                b->match_off[q + 1] = 128ull * qnb0[q];
+            }
+        } else {
+            for (size_t i = begin; i < qterms.size(); ++i) cost += qnbs[i] * (ranked ? 2.0 : 1.0);
+        }
+        if (ranked && idx->d_bmw && qterms.size() > begin) {
+            // ranked_and pruning bounds (kernels.hip): suffix sums of the list bounds in enumerator order; a one-term
+            // query additionally starts from the k-th largest block weight of its list
+            float suf = 0.f;
+            for (size_t i = qterms.size(); i-- > begin;) {
+                qterms[i].suf_bmw = suf;
+                suf += qterms[i].max_bmw;
+            }
+            if (qterms.size() - begin == 1)
+                qterms[begin].floor1 = qterms[begin].q_weight * idx->list_topbmw[(size_t)tf[0].first * DS2I_HIP_MAX_K + (k - 1)];
+        }
+        qoff[q + 1] = (uint32_t)qterms.size();
+        qcost[q] = cost;
+        total_cost[class_of(tf.size())] += cost;
+        if (tf.size() > DS2I_HIP_MAX_TERMS) b->long_terms = std::max<uint32_t>(b->long_terms, (uint32_t)tf.size());
+    }
+    for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
+
+    // ---- work units: long conjunctive queries are split by block ranges of their shortest list so
+    // that one giant query does not pin a single wavefront (SURVEY.md §7 "Load imbalance")
+    b->units.clear();
+    b->unit_cost.clear();
+    b->q_unit_off.assign(nq + 1, 0);
+    b->split_queries.clear();
+    b->single_queries.clear();
+    std::vector<uint32_t> cls_ids[NCLS];
+    for (int c = 0; c < NCLS; ++c) b->nqcls[c] = 0;
+    // ranked_or takes the seed only in its block-synchronous form: its reference-order traversal stays the unpruned
+    // exhaustive OR of queries.hpp:404-476 (the oracle the reference tests wand / maxscore against)
+    const bool seeded = nq && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
+                               (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
+    double all_cost = 0;
+    for (double c : total_cost) all_cost += c;
+    const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
+    // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
+    static const char* uf = std::getenv("DS2I_UNIT_FACTOR");
+    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : 16.0;
+    auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
+        Unit u;
+        u.q = q;
+        u.blk_begin = lo;
+        u.blk_end = hi;
+        u.nparts = parts;
+        cls_ids[c].push_back((uint32_t)b->units.size());
+        b->units.push_back(u);
+        b->unit_cost.push_back((float)cost);
+    };
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t nt = qoff[q + 1] - qoff[q];
+        const int c = class_of(nt);
+        // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : 4.0));
+        ++b->nqcls[c];
+        if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
+            b->single_queries.push_back(q);
+            b->q_unit_off[q + 1] = (uint32_t)b->units.size();
+            continue;
+        }
+        if (c == CLS_LONG) { // > 16 terms: one unit, reference-order traversal over global scratch
+            add_unit(c, q, 0, conj ? std::max(1u, qnb0[q]) : (uint32_t)idx->num_docs, 1, qcost[q]);
+        } else if (conj) {
+            uint32_t parts = 1;
+            if (split_ok && nt && qnb0[q] > 1) {
+                double want = std::floor(qcost[q] / target);
+                parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
+            }
+            const uint32_t nb0 = std::max(1u, qnb0[q]);
+            const uint32_t per = (nb0 + parts - 1) / parts;
+            parts = (nb0 + per - 1) / per;
+            if (parts > 1) b->split_queries.push_back(q);
+            for (uint32_t j = 0; j < parts; ++j) add_unit(c, q, j * per, std::min(nb0, (j + 1) * per), parts, qcost[q] / parts);
+        } else {
+            // or / ranked_or / wand / maxscore: units are equal-width doc-id ranges; every part keeps its own
+            // top-k (its own pruning threshold), the merge is exact
+            const uint32_t N = (uint32_t)idx->num_docs;
+            uint32_t parts = 1;
+            // every part re-seeks its lists (the parts of a query share their pruning floor through q_floor), and the
+            // many-list classes pay that per list: they want coarser parts than the one/two-list class (measured on
+            // the GOV2-scale batch)
+            static const double disj_scale[NCLS] = {8.0, 2.0, 1.0, 1.0, 1.0};
+            const double dtarget = std::max(48.0, all_cost / (unit_factor * disj_scale[c] * resident));
+            if (nt && N > 1)
+                parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));
+            const uint32_t width = (N + parts - 1) / parts;
+            parts = width ? (N + width - 1) / width : 1;
+            if (parts > 1) b->split_queries.push_back(q);
+            for (uint32_t j = 0; j < parts; ++j)
+                add_unit(c, q, j * width, (uint32_t)std::min<uint64_t>(N, (uint64_t)(j + 1) * width), parts, qcost[q] / parts);
+        }
+        b->q_unit_off[q + 1] = (uint32_t)b->units.size();
+    }
+    b->nunits = (uint32_t)b->units.size();
+    b->nsplit = (uint32_t)b->split_queries.size();
+    b->nsingle = (uint32_t)b->single_queries.size();
+    for (int c = 0; c < NCLS; ++c) {
+        order_by_cost(b->unit_cost, cls_ids[c], b->order[c], b->scratch_u32); // costliest first
+        b->ncls[c] = (uint32_t)b->order[c].size();
+    }
+
+    static const bool debug_plan = std::getenv("DS2I_DEBUG_PLAN") != nullptr;
+    if (debug_plan)
+        std::fprintf(stderr, "ds2i plan: op %d nq %u units %u (per class %u %u %u %u %u) split queries %u cost %.0f\n", op, nq, b->nunits,
+                     b->ncls[0], b->ncls[1], b->ncls[2], b->ncls[3], b->ncls[4], b->nsplit, all_cost);
+
+    // ---- layouts
+    size_t o = 0;
+    auto place = [&](size_t bytes) { size_t at = o; o = align16(o + bytes); return at; };
+    b->o_qterms = place(qterms.size() * sizeof(QTerm));
+    b->o_qoff = place(qoff.size() * 4);
+    b->o_units = place(b->units.size() * sizeof(Unit));
+    b->o_q_unit_off = place(b->q_unit_off.size() * 4);
+    b->o_split = place(b->split_queries.size() * 4);
+    b->o_single = place(b->single_queries.size() * 4);
+    for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
+    b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
+    b->up_bytes = o + 16;
+    const size_t nq1 = nq ? nq : 1, nu1 = b->nunits ? b->nunits : 1;
+    o = 0;
+    b->o_count = place(8 * nq1);
+    b->o_topk = place(4 * nq1 * k);
+    b->o_topk_len = place(4 * nq1);
+    b->o_freq_sum = place(8 * nq1);
+    b->out_bytes = o;
+    o = 0;
+    b->o_unit_count = place(8 * nu1);
+    b->o_unit_topk = place(4 * nu1 * k);
+    b->o_unit_topk_len = place(4 * nu1);
+    b->o_unit_freq_sum = place(8 * nu1);
+    // ranked_and: a 256-bucket score histogram per query (kernels.hip); the disjunctive operators: one floor word
+    const bool hist = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && idx->d_bmw && b->nsplit;
+    b->o_qfloor = place(hist ? 1024 * nq1 : 4 * nq1);
+    b->scr_bytes = o;
+
+    b->use_seed = seeded;
+    if (seeded) {
+        // The seed is the ranked_and top-k of a SUB-query: any k documents' partial scores bound the final k-th
+        // score from below. One- and two-term queries use all their terms (the one-term answer is final); longer
+        // queries use their two shortest lists -- the full conjunction of 5+ terms is usually too small to give k
+        // documents, while the rarest pair is cheap to intersect and carries the largest term weights.
+        static const char* sv = std::getenv("DS2I_SEED_TERMS");
+        const size_t seed_terms = sv && std::atoi(sv) > 0 ? (size_t)std::atoi(sv) : 2;
+        auto& sterms = b->seed_terms;
+        auto& soffs = b->seed_offs;
+        sterms.clear();
+        soffs.assign(nq + 1, 0);
+        std::vector<uint32_t> dt;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint32_t* qb = terms + query_offsets[q];
+            const uint32_t* qe = terms + query_offsets[q + 1];
+            dt.assign(qb, qe);
+            std::sort(dt.begin(), dt.end());
+            dt.erase(std::unique(dt.begin(), dt.end()), dt.end());
+            if (dt.size() > seed_terms && dt.size() > 2) {
+                std::stable_sort(dt.begin(), dt.end(), [&](uint32_t x, uint32_t y) { return idx->list_n[x] < idx->list_n[y]; });
+                dt.resize(std::max<size_t>(2, seed_terms));
+                for (const uint32_t* p = qb; p != qe; ++p) // keep multiplicities: the query term weight counts them
+                    if (std::find(dt.begin(), dt.end(), *p) != dt.end()) sterms.push_back(*p);
+            } else {
+                sterms.insert(sterms.end(), qb, qe);
+            }
+            soffs[q + 1] = (uint32_t)sterms.size();
+        }
+        if (!b->seed) {
+            b->seed = new ds2i_hip_batch;
+            b->seed->idx = idx;
+        }
+        int rc = plan_batch(b->seed, DS2I_OP_RANKED_AND, k, sterms.data(), soffs.data(), nq, 0);
+        if (rc) return rc;
+    }
+    return DS2I_OK;
+}
+
+// ---------------------------------------------------------------- upload: one async H2D copy of the packed plan
+int upload_batch(ds2i_hip_batch* b) {
+    ds2i_hip_index* idx = b->idx;
+    int rc = ensure_events(b);
+    if (rc) return rc;
+    if (b->use_seed) {
+        rc = upload_batch(b->seed);
+        if (rc) return rc;
+    }
+    HIP_OK(b->h_up.reserve(b->up_bytes));
+    HIP_OK(b->d_up.reserve(b->up_bytes));
+    HIP_OK(b->d_out.reserve(b->out_bytes));
+    HIP_OK(b->h_out.reserve(b->out_bytes));
+    HIP_OK(b->d_scr.reserve(b->scr_bytes));
+    HIP_OK(b->d_stats.reserve(NCLS * sizeof(Stats)));
+    if (b->want_matches) HIP_OK(b->d_matches.reserve(4 * (size_t)(b->match_off[b->nq] ? b->match_off[b->nq] : 1)));
+    if (b->long_terms) {
+        const size_t stride = (size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16;
+        HIP_OK(b->d_long.reserve(4 * stride * std::max<uint32_t>(1, b->ncls[CLS_LONG])));
+    }
+    uint8_t* h = (uint8_t*)b->h_up.p;
+    auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) std::memcpy(h + off, src, bytes); };
+    put(b->o_qterms, b->qterms.data(), b->qterms.size() * sizeof(QTerm));
+    put(b->o_qoff, b->qoff.data(), b->qoff.size() * 4);
+    put(b->o_units, b->units.data(), b->units.size() * sizeof(Unit));
+    put(b->o_q_unit_off, b->q_unit_off.data(), b->q_unit_off.size() * 4);
+    put(b->o_split, b->split_queries.data(), b->split_queries.size() * 4);
+    put(b->o_single, b->single_queries.data(), b->single_queries.size() * 4);
+    for (int c = 0; c < NCLS; ++c) put(b->o_order[c], b->order[c].data(), b->order[c].size() * 4);
+    if (b->want_matches) put(b->o_match_off, b->match_off.data(), b->match_off.size() * 8);
+    HIP_OK(hipMemcpyAsync(b->d_up.p, b->h_up.p, b->up_bytes, hipMemcpyHostToDevice, idx->s_up));
+    HIP_OK(hipEventRecord(b->ev_up, idx->s_up));
+    b->uploaded = true;
+    return DS2I_OK;
+}
+
+// ---------------------------------------------------------------- launch: kernels + merge + one async D2H; no host sync
+int launch_batch(ds2i_hip_batch* b) {
+    ds2i_hip_index* idx = b->idx;
+    if (!b->uploaded) return ds2i_set_error(DS2I_EINVAL, "batch has not been prepared");
+    if (b->use_seed) { // block-synchronous ranked_and first: its k-th score seeds the pruning floor of every unit
+        b->seed->instrument = b->instrument;
+        b->seed->profile_on = b->profile_on;
+        b->seed->prof_ptr = b->prof_ptr;
+        int rc = launch_batch(b->seed);
+        if (rc) return rc;
+    }
+    // per-unit partials, shared floors, result block and counters start from zero. The clears go to the upload
+    // stream: they depend on nothing but the slot being free, so the class kernels of this batch can start while the
+    // previous batch is still being merged
+    hipStream_t sm = idx->s_merge, su = idx->s_up;
+    HIP_OK(hipMemsetAsync(b->d_scr.p, 0, b->scr_bytes, su));
+    HIP_OK(hipMemsetAsync(b->d_out.p, 0, b->out_bytes, su));
+    if (b->instrument) HIP_OK(hipMemsetAsync(b->d_stats.p, 0, NCLS * sizeof(Stats), su));
+    HIP_OK(hipEventRecord(b->ev_clear, su)); // also orders this launch after the batch's upload (same stream)
+    // Launch order of the class kernels (they overlap on separate streams either way; measured on the GOV2-scale
+    // batch): the block-synchronous conjunctions run 3 % faster when the issue-bound <=2-list class is enqueued first,
+    // the disjunctive operators 2.5 % faster when the many-list classes are.
+    const int base_op = b->op & 0xFF;
+    const bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
+                             (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND);
+    static const bool no_skiptab = std::getenv("DS2I_NO_SKIPTAB") != nullptr;
+    static const bool no_bmw_prune = std::getenv("DS2I_NO_BMW_PRUNE") != nullptr;
+    // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
+    for (int c = 0; c < NCLS; ++c) {
+        if (!b->ncls[c]) continue;
+        HIP_OK(hipStreamWaitEvent(idx->stream[c], b->ev_clear, 0));
+        if (b->use_seed) HIP_OK(hipStreamWaitEvent(idx->stream[c], b->seed->ev_done, 0));
+    }
+    HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
+    if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
+    for (int ci = NCLS - 1; ci >= 0; --ci) {
+        const int c = small_first ? NCLS - 1 - ci : ci;
+        if (!b->ncls[c]) continue;
+        hipStream_t s = idx->stream[c];
+        HIP_OK(hipEventRecord(b->ev_c0[c], s));
+        BatchArgs a{};
+        a.arena = idx->d_arena;
+        a.bits0 = idx->d_bits0;
+        a.bits1 = idx->d_bits1;
+        a.norm_lens = idx->d_norm_lens;
+        a.qterms = b->d_up.at<QTerm>(b->o_qterms);
+        a.q_off = b->d_up.at<uint32_t>(b->o_qoff);
+        a.units = b->d_up.at<Unit>(b->o_units);
+        a.order = b->d_up.at<uint32_t>(b->o_order[c]);
+        a.nslice = b->ncls[c];
+        a.num_docs = (uint32_t)idx->num_docs;
+        a.k = b->k;
+        a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
+        a.ticket = idx->d_ticket;
+        a.out_count = b->d_out.at<unsigned long long>(b->o_count);
+        a.out_topk = b->d_out.at<float>(b->o_topk);
+        a.out_topk_len = b->d_out.at<uint32_t>(b->o_topk_len);
+        a.out_freq_sum = b->d_out.at<unsigned long long>(b->o_freq_sum);
+        a.out_matches = b->want_matches ? (uint32_t*)b->d_matches.p : nullptr;
+        a.match_off = b->want_matches ? b->d_up.at<unsigned long long>(b->o_match_off) : nullptr;
+        a.unit_count = b->d_scr.at<unsigned long long>(b->o_unit_count);
+        a.unit_topk = b->d_scr.at<float>(b->o_unit_topk);
+        a.unit_topk_len = b->d_scr.at<uint32_t>(b->o_unit_topk_len);
+        a.unit_freq_sum = b->d_scr.at<unsigned long long>(b->o_unit_freq_sum);
+        a.seed_topk = b->use_seed ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
+        a.seed_len = b->use_seed ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
+        const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
+        a.q_floor = (disj_topk && !(b->op & DS2I_OP_REFERENCE_ORDER)) ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
+        a.q_hist = (base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && idx->d_bmw && b->nsplit)
+                       ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
+        a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
+        a.skip = no_skiptab ? nullptr : idx->d_skip;
+        a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;
+        a.long_scratch = (uint32_t*)b->d_long.p;
+        a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
+        a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;
+        HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, b->ncls[c], s));
+        HIP_OK(hipEventRecord(b->ev_c1[c], s));
+        HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[c], 0));
+    }
+    if (b->nsplit) {
+        MergeArgs m{};
+        m.split_queries = b->d_up.at<uint32_t>(b->o_split);
+        m.nsplit = b->nsplit;
+        m.q_unit_off = b->d_up.at<uint32_t>(b->o_q_unit_off);
+        m.k = b->k;
+        m.ranked = (b->op & 0xFF) >= DS2I_OP_RANKED_AND;
+        m.unit_count = b->d_scr.at<unsigned long long>(b->o_unit_count);
+        m.unit_topk = b->d_scr.at<float>(b->o_unit_topk);
+        m.unit_topk_len = b->d_scr.at<uint32_t>(b->o_unit_topk_len);
+        m.unit_freq_sum = b->d_scr.at<unsigned long long>(b->o_unit_freq_sum);
+        m.out_count = b->d_out.at<unsigned long long>(b->o_count);
+        m.out_topk = b->d_out.at<float>(b->o_topk);
+        m.out_topk_len = b->d_out.at<uint32_t>(b->o_topk_len);
+        m.out_freq_sum = b->d_out.at<unsigned long long>(b->o_freq_sum);
+        HIP_OK(ds2i_launch_merge(&m, std::min<unsigned>(b->nsplit, 4096u), sm));
+    }
+    if (b->use_seed && b->nsingle)
+        HIP_OK(ds2i_launch_copy_seed(b->d_up.at<uint32_t>(b->o_single), b->nsingle, b->k, b->seed->d_out.at<float>(b->seed->o_topk),
+                                     b->seed->d_out.at<uint32_t>(b->seed->o_topk_len),
+                                     b->seed->d_out.at<unsigned long long>(b->seed->o_count), b->d_out.at<float>(b->o_topk),
+                                     b->d_out.at<uint32_t>(b->o_topk_len), b->d_out.at<unsigned long long>(b->o_count), sm));
+    HIP_OK(hipMemcpyAsync(b->h_out.p, b->d_out.p, b->out_bytes, hipMemcpyDeviceToHost, sm));
+    HIP_OK(hipEventRecord(b->ev_done, sm));
+    b->launched = true;
+    return DS2I_OK;
+}
+
+// ---------------------------------------------------------------- finish: wait for the batch, collect timings / counters
+int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
+    if (!b->launched) return ds2i_set_error(DS2I_EINVAL, "batch has not been launched");
+    double seed_ms = 0;
+    HIP_OK(hipEventSynchronize(b->ev_done));
+    if (b->use_seed) {
+        ds2i_hip_stats ss;
+        int rc = finish_batch(b->seed, &ss);
+        if (rc) return rc;
+        seed_ms = ss.kernel_ms;
+    }
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, b->ev_clear, b->ev_done));
+    b->total_ms = ms;
+    for (int c = 0; c < NCLS; ++c) {
+        b->cls_ms[c] = 0.f;
+        if (b->ncls[c]) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], b->ev_c0[c], b->ev_c1[c]));
+    }
+    if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, b->d_stats.p, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
+    else std::memset(b->cls_stats, 0, sizeof(b->cls_stats));
+    if (stats) {
+        stats->kernel_ms = ms + seed_ms;
+        stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;
+        stats->algorithmic_bytes = stats->postings_scored = stats->rounds = 0;
+        for (int c = 0; c < NCLS; ++c) {
+            stats->docs_blocks_decoded += b->cls_stats[c].docs_blocks;
+            stats->freqs_blocks_decoded += b->cls_stats[c].freqs_blocks;
+            stats->block_max_examined += b->cls_stats[c].block_max_examined;
+            stats->algorithmic_bytes += b->cls_stats[c].algorithmic_bytes;
+            stats->postings_scored += b->cls_stats[c].postings_scored;
+            stats->rounds += b->cls_stats[c].rounds;
+        }
+    }
+    return DS2I_OK;
+}
+
+// results of the last finished run, from the pinned mirror
+void copy_results(const ds2i_hip_batch* b, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len, uint64_t* out_freq_sum) {
+    const size_t nq = b->nq;
+    if (!nq) return;
+    const uint8_t* h = (const uint8_t*)b->h_out.p;
+    const bool ranked = (b->op & 0xFF) >= DS2I_OP_RANKED_AND;
+    if (out_count) std::memcpy(out_count, h + b->o_count, 8 * nq);
+    if (out_topk && ranked) std::memcpy(out_topk, h + b->o_topk, 4 * nq * b->k); // and / or have no top-k (k is ignored)
+    if (out_topk_len) std::memcpy(out_topk_len, h + b->o_topk_len, 4 * nq);
+    if (out_freq_sum) std::memcpy(out_freq_sum, h + b->o_freq_sum, 8 * nq);
+}
+
+} // namespace
+
+void ds2i_batch_destroy(ds2i_hip_batch* b) {
+    if (!b) return;
+    if (b->seed) ds2i_batch_destroy(b->seed);
+    (void)hipSetDevice(b->idx->device);
+    if (b->launched) (void)hipEventSynchronize(b->ev_done); // never free buffers under a running kernel
+    if (b->ev_up) {
+        (void)hipEventDestroy(b->ev_up);
+        (void)hipEventDestroy(b->ev_clear);
+        (void)hipEventDestroy(b->ev_done);
+        for (int c = 0; c < NCLS; ++c) {
+            (void)hipEventDestroy(b->ev_c0[c]);
+            (void)hipEventDestroy(b->ev_c1[c]);
+        }
+    }
+    delete b; // DevBuf / PinBuf members release their memory
+}
+
+struct ds2i_hip_pipeline {
+    ds2i_hip_index* idx = nullptr;
+    std::vector<ds2i_hip_batch*> slots;
+    std::vector<uint64_t> slot_ticket;
+    std::vector<char> busy;
+    uint64_t next_ticket = 0;
+    ds2i_hip_batch* last_waited = nullptr;
+};
+
+extern "C" {
+
+void ds2i_hip_batch_free(ds2i_hip_batch* b) { ds2i_batch_destroy(b); }
+
+int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                           const uint32_t* query_offsets, uint32_t nq, int want_matches, ds2i_hip_batch** out) {
+    if (!idx || !out) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
+    HIP_OK(hipSetDevice(idx->device));
+    std::unique_ptr<ds2i_hip_batch, void (*)(ds2i_hip_batch*)> b(new ds2i_hip_batch, ds2i_batch_destroy);
+    b->idx = idx;
+    int rc = plan_batch(b.get(), op, k, terms, query_offsets, nq, want_matches);
+    if (!rc) rc = upload_batch(b.get());
+    if (rc) return rc;
+    HIP_OK(hipEventSynchronize(b->ev_up));
+    *out = b.release();
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_run: null batch");
+    HIP_OK(hipSetDevice(b->idx->device));
+    int rc = launch_batch(b);
+    if (!rc) rc = finish_batch(b, stats);
+    return rc;
+}
+
+// GPU-side counterpart of profile_queries.cpp: per-block decode counts of the batch (input of the block_mixed
+// optimiser, ds2i_hybrid_*). Counting happens in instrumented runs only and accumulates over runs.
+int ds2i_hip_batch_enable_block_profile(ds2i_hip_batch* b) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_enable_block_profile: null batch");
+    ds2i_hip_index* idx = b->idx;
+    if (idx->kind >= DS2I_OPT) return ds2i_set_error(DS2I_EINVAL, "the block access profile exists for block indexes only");
+    HIP_OK(hipSetDevice(idx->device));
+    const size_t bytes = 8 * (size_t)(idx->total_blocks ? idx->total_blocks : 1);
+    HIP_OK(b->d_prof.reserve(bytes));
+    HIP_OK(hipMemset(b->d_prof.p, 0, bytes));
+    b->profile_on = true;
+    b->prof_ptr = (unsigned int*)b->d_prof.p; // the seed pass decodes blocks too: launch_batch hands it the same buffer
+    return DS2I_OK;
+}
+int ds2i_hip_batch_block_profile(ds2i_hip_batch* b, uint32_t* counts, uint64_t capacity, uint64_t* total_blocks) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_block_profile: null batch");
+    ds2i_hip_index* idx = b->idx;
+    if (total_blocks) *total_blocks = idx->total_blocks;
+    if (!counts) return DS2I_OK;
+    if (!b->profile_on) return ds2i_set_error(DS2I_EINVAL, "block profile not enabled on this batch");
+    if (capacity < 2 * idx->total_blocks) return ds2i_set_error(DS2I_EINVAL, "counts buffer too small (2 per block)");
+    HIP_OK(hipSetDevice(idx->device));
+    HIP_OK(hipMemcpy(counts, b->d_prof.p, 8 * (size_t)idx->total_blocks, hipMemcpyDeviceToHost));
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_set_instrumented(ds2i_hip_batch* b, int on) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_set_instrumented: null batch");
+    b->instrument = on != 0;
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries) {
+    if (!b || !out || cls < 0 || cls >= NCLS) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_class_stats: bad argument");
+    out->kernel_ms = b->cls_ms[cls];
+    out->docs_blocks_decoded = b->cls_stats[cls].docs_blocks;
+    out->freqs_blocks_decoded = b->cls_stats[cls].freqs_blocks;
+    out->block_max_examined = b->cls_stats[cls].block_max_examined;
+    out->algorithmic_bytes = b->cls_stats[cls].algorithmic_bytes;
+    out->postings_scored = b->cls_stats[cls].postings_scored;
+    out->rounds = b->cls_stats[cls].rounds;
+    if (nqueries) *nqueries = b->nqcls[cls];
+    return DS2I_OK;
+}
+
+// diagnostic: phase cycle sums of class `cls` (all zero unless built with -DDS2I_PHASE_TIMING)
+int ds2i_hip_batch_phase_cycles(ds2i_hip_batch* b, int cls, uint64_t* out, int n) {
+    if (!b || !out || cls < 0 || cls >= NCLS) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_phase_cycles: bad argument");
+    for (int i = 0; i < n && i < ds2i_dev::PH_COUNT; ++i) out[i] = b->cls_stats[cls].phase_cycles[i];
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_fetch(ds2i_hip_batch* b, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len,
+                         uint64_t* out_freq_sum) {
+    if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch: null batch");
+    if (!b->launched) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch: the batch has not been run");
+    HIP_OK(hipSetDevice(b->idx->device));
+    HIP_OK(hipEventSynchronize(b->ev_done));
+    copy_results(b, out_count, out_topk, out_topk_len, out_freq_sum);
+    return DS2I_OK;
+}
+
+int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total) {
+    if (!b || !total) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_match_total: null argument");
+    *total = b->want_matches ? b->match_off[b->nq] : 0; // capacity: 128 per block of each query's shortest list
+    return DS2I_OK;
+}
+
+// On return matches of query q occupy [match_offsets[q], match_offsets[q] + out_count[q]); the device
+// buffer holds one segment per work unit (at 128*blk_begin), compacted here on the host.
+int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches) {
+    if (!b || !match_offsets || !matches) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch_matches: null argument");
+    if (!b->want_matches) return ds2i_set_error(DS2I_EINVAL, "batch was prepared without want_matches");
+    if (!b->launched) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_fetch_matches: the batch has not been run");
+    HIP_OK(hipSetDevice(b->idx->device));
+    HIP_OK(hipEventSynchronize(b->ev_done));
+    for (size_t i = 0; i <= b->nq; ++i) match_offsets[i] = b->match_off[i];
+    const size_t total = (size_t)b->match_off[b->nq];
+    if (!total) return DS2I_OK;
+    HIP_OK(hipMemcpy(matches, b->d_matches.p, 4 * total, hipMemcpyDeviceToHost));
+    if (b->nsplit) {
+        std::vector<unsigned long long> ucount(b->nunits);
+        HIP_OK(hipMemcpy(ucount.data(), b->d_scr.at<uint8_t>(b->o_unit_count), 8 * (size_t)b->nunits, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < b->nq; ++q) {
+            const uint32_t u0 = b->q_unit_off[q], u1 = b->q_unit_off[q + 1];
+            if (u1 - u0 < 2) continue;
+            uint32_t* base = matches + b->match_off[q];
+            size_t w = 0;
+            for (uint32_t u = u0; u < u1; ++u) {
+                const uint32_t* seg = base + 128ull * b->units[u].blk_begin;
+                std::memmove(base + w, seg, 4 * (size_t)ucount[u]);
+                w += (size_t)ucount[u];
+            }
+        }
+    }
+    return DS2I_OK;
+}
+
+// One-shot form: the slot (pinned staging, device blocks, events) is cached in the index handle, so repeated calls
+// -- the per-query latency loop of the `queries` driver, the Python op(index, terms) form -- allocate nothing.
+int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
+                         const uint32_t* query_offsets, uint32_t nq, uint64_t* out_count, float* out_topk,
+                         uint32_t* out_topk_len, ds2i_hip_stats* stats) {
+    if (!idx) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_query_batch: null index");
+    HIP_OK(hipSetDevice(idx->device));
+    if (!idx->oneshot) {
+        idx->oneshot = new ds2i_hip_batch;
+        idx->oneshot->idx = idx;
+    }
+    ds2i_hip_batch* b = idx->oneshot;
+    b->profile_on = false;
+    // the counters cost throughput: collected only when the caller asks for them (stats given, no DS2I_OP_NO_COUNTERS)
+    b->instrument = stats != nullptr && !(op & DS2I_OP_NO_COUNTERS);
+    int rc = plan_batch(b, op, k, terms, query_offsets, nq, 0);
+    if (!rc) rc = upload_batch(b);
+    if (!rc) rc = launch_batch(b);
+    if (!rc) rc = finish_batch(b, stats);
+    if (!rc) copy_results(b, out_count, out_topk, out_topk_len, nullptr);
+    return rc;
+}
+
+// ---------------------------------------------------------------- pipelined form
+int ds2i_hip_pipeline_create(ds2i_hip_index* idx, uint32_t depth, ds2i_hip_pipeline** out) {
+    if (!idx || !out || depth == 0 || depth > 16) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_create: bad argument (depth in [1,16])");
+    ds2i_hip_pipeline* p = new ds2i_hip_pipeline;
+    p->idx = idx;
+    for (uint32_t i = 0; i < depth; ++i) {
+        ds2i_hip_batch* b = new ds2i_hip_batch;
+        b->idx = idx;
+        b->instrument = false;
+        p->slots.push_back(b);
+    }
+    p->slot_ticket.assign(depth, 0);
+    p->busy.assign(depth, 0);
+    *out = p;
+    return DS2I_OK;
+}
+
+void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p) {
+    if (!p) return;
+    for (auto* b : p->slots) ds2i_batch_destroy(b);
+    delete p;
+}
+
+int ds2i_hip_pipeline_submit(ds2i_hip_pipeline* p, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets,
+                             uint32_t nq, uint64_t* ticket) {
+    if (!p || !ticket) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_submit: null argument");
+    const size_t slot = (size_t)(p->next_ticket % p->slots.size());
+    if (p->busy[slot]) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_pipeline_submit: all slots in flight; wait for the oldest ticket first");
+    HIP_OK(hipSetDevice(p->idx->device));
+    ds2i_hip_batch* b = p->slots[slot];
+    int rc = plan_batch(b, op, k, terms, query_offsets, nq, 0);
+    if (!rc) rc = upload_batch(b);
+    if (!rc) rc = launch_batch(b);
+    if (rc) return rc;
+    p->busy[slot] = 1;
+    p->slot_ticket[slot] = p->next_ticket;
+    *ticket = p->next_ticket++;
+    return DS2I_OK;
+}
+
+int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_count, float* out_topk, uint32_t* out_topk_len,
+                           ds2i_hip_stats* stats) {
+    if (!p) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_wait: null pipeline");
+    const size_t slot = (size_t)(ticket % p->slots.size());
+    if (!p->busy[slot] || p->slot_ticket[slot] != ticket)
+        return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_wait: unknown or already collected ticket");
+    HIP_OK(hipSetDevice(p->idx->device));
+    ds2i_hip_batch* b = p->slots[slot];
+    int rc = finish_batch(b, stats);
+    p->busy[slot] = 0;
+    if (rc) return rc;
+    p->last_waited = b;
+    copy_results(b, out_count, out_topk, out_topk_len, nullptr);
+    return DS2I_OK;
+}
+
+// per kernel class of the ticket collected last (hipEvent duration of the class kernel, counters when instrumented)
+int ds2i_hip_pipeline_class_stats(ds2i_hip_pipeline* p, int cls, ds2i_hip_stats* out, uint32_t* nqueries) {
+    if (!p || !p->last_waited) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_class_stats: no collected ticket");
+    return ds2i_hip_batch_class_stats(p->last_waited, cls, out, nqueries);
+}
+
+int ds2i_hip_pipeline_set_instrumented(ds2i_hip_pipeline* p, int on) {
+    if (!p) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_set_instrumented: null pipeline");
+    for (auto* b : p->slots) b->instrument = on != 0;
+    return DS2I_OK;
+}
+
+} // extern "C"

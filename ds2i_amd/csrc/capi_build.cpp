@@ -115,6 +115,19 @@ int ds2i_encode_block(int codec, const uint32_t* values, uint32_t sum, uint32_t 
     return 0;
     DS2I_CATCH
 }
+// the host half of the BM25 scorer exactly as the query path uses it (query weights in plan_batch, max_term_weight in
+// the wand builder); element-wise so that tests can hold it against the reference's bm25.hpp
+int ds2i_bm25_query_term_weight(const uint64_t* qtf, const uint64_t* df, uint64_t num_docs, uint64_t n, float* out) {
+    if (!qtf || !df || !out) return ds2i_set_error(-1, "ds2i_bm25_query_term_weight: null argument");
+    for (uint64_t i = 0; i < n; ++i) out[i] = ds2i_host::bm25::query_term_weight(qtf[i], df[i], num_docs);
+    return 0;
+}
+int ds2i_bm25_doc_term_weight(const uint64_t* freq, const float* norm_len, uint64_t n, float* out) {
+    if (!freq || !norm_len || !out) return ds2i_set_error(-1, "ds2i_bm25_doc_term_weight: null argument");
+    for (uint64_t i = 0; i < n; ++i) out[i] = ds2i_host::bm25::doc_term_weight(freq[i], norm_len[i]);
+    return 0;
+}
+
 int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out) {
     if (!out) return ds2i_set_error(-1, "ds2i_encode_vbyte: null argument");
     auto* blob = new ds2i_blob;

@@ -1,0 +1,129 @@
+// Shared by the C-ABI translation units (capi.cpp: index handle, capi_batch.cpp: query batches and the
+// pipelined submit/wait form): the index handle, RAII device / pinned buffers, error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ds2i_hip.h"
+#include "abi_structs.hpp"
+#include "capi_error.hpp"
+
+#define HIP_OK(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return ds2i_set_error(DS2I_EDEVICE, m_.c_str());                                       \
+        }                                                                                          \
+    } while (0)
+
+// Kernel classes by number of distinct query terms: <=2, <=4, <=8, <=16 keep every list's current block in LDS
+// (footprint per wave grows with the class); class 4 ("long", > 16 terms -- the reference has no limit,
+// queries.hpp:35-86) keeps the per-list state in a global scratch area and runs the one-document-per-step traversal.
+static const int NCLS = 5;
+static const int CLS_LONG = 4;
+static inline int class_of(size_t nterms) { return nterms <= 2 ? 0 : nterms <= 4 ? 1 : nterms <= 8 ? 2 : nterms <= 16 ? 3 : 4; }
+
+// grow-only device allocation: a reused batch slot re-allocates only when a batch needs more than any before it
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() {}
+    DevBuf(DevBuf const&) = delete;
+    DevBuf& operator=(DevBuf const&) = delete;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        release();
+        const size_t c = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, c);
+        if (e == hipSuccess) cap = c; else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+    template <class T> T* at(size_t byte_off) const { return (T*)((uint8_t*)p + byte_off); }
+};
+
+// grow-only pinned host allocation (async H2D / D2H need page-locked memory to overlap with kernels)
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() {}
+    PinBuf(PinBuf const&) = delete;
+    PinBuf& operator=(PinBuf const&) = delete;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        release();
+        const size_t c = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, c, hipHostMallocDefault);
+        if (e == hipSuccess) cap = c; else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~PinBuf() { release(); }
+    template <class T> T* at(size_t byte_off) const { return (T*)((uint8_t*)p + byte_off); }
+};
+
+struct ds2i_hip_batch;
+
+struct ds2i_hip_index {
+    int device = 0, kind = 0, num_cus = 256;
+    uint64_t size = 0, num_docs = 0;
+    uint8_t* d_arena = nullptr;
+    uint64_t arena_bytes = 0;
+    float* d_norm_lens = nullptr;
+    bool has_wand = false;
+    std::vector<uint64_t> list_off; // arena offsets, size+1 (list i spans [off[i], end[i]))
+    std::vector<uint64_t> list_end;
+    std::vector<uint32_t> list_n;
+    std::vector<uint32_t> list_nb;  // blocks (block indexes) / chunks (opt index) per list
+    std::vector<uint64_t> list_aux0, list_aux1; // opt index: docs / freqs sequence bit offsets
+    std::vector<uint64_t> list_blk_base;        // blocks / chunks of all preceding lists (access profile, skip table, block-max weights)
+    uint64_t total_blocks = 0;
+    uint8_t* d_skip = nullptr;                  // block indexes: interleaved {block_max, block end offset} per block
+    uint8_t* d_bits0 = nullptr;     // opt index: docs bit vector
+    uint8_t* d_bits1 = nullptr;     // opt index: freqs bit vector
+    float* d_bmw = nullptr;         // per block / chunk: max doc_term_weight of its postings (ranked_and pruning), or null
+    std::vector<float> list_bmw;    // per list: max over its blocks of d_bmw (device-computed)
+    std::vector<float> list_topbmw; // per list: its DS2I_HIP_MAX_K largest block weights, descending, padded with 0
+    uint64_t extra_bytes = 0;
+    std::vector<float> max_term_weight;
+    // class kernels of consecutive batches queue up on the class streams; uploads and merges / result copies have
+    // their own streams so that the next batch's H2D never waits behind the previous batch's merge
+    hipStream_t stream[NCLS] = {};
+    hipStream_t s_up = nullptr, s_merge = nullptr;
+    unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
+    ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)
+};
+
+void ds2i_batch_destroy(ds2i_hip_batch* b); // capi_batch.cpp
+
+// index[term] as the kernels see it (weights left at 0: they depend on the query)
+static inline ds2i_dev::QTerm ds2i_make_qterm(const ds2i_hip_index* idx, uint32_t term) {
+    ds2i_dev::QTerm qt;
+    const bool freq_layout = idx->kind >= DS2I_OPT;
+    qt.list_off = idx->list_off[term];
+    qt.list_end = idx->list_end[term];
+    qt.n = idx->list_n[term];
+    qt.q_weight = 0.f;
+    qt.max_weight = 0.f;
+    qt.term = freq_layout ? idx->list_nb[term] : term;
+    qt.aux0 = freq_layout ? idx->list_aux0[term] : idx->list_blk_base[term];
+    qt.aux1 = freq_layout ? idx->list_aux1[term] : 0;
+    qt.blk_base = (uint32_t)idx->list_blk_base[term];
+    qt.max_bmw = 0.f;
+    qt.suf_bmw = 0.f;
+    qt.floor1 = 0.f;
+    return qt;
+}

@@ -20,8 +20,10 @@
 namespace ds2i_dev {
 
 enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCID, M_FREQ_LO, M_FREQ_HI, M_FDEC,
-       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PBASE /* first block of the list in the access profile */,
-       M_WORDS }; // 24 dwords per list slot
+       M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PBASE /* blocks (chunks) of all preceding lists: the list's base in the access profile, skip table, bmw[] */,
+       M_CBW /* q_weight * bmw of the current block (float bits) */,
+       M_SUF /* sum of the later lists' q_weight * list max bmw (float bits) */,
+       M_WORDS }; // 26 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
 #define PT_BEGIN(cx) const unsigned long long pt_t0_ = __builtin_readcyclecounter()
@@ -356,6 +358,9 @@ struct CtxT {
             setm(s, M_CUR, 0xFFFFFFFFu);
             setm(s, M_BMAX, 0);
             setm(s, M_FDEC, 0);
+            setm(s, M_PBASE, t.blk_base);
+            setm(s, M_CBW, 0);
+            setm(s, M_SUF, __float_as_uint(t.suf_bmw));
             wave_sync();
             s_bytes += 16 + 8; // two collection offsets + gamma(occurrences), n
             return;
@@ -374,7 +379,9 @@ struct CtxT {
         setm(s, M_CUR, 0xFFFFFFFFu); // no block decoded yet
         setm(s, M_BMAX, 0);
         setm(s, M_FDEC, 0);
-        if (STATS || META::SKIPTAB) setm(s, M_PBASE, (uint32_t)t.aux0);
+        setm(s, M_PBASE, t.blk_base);
+        setm(s, M_CBW, 0);
+        setm(s, M_SUF, __float_as_uint(t.suf_bmw));
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset
@@ -389,17 +396,32 @@ struct CtxT {
     // first block >= from whose block_max >= lb, or nb if none. The reference scans block_max
     // linearly (block_posting_list.hpp:134-137); here one wave probes 64 entries at a time: first the
     // 64 entries right after the current block (short skips), then a 64-ary search over the rest.
+    // `bmax` receives block_max of the returned block (valid iff the result < nb).
+    // With a weight table `wtab` (bmw[] of this list) the block's max weight rides along: its load is issued together
+    // with the block_max probe, so the caller's bound test costs no extra round trip. `w` is valid iff result < nb.
     DS2I_DEV uint32_t find_block(uint32_t s, uint32_t from, uint32_t lb) {
+        uint32_t bmax;
+        float w;
+        return find_block(s, from, lb, bmax, nullptr, w);
+    }
+    DS2I_DEV uint32_t find_block(uint32_t s, uint32_t from, uint32_t lb, uint32_t& bmax, const float* wtab, float& w) {
         const uint8_t* maxs = ptr(s, M_MAXS_LO);
         const uint32_t nb = m(s, M_NB);
         const uint32_t lane = lane_id();
+        bmax = 0;
+        w = 0.f;
         if (from >= nb) return nb;
         {
             uint32_t idx = from + lane;
             uint32_t v = (idx < nb) ? ld32(maxs + 4ull * idx) : 0xFFFFFFFFu;
+            float wv = 0.f;
+            if (wtab && idx < nb) wv = wtab[idx];
             uint64_t hit = ballot(v >= lb);
             if (hit) {
-                uint32_t blk = from + (uint32_t)__builtin_ctzll(hit);
+                const uint32_t f = (uint32_t)__builtin_ctzll(hit);
+                uint32_t blk = from + f;
+                bmax = bcast(v, f);
+                w = __uint_as_float(bcast(__float_as_uint(wv), f));
                 return blk < nb ? blk : nb;
             }
         }
@@ -419,9 +441,14 @@ struct CtxT {
         }
         uint32_t idx = lo + lane;
         uint32_t v = (idx < hi) ? ld32(maxs + 4ull * idx) : 0xFFFFFFFFu;
+        float wv = 0.f;
+        if (wtab && idx < hi) wv = wtab[idx];
         uint64_t hit = ballot(v >= lb);
         if (!hit) return nb;
-        uint32_t blk = lo + (uint32_t)__builtin_ctzll(hit);
+        const uint32_t f = (uint32_t)__builtin_ctzll(hit);
+        uint32_t blk = lo + f;
+        bmax = bcast(v, f);
+        w = __uint_as_float(bcast(__float_as_uint(wv), f));
         return blk < hi ? blk : nb;
     }
 
@@ -429,13 +456,20 @@ struct CtxT {
     // entry of the block before it rides in the neighbouring lane), so the decode that follows needs no table load.
     // Same result as find_block(); `info` is valid iff the returned block < nb.
     DS2I_DEV uint32_t find_block_info(uint32_t s, uint32_t from, uint32_t lb, BlockInfo& info) {
+        float w;
+        return find_block_info(s, from, lb, info, nullptr, w);
+    }
+    DS2I_DEV uint32_t find_block_info(uint32_t s, uint32_t from, uint32_t lb, BlockInfo& info, const float* wtab, float& w) {
         const uint32_t nb = m(s, M_NB);
         const uint32_t lane = lane_id();
+        w = 0.f;
         if (from >= nb) return nb;
         const uint2* tab = skip + m(s, M_PBASE);
+        float wv = 0.f;
         auto finish = [&](uint2 e, uint32_t first_idx, uint64_t hit) -> uint32_t { // lane j holds entry first_idx + j
             const uint32_t f = (uint32_t)__builtin_ctzll(hit);
             const uint32_t blk = first_idx + f;
+            w = __uint_as_float(bcast(__float_as_uint(wv), f));
             info.bmax = bcast(e.x, f);
             info.next_ep = bcast(e.y, f);
             const uint32_t pf = f ? f - 1 : 0;
@@ -449,6 +483,7 @@ struct CtxT {
             const uint32_t idx = first + lane;
             uint2 e = make_uint2(0xFFFFFFFFu, 0u);
             if (idx < nb) e = tab[idx];
+            if (wtab && idx < nb) wv = wtab[idx];
             uint64_t hit = ballot(idx >= from && idx < nb && e.x >= lb);
             if (hit) return finish(e, first, hit);
             if (first + 64 >= nb) return nb;
@@ -471,6 +506,7 @@ struct CtxT {
         const uint32_t idx = first + lane;
         uint2 e = make_uint2(0xFFFFFFFFu, 0u);
         if (idx < hi) e = tab[idx];
+        if (wtab && idx < hi) wv = wtab[idx];
         uint64_t hit = ballot(idx >= lo && idx < hi && e.x >= lb);
         if (!hit) return nb;
         return finish(e, first, hit);

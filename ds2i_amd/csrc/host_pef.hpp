@@ -141,52 +141,55 @@ inline void seq_write(bitvec_builder& bvb, const uint64_t* v, uint64_t universe,
 // ---------------------------------------------------------------- optimal partition (approximate DP)
 struct partition_config { double eps1 = 0.03, eps2 = 0.3; uint64_t fix_cost = 64; };
 
+// Shortest path over the sparsified partition DAG of "Partitioned Elias-Fano indexes" (Ottaviano & Venturini,
+// SIGIR'14, section 5): node p = "the first p elements are partitioned", edge (i -> e) = one partition holding
+// elements [i, e) at cost_fun(universe of the run, e - i). Only edges of geometrically growing cost classes are kept:
+// class c may extend a partition starting at i while its cost stays below budget[c] = c_min * (1+eps2)^c, and classes
+// stop at c_min / eps1. All classes start at the same node i, so the only per-class state is how far the class has
+// reached (`reach`) and the largest element it covers; the run's smallest possible value follows from i alone.
+// Parameters, edge order and the strict `<` of the relaxation match the reference builder
+// (optimal_partition.hpp:67-121, eps1 = 0.03, eps2 = 0.3, configuration.hpp), so the chosen end points -- and with
+// them the image -- are the ones ds2i's create_freq_index would choose.
 template <class CostFun>
 inline std::vector<uint32_t> optimal_partition(const uint64_t* seq, uint64_t universe, uint64_t size, CostFun cost_fun,
                                                double eps1, double eps2) {
-    typedef uint64_t cost_t;
-    struct window { uint64_t start = 0, end = 0, min_p = 0, max_p = 0; cost_t cost_upper_bound = 0; };
-    const cost_t single_block_cost = cost_fun(universe, size);
-    std::vector<cost_t> min_cost(size + 1, single_block_cost);
-    min_cost[0] = 0;
-    std::vector<window> windows;
-    const cost_t cost_lb = cost_fun(1, 1);
-    cost_t cost_bound = cost_lb;
-    while (eps1 == 0 || cost_bound < cost_lb / eps1) {
-        window w;
-        w.min_p = seq[0];
-        w.cost_upper_bound = cost_bound;
-        windows.push_back(w);
-        if (cost_bound >= single_block_cost) break;
-        cost_bound = (cost_t)(cost_bound * (1 + eps2));
+    const uint64_t whole = cost_fun(universe, size);
+    std::vector<uint64_t> dist(size + 1, whole); // cheapest known cost of partitioning the first p elements
+    std::vector<uint32_t> parent(size + 1, 0);
+    dist[0] = 0;
+    std::vector<uint64_t> budget, reach, reach_top;
+    const uint64_t c_min = cost_fun(1, 1);
+    for (uint64_t bnd = c_min; eps1 == 0 || bnd < c_min / eps1; bnd = (uint64_t)(bnd * (1 + eps2))) {
+        budget.push_back(bnd);
+        if (bnd >= whole) break;
     }
-    std::vector<uint32_t> path(size + 1, 0);
+    reach.assign(budget.size(), 0);
+    reach_top.assign(budget.size(), 0);
     for (uint64_t i = 0; i < size; ++i) {
-        uint64_t last_end = i + 1;
-        for (auto& w : windows) {
-            while (w.end < last_end) { w.max_p = seq[w.end]; ++w.end; }
-            cost_t window_cost;
-            while (true) {
-                window_cost = cost_fun(w.max_p - w.min_p + 1, w.end - w.start);
-                if (min_cost[i] + window_cost < min_cost[w.end]) {
-                    min_cost[w.end] = min_cost[i] + window_cost;
-                    path[w.end] = (uint32_t)i;
+        const uint64_t floor_value = i ? seq[i - 1] + 1 : seq[0]; // smallest value a partition starting at i can hold
+        const uint64_t here = dist[i];
+        uint64_t at_least = i + 1; // a class never ends before the previous (cheaper) class did
+        for (size_t c = 0; c < budget.size(); ++c) {
+            uint64_t e = reach[c], top = reach_top[c];
+            while (e < at_least) top = seq[e++];
+            for (;;) {
+                const uint64_t edge = cost_fun(top - floor_value + 1, e - i);
+                if (here + edge < dist[e]) {
+                    dist[e] = here + edge;
+                    parent[e] = (uint32_t)i;
                 }
-                last_end = w.end;
-                if (w.end == size) break;
-                if (window_cost >= w.cost_upper_bound) break;
-                w.max_p = seq[w.end];
-                ++w.end;
+                if (e == size || edge >= budget[c]) break;
+                top = seq[e++];
             }
-            w.min_p = seq[w.start] + 1;
-            ++w.start;
+            reach[c] = e;
+            reach_top[c] = top;
+            at_least = e;
         }
     }
-    std::vector<uint32_t> partition;
-    uint64_t cur = size;
-    while (cur != 0) { partition.push_back((uint32_t)cur); cur = path[cur]; }
-    std::reverse(partition.begin(), partition.end());
-    return partition;
+    std::vector<uint32_t> ends;
+    for (uint64_t p = size; p != 0; p = parent[p]) ends.push_back((uint32_t)p);
+    std::reverse(ends.begin(), ends.end());
+    return ends;
 }
 
 // ---------------------------------------------------------------- partitioned sequence

@@ -103,15 +103,47 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
             if (!body(i_)) break;                                    \
     }
 
+// Slack of the ranked_and pruning bound. A document's score is the float32 sum of its term scores in list order
+// (queries.hpp:372-380); the bound adds, in a different association, the current blocks' weights of the lists already
+// positioned and one precomputed suffix sum for the lists still to come. Both evaluate the same real sum of <= 17
+// non-negative terms, so they differ by at most ~3 * 17 * 2^-24 relative; 2^-17 covers that with margin and costs no
+// pruning power. Everything else about the bound is exact: float multiplication and addition are monotone, and bmw[]
+// holds the maxima of the very doc_term_weight values the scoring code computes.
+static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
+
+// Waves per SIMD the conjunctive kernels are compiled for. <=2 lists: 8 (64 VGPRs; latency hiding wins); beyond that
+// LDS caps the residency anyway (7 / 12 / 22 KiB per wave of the 160 KiB per CU), and without a bound the register
+// allocator lets the unrolled list loops balloon (237 VGPRs, 2 waves/SIMD for the 4-list kernel when left alone).
+#ifndef DS2I_OCC2
+#define DS2I_OCC2 8
+#endif
+#define CONJ_WAVES(T) ((T) <= 2 ? DS2I_OCC2 : (T) <= 4 ? 5 : (T) <= 8 ? 3 : 1)
+
+// LDS of the conjunctive kernels: the shared layout plus, for ranked_and's score-first rounds, the norm_len and the
+// list-0 term score of every posting of list 0's current block
+template <int TMAX, bool META_IN_LDS, bool RANKED>
+struct LdsConj : Lds<TMAX, META_IN_LDS> {
+    float nl[RANKED ? 128 : 1];
+    float part0[RANKED ? 128 : 1];
+};
+
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
-__global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
-    __shared__ Lds<TMAX, !REG> L;
+    __shared__ LdsConj<TMAX, !REG, RANKED> L;
     const uint32_t lane = lane_id();
     CtxT<CODEC_T, META, STATS> cx = make_ctx<CODEC_T, META, STATS>(L, a);
+    // ranked_and only: per-block max doc_term_weight table (null = no pruning). Three levels, all exact (the bounds
+    // are true upper bounds of the float32 score and topk_queue::insert is strict, queries.hpp:157-172):
+    //   * blocks of list 0 whose bound cannot enter the heap are skipped without being decoded (skip_list0);
+    //   * SCORE-FIRST rounds, once the heap is full or a floor is known: the list-0 term score of every candidate is
+    //     computed first; a candidate goes on to list i only while its partial score + the later lists' list maxima can
+    //     still enter the heap, so the long lists are probed -- and their blocks decoded -- for few candidates;
+    //   * before list i's next block is decoded, the best alive partial score + that block's max weight is tested.
+    const float* const bmw = RANKED ? a.bmw : nullptr;
     // one work unit per (single-wave) workgroup, costliest units first: the hardware dispatcher
     // interleaves the workgroups of the concurrently running LDS classes as resources free up
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
@@ -137,28 +169,132 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
         DS2I_LIST_LOOP(0, bind_one)
         const unsigned long long mbase = a.out_matches ? a.match_off[q] + 128ull * u.blk_begin : 0;
         const unsigned long long mcap = a.out_matches ? 128ull * (u.blk_end - u.blk_begin) : 0;
+        // ---- pruning state (ranked_and with a bmw table)
+        // The parts of a split query share a SCORE HISTOGRAM (256 buckets over [0, the query's score bound]): every
+        // score that enters a part's heap is counted, and a part's floor is the lower edge of the highest bucket with
+        // >= k documents at or above it -- a lower bound of the whole query's k-th score that tightens with every part's
+        // progress, not just with the best single part (all parts add a document's terms in the same order, so the
+        // scores are comparable bit for bit; a dropped document scores <= the floor <= the final threshold).
+        const bool shared_floor = RANKED && bmw && !whole && a.q_hist;
+        unsigned int* const hist = shared_floor ? a.q_hist + 256u * q : nullptr;
+        float h_scale = 0.f, h_inv = 0.f; // bucket b covers [b * h_scale, (b + 1) * h_scale)
+        if (shared_floor) {
+            const float mx = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw)));
+            h_scale = mx * (1.0f / 256.0f);
+            h_inv = mx > 0.f ? 256.0f / mx : 0.f;
+        }
+        auto adopt_floor = [&]() __attribute__((always_inline)) {
+            // lane l reads buckets 255-4l .. 252-4l (highest scores in lane 0); suffix counts by one wave scan
+            // (relaxed agent-scope loads: the counts are updated by atomics of other CUs and must not come from a stale L1 line)
+            const unsigned int* hp = hist + 252u - 4u * lane;
+            uint4 hv;
+            hv.x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hv.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hv.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hv.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t mine = hv.x + hv.y + hv.z + hv.w;
+            const uint32_t incl = wave_incl_scan(mine);
+            const uint64_t full = ballot(incl >= tk.k);
+            if (full) {
+                const uint32_t fl = (uint32_t)__builtin_ctzll(full);
+                // inside lane fl: buckets from the top are w, z, y, x
+                const uint32_t before = bcast(incl - mine, fl);
+                const uint32_t bw = bcast(hv.w, fl), bz = bcast(hv.z, fl), by = bcast(hv.y, fl);
+                uint32_t bucket = 255u - 4u * fl;
+                uint32_t c = before + bw;
+                if (c < tk.k) { --bucket; c += bz; if (c < tk.k) { --bucket; c += by; if (c < tk.k) --bucket; } }
+                const float f = (float)bucket * h_scale * (1.0f - 1.0f / 1048576.0f);
+                if (f > tk.floor) tk.floor = f;
+            }
+        };
+        if (RANKED && bmw && nt == 1) // k blocks of the list hold a document reaching floor1 (computed at upload)
+            tk.floor = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1)));
+        if (shared_floor) adopt_floor();
+        auto can_prune = [&]() { return tk.n >= tk.k || tk.floor > 0.f; };
+        const float* const w0tab = bmw ? bmw + cx.m(0, M_PBASE) : nullptr;
+        // first block >= blk of list 0, inside the unit, whose bound (its own max weight + the other lists' list maxima)
+        // can enter the heap: 64 table entries per probe, nothing decoded
+        auto skip_list0 = [&](uint32_t blk) __attribute__((always_inline)) -> uint32_t {
+            if (!RANKED || !bmw || !can_prune()) return blk;
+            const float qw0 = __uint_as_float(cx.m(0, M_QW)), suf0 = __uint_as_float(cx.m(0, M_SUF));
+            while (blk < u.blk_end) {
+                const uint32_t idx = blk + lane;
+                float w = 0.f;
+                if (idx < u.blk_end) w = w0tab[idx];
+                const float ub = (qw0 * w + suf0) * BOUND_SLACK;
+                const uint64_t hit = ballot(idx < u.blk_end && tk.would_enter(ub));
+                if (hit) return blk + (uint32_t)__builtin_ctzll(hit);
+                blk += 64;
+            }
+            return u.blk_end;
+        };
         cx.s_bytes += 4;
         ++cx.s_bm_examined;
-        cx.decode_docs(0, u.blk_begin);
         uint32_t lo = 0;
+        uint32_t part_blk = 0xFFFFFFFFu; // block of list 0 whose norm_lens / list-0 scores are in L.nl / L.part0
+        // list 0 moves on: `want` = first block with block_max >= lo (or the unit's first block)
+        uint32_t want = u.blk_begin;
+        bool have_bi = false;
+        typename decltype(cx)::BlockInfo bi0;
         bool finished = false;
+        bool need0 = true;
         while (!finished) {
             ++cx.s_rounds;
-            // list 0 supplies the candidates of this round
-            if (lo > cx.m(0, M_BMAX)) {
-                uint32_t cur = cx.m(0, M_CUR);
-                uint32_t blk;
-                typename decltype(cx)::BlockInfo bi;
+            if (need0 || lo > cx.m(0, M_BMAX)) { // list 0 supplies the candidates of this round
                 const bool tabbed = META::SKIPTAB && !cx.is_pef() && cx.skip;
-                { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(0, cur + 1, lo, bi) : cx.find_block(0, cur + 1, lo); PT_END(cx, PH_FIND); }
-                if (blk >= u.blk_end) break;
-                cx.s_bm_examined += blk - cur;
-                cx.s_bytes += 4ull * (blk - cur);
-                cx.decode_docs(0, blk, tabbed ? &bi : nullptr);
+                if (!need0) {
+                    const uint32_t cur = cx.m(0, M_CUR);
+                    { PT_BEGIN(cx); want = tabbed ? cx.find_block_info(0, cur + 1, lo, bi0) : cx.find_block(0, cur + 1, lo); PT_END(cx, PH_FIND); }
+                    have_bi = tabbed;
+                    cx.s_bm_examined += want - cur;
+                    cx.s_bytes += 4ull * (want - cur);
+                }
+                if (want >= u.blk_end) break;
+                if (shared_floor) adopt_floor();
+                const uint32_t blk2 = skip_list0(want);
+                if (blk2 >= u.blk_end) break;
+                cx.decode_docs(0, blk2, (have_bi && blk2 == want) ? &bi0 : nullptr);
+                need0 = false;
             }
             uint32_t hi = cx.m(0, M_BMAX);
             const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
             bool al0 = c0 >= lo && c0 != 0xFFFFFFFFu, al1 = c1 >= lo && c1 != 0xFFFFFFFFu;
+            // ranked_and scores PROGRESSIVELY: pa0 / pa1 are the running float32 sums of this lane's two candidates in
+            // list order (queries.hpp:372-380). `sf` (wave-uniform) = the heap is full or a floor is known, so bounds
+            // can prune: then the list-0 term scores of the whole block are computed up front (once per block, kept in
+            // LDS); otherwise they are computed for the candidates that survive list 1, when they are first needed.
+            const bool sf = RANKED && bmw && can_prune();
+            float pa0 = 0.f, pa1 = 0.f;
+            bool have_p = false;
+            if constexpr (RANKED) {
+                if (sf || nt == 1) {
+                    const uint32_t cur0 = cx.m(0, M_CUR);
+                    if (part_blk != cur0) { // once per block of list 0: its freqs, the norm_lens and the list-0 term scores
+                        if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
+                        const float qw0 = __uint_as_float(cx.m(0, M_QW));
+                        const bool v0 = c0 != 0xFFFFFFFFu, v1 = c1 != 0xFFFFFFFFu;
+                        const float n0 = v0 ? a.norm_lens[c0] : 0.f, n1 = v1 ? a.norm_lens[c1] : 0.f;
+                        L.nl[lane] = n0;
+                        L.nl[lane + 64] = n1;
+                        L.part0[lane] = v0 ? qw0 * doc_term_weight(L.freqs[0][lane], n0) : 0.f;
+                        L.part0[lane + 64] = v1 ? qw0 * doc_term_weight(L.freqs[0][lane + 64], n1) : 0.f;
+                        part_blk = cur0;
+                        const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1)));
+                        cx.s_bytes += 4ull * nv;
+                        cx.s_scored += nv;
+                        wave_sync();
+                    }
+                    pa0 = L.part0[lane];
+                    pa1 = L.part0[lane + 64];
+                    have_p = true;
+                    if (sf) {
+                        const float suf0 = __uint_as_float(cx.m(0, M_SUF));
+                        al0 = al0 && tk.would_enter((pa0 + suf0) * BOUND_SLACK);
+                        al1 = al1 && tk.would_enter((pa1 + suf0) * BOUND_SLACK);
+                    }
+                }
+            }
+            bool pruned = false;
             auto probe_list = [&](auto ic) __attribute__((always_inline)) -> bool {
                 const uint32_t i = ic;
                 uint64_t b0 = ballot(al0), b1 = ballot(al1);
@@ -166,10 +302,17 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                 uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
                 if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
                     uint32_t cur = cx.m(i, M_CUR);
-                    uint32_t blk;
+                    uint32_t blk, nbmax = 0;
+                    float wnew = 0.f;
                     typename decltype(cx)::BlockInfo bi;
                     const bool tabbed = META::SKIPTAB && !cx.is_pef() && cx.skip;
-                    { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(i, cur + 1, amin, bi) : cx.find_block(i, cur + 1, amin); PT_END(cx, PH_FIND); }
+                    const float* wtab = (RANKED && sf) ? bmw + cx.m(i, M_PBASE) : nullptr;
+                    {
+                        PT_BEGIN(cx);
+                        if (tabbed) { blk = cx.find_block_info(i, cur + 1, amin, bi, wtab, wnew); nbmax = bi.bmax; }
+                        else blk = cx.find_block(i, cur + 1, amin, nbmax, wtab, wnew);
+                        PT_END(cx, PH_FIND);
+                    }
                     if (blk >= cx.m(i, M_NB)) { // list i has nothing >= amin: no further match exists
                         cx.s_bm_examined += 1;
                         cx.s_bytes += 4;
@@ -180,6 +323,27 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                     // a lazily bound list is positioned by one 64-ary search, not a scan from block 0
                     cx.s_bm_examined += (cur == 0xFFFFFFFFu) ? 1u : blk - cur;
                     cx.s_bytes += 4ull * ((cur == 0xFFFFFFFFu) ? 1u : blk - cur);
+                    bool skip_decode = false;
+                    if constexpr (RANKED) {
+                        if (sf) {
+                            // best alive partial score inside [lo, min(hi, block_max)] + this block's max weight + the
+                            // later lists' maxima: if that cannot enter the heap the block is not even decoded
+                            const uint32_t wh = nbmax < hi ? nbmax : hi;
+                            float pm = (al0 && c0 <= wh) ? pa0 : 0.f;
+                            const float p1 = (al1 && c1 <= wh) ? pa1 : 0.f;
+                            pm = p1 > pm ? p1 : pm; // scores are >= 0: their bit patterns order like the values
+                            pm = __uint_as_float(bcast(wave_incl_max_scan(__float_as_uint(pm)), 63));
+                            const float cbw = __uint_as_float(cx.m(i, M_QW)) * wnew;
+                            if (!tk.would_enter(((pm + cbw) + __uint_as_float(cx.m(i, M_SUF))) * BOUND_SLACK)) {
+                                hi = wh;
+                                skip_decode = true;
+                            }
+                        }
+                    }
+                    if (skip_decode) {
+                        pruned = true;
+                        return false;
+                    }
                     cx.decode_docs(i, blk, tabbed ? &bi : nullptr);
                 }
                 PT_BEGIN(cx);
@@ -214,14 +378,48 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                     al0 = (r0 >> lane) & 1;
                     al1 = (r1 >> lane) & 1;
                 }
-                if (RANKED || WITH_FREQS) {
+                PT_END(cx, PH_MEMBER);
+                if constexpr (RANKED) { // members take list i's term score at once
+                    if (ballot(al0) | ballot(al1)) {
+                        if (!have_p) { // (only possible at list 1) list-0 term scores of the surviving candidates
+                            if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
+                            const float qw0 = __uint_as_float(cx.m(0, M_QW));
+                            const float n0 = al0 ? a.norm_lens[c0] : 0.f, n1 = al1 ? a.norm_lens[c1] : 0.f;
+                            L.nl[lane] = n0;
+                            L.nl[lane + 64] = n1;
+                            pa0 = al0 ? qw0 * doc_term_weight(L.freqs[0][lane], n0) : 0.f;
+                            pa1 = al1 ? qw0 * doc_term_weight(L.freqs[0][lane + 64], n1) : 0.f;
+                            part_blk = 0xFFFFFFFFu; // L.nl now holds this round's survivors only
+                            have_p = true;
+                            const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(al0)) + __builtin_popcountll(ballot(al1)));
+                            cx.s_bytes += 4ull * nv;
+                            cx.s_scored += nv;
+                        }
+                        if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
+                        const float qw = __uint_as_float(cx.m(i, M_QW));
+                        const uint32_t* f = L.freqs[i];
+                        if (al0) pa0 = pa0 + qw * doc_term_weight(f[p0], L.nl[lane]);
+                        if (al1) pa1 = pa1 + qw * doc_term_weight(f[p1], L.nl[lane + 64]);
+                        if (sf) { // who cannot reach the heap any more drops out before the next list is touched
+                            const float sufi = __uint_as_float(cx.m(i, M_SUF));
+                            al0 = al0 && tk.would_enter((pa0 + sufi) * BOUND_SLACK);
+                            al1 = al1 && tk.would_enter((pa1 + sufi) * BOUND_SLACK);
+                        }
+                    }
+                    return true;
+                }
+                if (WITH_FREQS) {
                     if (al0) L.pos[i][lane] = (uint8_t)p0;
                     if (al1) L.pos[i][lane + 64] = (uint8_t)p1;
                 }
-                PT_END(cx, PH_MEMBER);
                 return true;
             };
             DS2I_LIST_LOOP(1, probe_list)
+            if (RANKED && pruned) { // the window [lo, hi] holds no document that could enter the heap
+                if (hi == 0xFFFFFFFFu) break;
+                lo = hi + 1;
+                continue;
+            }
             // candidates that survived every list and lie inside the window are matches
             al0 = al0 && c0 <= hi;
             al1 = al1 && c1 <= hi;
@@ -236,55 +434,40 @@ __global__ void __launch_bounds__(64, (TMAX <= 2 ? 8 : 1)) k_conjunctive(BatchAr
                     if (al1 && i1 < mcap) a.out_matches[mbase + i1] = c1;
                 }
                 count += ns;
-                if (RANKED || WITH_FREQS) {
+                if constexpr (WITH_FREQS && !RANKED) { // and_query<with_freqs> touches every matching posting's freq
                     wave_sync(); // L.pos writes visible
-#ifdef DS2I_PHASE_TIMING
-                    const unsigned long long sc_t0 = __builtin_readcyclecounter();
-                    const unsigned long long fr_before = cx.s_phase[PH_FREQS];
-#endif
-                    float nl0 = 0.f, nl1 = 0.f, sc0 = 0.f, sc1 = 0.f;
-                    if (RANKED) {
-                        if (al0) nl0 = a.norm_lens[c0];
-                        if (al1) nl1 = a.norm_lens[c1];
-                        cx.s_bytes += 4ull * ns;
-                        cx.s_scored += ns;
-                    }
                     unsigned long long fs = 0; // freqs are u32: the checksum must not wrap at 2^32
-                    auto score_list = [&](auto ic) __attribute__((always_inline)) -> bool {
+                    auto freq_list = [&](auto ic) __attribute__((always_inline)) -> bool {
                         const uint32_t i = ic;
                         if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
                         const uint32_t* f = L.freqs[i];
                         uint32_t f0 = 0, f1 = 0;
                         if (al0) f0 = f[i ? L.pos[i][lane] : lane];
                         if (al1) f1 = f[i ? L.pos[i][lane + 64] : lane + 64];
-                        if (RANKED) {
-                            float qw = __uint_as_float(cx.m(i, M_QW));
-                            if (al0) sc0 += qw * doc_term_weight(f0, nl0);
-                            if (al1) sc1 += qw * doc_term_weight(f1, nl1);
-                        } else {
-                            fs += (unsigned long long)f0 + f1;
-                        }
+                        fs += (unsigned long long)f0 + f1;
                         return true;
                     };
-                    DS2I_LIST_LOOP(0, score_list)
-                    if (WITH_FREQS && !RANKED) {
-                        for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
-                        fsum += fs;
-                    }
+                    DS2I_LIST_LOOP(0, freq_list)
+                    for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                    fsum += fs;
+                }
+                if constexpr (RANKED) {
+                    // pa0 / pa1 are complete scores now; only those that can enter the heap are inserted (serial, rare once warm)
 #ifdef DS2I_PHASE_TIMING
                     const unsigned long long tk_t0 = __builtin_readcyclecounter();
-                    cx.s_phase[PH_SCORE] += tk_t0 - sc_t0 - (cx.s_phase[PH_FREQS] - fr_before);
 #endif
-                    if (RANKED) {
-                        // only scores that can enter the heap are inserted (serial, rare once warm)
-                        for (int half = 0; half < 2; ++half) {
-                            const bool al = half ? al1 : al0;
-                            const float sc = half ? sc1 : sc0;
-                            uint64_t todo = ballot(al && tk.would_enter(sc));
-                            while (todo) {
-                                uint32_t src = (uint32_t)__builtin_ctzll(todo);
-                                todo &= todo - 1;
-                                tk.insert(__uint_as_float(bcast(__float_as_uint(sc), src)));
+                    for (int half = 0; half < 2; ++half) {
+                        const bool al = half ? al1 : al0;
+                        const float sc = half ? pa1 : pa0;
+                        uint64_t todo = ballot(al && tk.would_enter(sc));
+                        while (todo) {
+                            uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
+                            if (tk.insert(v) && shared_floor && lane == 0) {
+                                uint32_t bkt = (uint32_t)(v * h_inv);
+                                bkt = bkt > 255u ? 255u : bkt;
+                                __hip_atomic_fetch_add(hist + bkt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
                     }
@@ -352,36 +535,36 @@ __global__ void __launch_bounds__(64) k_merge(MergeArgs a) {
 }
 
 // ------------------------------------------------------------------ document-at-a-time
-template <int TMAX, class CX>
+template <class CX>
 DS2I_DEV float score_of(CX& cx, uint32_t s, float norm_len) {
     return __uint_as_float(cx.m(s, M_QW)) * doc_term_weight(cx.freq(s), norm_len);
 }
 
 // stable insertion sort of ord[0..n) by key(slot) (== libstdc++ std::sort for n <= 16)
-template <int TMAX, class Key>
-DS2I_DEV void sort_ord(Lds<TMAX>& L, uint32_t n, Key key) {
+template <class Key>
+DS2I_DEV void sort_ord(uint32_t* ord, uint32_t n, Key key) {
     if (lane_id() == 0) {
         for (uint32_t i = 1; i < n; ++i) {
-            uint32_t v = L.ord()[i];
+            uint32_t v = ord[i];
             auto kv = key(v);
             uint32_t j = i;
-            while (j > 0 && kv < key(L.ord()[j - 1])) { L.ord()[j] = L.ord()[j - 1]; --j; }
-            L.ord()[j] = v;
+            while (j > 0 && kv < key(ord[j - 1])) { ord[j] = ord[j - 1]; --j; }
+            ord[j] = v;
         }
     }
     wave_sync();
 }
 
-template <int OP, int TMAX, int CODEC_T = -1>
-__global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
-    __shared__ Lds<TMAX> L;
+// One unit of a reference-order operator. The per-list enumerator state (`meta`: M_WORDS dwords per slot, the same
+// memory cx.meta points to), the list order `ord` and the maxscore upper bounds `ub` live wherever the caller keeps
+// them: LDS for the <=16-term classes (k_daat), a global scratch area for longer queries (k_daat_long).
+template <int OP, class CX>
+DS2I_DEV void daat_unit(CX& cx, const BatchArgs& a, const uint32_t uid, uint32_t* meta, uint32_t* ord, float* ubs, const uint32_t tmax) {
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T, MetaLds> cx = make_ctx<CODEC_T, MetaLds>(L, a);
     constexpr bool RANKED = OP >= OP_RANKED_AND;
-    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
+    {
         // a unit of these operators is a doc-id range [blk_begin, blk_end) of the query (whole range when
         // nparts == 1); inside the unit blk_end plays the role of num_docs (the exhaustion sentinel)
-        const uint32_t uid = a.order[tkt];
         const Unit u = a.units[uid];
         const uint32_t q = u.q;
         const bool whole = u.nparts == 1;
@@ -391,10 +574,10 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
         unsigned long long count = 0, fsum = 0;
         TopK tk;
         tk.init(a.k);
-        if (nt == 0 || nt > (uint32_t)TMAX) {
+        if (nt == 0 || nt > tmax) {
             if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
             if (RANKED) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
-            continue;
+            return;
         }
         if (whole) {
             for (uint32_t i = 0; i < nt; ++i) cx.open(i, a.qterms[t0 + i]);
@@ -432,7 +615,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 if (i == nt) {
                     if (OP == OP_RANKED_AND) {
                         float nl = norm_len(cand), score = 0.f;
-                        for (i = 0; i < nt; ++i) score += score_of<TMAX>(cx, i, nl);
+                        for (i = 0; i < nt; ++i) score += score_of(cx, i, nl);
                         tk.insert(score);
                     } else {
                         if (a.out_matches && lane == 0 && count < mcap) a.out_matches[mbase + count] = cand;
@@ -454,7 +637,7 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 uint32_t nxt = N;
                 for (uint32_t i = 0; i < nt; ++i) {
                     if (cx.docid(i) == cur) {
-                        if (OP == OP_RANKED_OR) score += score_of<TMAX>(cx, i, nl);
+                        if (OP == OP_RANKED_OR) score += score_of(cx, i, nl);
                         if (OP == OP_OR_FREQ) fsum += cx.freq(i);
                         cx.next(i);
                     }
@@ -466,40 +649,40 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             }
         } else if (OP == OP_WAND) {
             // queries.hpp:236-305
-            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord()[i] = i;
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) ord[i] = i;
             wave_sync();
-            auto by_docid = [&](uint32_t s) { return L.meta[s][M_DOCID]; };
-            sort_ord(L, nt, by_docid);
+            auto by_docid = [&](uint32_t s) { return meta[s * M_WORDS + M_DOCID]; };
+            sort_ord(ord, nt, by_docid);
             for (;;) {
                 float upper = 0.f;
                 uint32_t pivot = 0;
                 bool found = false;
                 for (pivot = 0; pivot < nt; ++pivot) {
-                    uint32_t s = uniform(L.ord()[pivot]);
+                    uint32_t s = uniform(ord[pivot]);
                     if (cx.docid(s) == N) break;
                     upper += __uint_as_float(cx.m(s, M_MAXW));
                     if (tk.would_enter(upper)) { found = true; break; }
                 }
                 if (!found) break;
-                const uint32_t pivot_id = cx.docid(uniform(L.ord()[pivot]));
-                if (pivot_id == cx.docid(uniform(L.ord()[0]))) {
+                const uint32_t pivot_id = cx.docid(uniform(ord[pivot]));
+                if (pivot_id == cx.docid(uniform(ord[0]))) {
                     float score = 0.f, nl = norm_len(pivot_id);
                     for (uint32_t j = 0; j < nt; ++j) {
-                        uint32_t s = uniform(L.ord()[j]);
+                        uint32_t s = uniform(ord[j]);
                         if (cx.docid(s) != pivot_id) break;
-                        score += score_of<TMAX>(cx, s, nl);
+                        score += score_of(cx, s, nl);
                         cx.next(s);
                     }
                     tk.insert(score);
-                    sort_ord(L, nt, by_docid);
+                    sort_ord(ord, nt, by_docid);
                 } else {
                     uint32_t nl_ = pivot;
-                    while (cx.docid(uniform(L.ord()[nl_])) == pivot_id) --nl_;
-                    cx.next_geq(uniform(L.ord()[nl_]), pivot_id);
+                    while (cx.docid(uniform(ord[nl_])) == pivot_id) --nl_;
+                    cx.next_geq(uniform(ord[nl_]), pivot_id);
                     if (lane == 0) {
                         for (uint32_t j = nl_ + 1; j < nt; ++j) {
-                            uint32_t x = L.ord()[j], y = L.ord()[j - 1];
-                            if (L.meta[x][M_DOCID] < L.meta[y][M_DOCID]) { L.ord()[j] = y; L.ord()[j - 1] = x; }
+                            uint32_t x = ord[j], y = ord[j - 1];
+                            if (meta[x * M_WORDS + M_DOCID] < meta[y * M_WORDS + M_DOCID]) { ord[j] = y; ord[j - 1] = x; }
                             else break;
                         }
                     }
@@ -507,46 +690,46 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
                 }
             }
         } else { // OP_MAXSCORE, queries.hpp:514-577
-            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) L.ord()[i] = i;
+            if (lane == 0) for (uint32_t i = 0; i < nt; ++i) ord[i] = i;
             wave_sync();
-            auto by_maxw = [&](uint32_t s) { return __uint_as_float(L.meta[s][M_MAXW]); };
-            sort_ord(L, nt, by_maxw);
+            auto by_maxw = [&](uint32_t s) { return __uint_as_float(meta[s * M_WORDS + M_MAXW]); };
+            sort_ord(ord, nt, by_maxw);
             if (lane == 0) {
                 float acc = 0.f;
                 for (uint32_t i = 0; i < nt; ++i) {
-                    float mw = __uint_as_float(L.meta[L.ord()[i]][M_MAXW]);
+                    float mw = __uint_as_float(meta[ord[i] * M_WORDS + M_MAXW]);
                     acc = i ? acc + mw : mw;
-                    L.ub()[i] = acc;
+                    ubs[i] = acc;
                 }
             }
             wave_sync();
             uint32_t non_ess = 0, cur = N;
             // with a seeded floor some lists are non-essential before the first document (the reference only updates
             // this after a successful insert, queries.hpp:568-574 -- same rule, applied to the initial bound)
-            while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub()[non_ess])))))
+            while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(ubs[non_ess])))))
                 ++non_ess;
             for (uint32_t i = 0; i < nt; ++i) { uint32_t d = cx.docid(i); cur = d < cur ? d : cur; }
             while (non_ess < nt && cur < N) {
                 float score = 0.f, nl = norm_len(cur);
                 uint32_t nxt = N;
                 for (uint32_t i = non_ess; i < nt; ++i) {
-                    uint32_t s = uniform(L.ord()[i]);
+                    uint32_t s = uniform(ord[i]);
                     if (cx.docid(s) == cur) {
-                        score += score_of<TMAX>(cx, s, nl);
+                        score += score_of(cx, s, nl);
                         cx.next(s);
                     }
                     uint32_t d = cx.docid(s);
                     nxt = d < nxt ? d : nxt;
                 }
                 for (uint32_t i = non_ess; i-- > 0;) {
-                    float ub = __uint_as_float(uniform(__float_as_uint(L.ub()[i])));
+                    float ub = __uint_as_float(uniform(__float_as_uint(ubs[i])));
                     if (!tk.would_enter(score + ub)) break;
-                    uint32_t s = uniform(L.ord()[i]);
+                    uint32_t s = uniform(ord[i]);
                     cx.next_geq(s, cur);
-                    if (cx.docid(s) == cur) score += score_of<TMAX>(cx, s, nl);
+                    if (cx.docid(s) == cur) score += score_of(cx, s, nl);
                 }
                 if (tk.insert(score)) {
-                    while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(L.ub()[non_ess])))))
+                    while (non_ess < nt && !tk.would_enter(__uint_as_float(uniform(__float_as_uint(ubs[non_ess])))))
                         ++non_ess;
                 }
                 cur = nxt;
@@ -565,6 +748,55 @@ __global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
             }
             if (RANKED) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
+    }
+}
+
+template <int OP, int TMAX, int CODEC_T = -1>
+__global__ void __launch_bounds__(64) k_daat(BatchArgs a) {
+    __shared__ Lds<TMAX> L;
+    CtxT<CODEC_T, MetaLds> cx = make_ctx<CODEC_T, MetaLds>(L, a);
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x)
+        daat_unit<OP>(cx, a, a.order[tkt], &L.meta[0][0], L.ord(), L.ub(), (uint32_t)TMAX);
+    cx.flush_stats(a.stats);
+}
+
+// Queries with more than 16 distinct terms (the reference has no limit, queries.hpp:35-86): the same traversals with
+// the per-list state -- 128 doc-ids + 128 freqs + M_WORDS dwords per list, the list order and the upper bounds -- in a
+// global scratch area of long_stride dwords per unit instead of LDS; only the decoders' staging stays in LDS.
+struct LdsLong {
+    uint32_t exc[EXC_LDS_DW];
+    uint32_t st[STAGE_DW];
+};
+template <int OP>
+__global__ void __launch_bounds__(64) k_daat_long(BatchArgs a) {
+    __shared__ LdsLong L;
+    CtxT<-1, MetaLds> cx;
+    cx.docs = cx.freqs = nullptr;
+    cx.meta.p = nullptr;
+    cx.exc = L.exc;
+    s16_table_init(L.exc);
+    cx.win.st = L.st;
+    cx.win.gbase = a.arena;
+    cx.win.nbytes = 0;
+    cx.arena = a.arena;
+    cx.bits0 = a.bits0;
+    cx.bits1 = a.bits1;
+    cx.codec = a.codec;
+    cx.num_docs = a.num_docs;
+    cx.block_profile = a.block_profile;
+    cx.skip = (const uint2*)a.skip;
+    cx.init_stats();
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
+        const uint32_t uid = a.order[tkt];
+        const uint32_t q = a.units[uid].q;
+        const uint32_t nt = a.q_off[q + 1] - a.q_off[q];
+        uint32_t* base = a.long_scratch + (size_t)tkt * a.long_stride;
+        cx.docs = base;
+        cx.freqs = base + 128u * nt;
+        cx.meta.p = base + 256u * nt;
+        uint32_t* ord = cx.meta.p + (uint32_t)M_WORDS * nt;
+        float* ub = (float*)(ord + nt);
+        daat_unit<OP>(cx, a, uid, cx.meta.p, ord, ub, 0xFFFFFFFFu);
     }
     cx.flush_stats(a.stats);
 }
@@ -856,11 +1088,86 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
     cx.flush_stats(a.stats);
 }
 
+// ------------------------------------------------------------------ upload-time block-max weights
+// bmw[block] = max over the block's postings of bm25::doc_term_weight(freq, norm_len[doc]) -- the block-level analogue
+// of wand_data's max_term_weight (wand_data.hpp:40-52), with the scoring code's own float32 arithmetic. One wave per
+// item = <=64 consecutive blocks of one list: lane j keeps the weight of block blk_begin + j, one coalesced store.
+__global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
+    __shared__ Lds<1> L;
+    BatchArgs ba{};
+    ba.arena = a.arena;
+    ba.bits0 = a.bits0;
+    ba.bits1 = a.bits1;
+    ba.codec = a.codec;
+    ba.num_docs = a.num_docs;
+    Ctx cx = make_ctx<-1, MetaLds>(L, ba);
+    const uint32_t lane = lane_id();
+    for (uint32_t item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        const BmwItem it = a.items[item];
+        const QTerm t = a.lists[it.list];
+        cx.bind(0, t);
+        const uint32_t nb = cx.m(0, M_NB);
+        const uint32_t end = it.blk_begin + 64u < nb ? it.blk_begin + 64u : nb;
+        float mine = 0.f;
+        for (uint32_t b = it.blk_begin; b < end; ++b) {
+            cx.decode_docs(0, b);
+            cx.decode_freqs(0);
+            const uint32_t sz = cx.m(0, M_SIZE);
+            float w = 0.f;
+            if (lane < sz) w = doc_term_weight(L.freqs[0][lane], a.norm_lens[L.docs[0][lane]]);
+            if (lane + 64 < sz) {
+                const float w1 = doc_term_weight(L.freqs[0][lane + 64], a.norm_lens[L.docs[0][lane + 64]]);
+                w = w1 > w ? w1 : w;
+            }
+            for (int o = 32; o; o >>= 1) {
+                const float x = __shfl_xor(w, o);
+                w = x > w ? x : w;
+            }
+            if (lane == b - it.blk_begin) mine = w;
+            wave_sync();
+        }
+        if (it.blk_begin + lane < end) a.bmw[t.blk_base + it.blk_begin + lane] = mine;
+        float lm = mine;
+        for (int o = 32; o; o >>= 1) {
+            const float x = __shfl_xor(lm, o);
+            lm = x > lm ? x : lm;
+        }
+        if (lane == 0) atomicMax(a.list_bmw + it.list, __float_as_uint(lm)); // weights >= 0: bit patterns order like values
+    }
+}
+
+// top[list][0..63] = the 64 largest bmw values of the list, descending, padded with 0 (one wave per list)
+__global__ void __launch_bounds__(64) k_list_top_bmw(const float* bmw, const QTerm* lists, uint32_t nlists, float* top) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlists; l += gridDim.x) {
+        const QTerm t = lists[l];
+        const uint32_t nb = t.aux1 ? t.term : (t.n + 127u) >> 7; // freq_index layouts carry their chunk count in `term`
+        const float* w = bmw + t.blk_base;
+        TopK tk;
+        tk.init(64);
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+            const float v = b0 + lane < nb ? w[b0 + lane] : -1.f;
+            uint64_t todo = ballot(b0 + lane < nb && tk.would_enter(v));
+            while (todo) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                tk.insert(__uint_as_float(bcast(__float_as_uint(v), src)));
+            }
+        }
+        top[(size_t)l * 64 + lane] = lane < tk.n ? tk.v : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ primitive self-test
 __global__ void __launch_bounds__(64) k_selftest(const uint32_t* in, uint32_t* out) {
     const uint32_t lane = lane_id();
     uint32_t x = in[blockIdx.x * 64 + lane];
     out[blockIdx.x * 64 + lane] = wave_incl_scan(x);
+}
+
+__global__ void __launch_bounds__(64) k_selftest_bm25(const uint32_t* freqs, const float* norm_lens, float* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 64 + lane_id();
+    if (i < n) out[i] = doc_term_weight(freqs[i], norm_lens[i]);
 }
 
 // wand / maxscore / ranked_or of a ONE-term query are exactly its ranked_and result: copy it from the seed pass
@@ -906,9 +1213,30 @@ struct Batch {
 // The file is compiled once per list-count class (-DDS2I_TU_TMAX=2|4|8|16: only launch_t<TMAX> and the kernels it
 // instantiates) and once without the macro (everything else): five translation units that build.py compiles in
 // parallel -- the kernel templates are by far the slowest part of the build.
+// DS2I_TU_TMAX == 0: the translation unit of the "long" class (k_daat_long, every operator in reference order)
+#if defined(DS2I_TU_TMAX) && DS2I_TU_TMAX == 0
+hipError_t launch_long(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
+    dim3 g(grid), b(64);
+    switch (op & 0xFF) {
+    case OP_AND: hipLaunchKernelGGL((k_daat_long<OP_AND>), g, b, 0, s, a); break;
+    case OP_AND_FREQ: hipLaunchKernelGGL((k_daat_long<OP_AND_FREQ>), g, b, 0, s, a); break;
+    case OP_OR: hipLaunchKernelGGL((k_daat_long<OP_OR>), g, b, 0, s, a); break;
+    case OP_OR_FREQ: hipLaunchKernelGGL((k_daat_long<OP_OR_FREQ>), g, b, 0, s, a); break;
+    case OP_RANKED_AND: hipLaunchKernelGGL((k_daat_long<OP_RANKED_AND>), g, b, 0, s, a); break;
+    case OP_WAND: hipLaunchKernelGGL((k_daat_long<OP_WAND>), g, b, 0, s, a); break;
+    case OP_MAXSCORE: hipLaunchKernelGGL((k_daat_long<OP_MAXSCORE>), g, b, 0, s, a); break;
+    case OP_RANKED_OR: hipLaunchKernelGGL((k_daat_long<OP_RANKED_OR>), g, b, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#else
+hipError_t launch_long(int op, const BatchArgs& a, unsigned grid, hipStream_t s);
+#endif
+
 template <int TMAX>
 hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
-#if defined(DS2I_TU_TMAX)
+#if defined(DS2I_TU_TMAX) && DS2I_TU_TMAX > 0
 {
     dim3 g(grid), b(64);
     switch (op) {
@@ -981,15 +1309,30 @@ extern template hipError_t launch_t<16>(int, const BatchArgs&, unsigned, hipStre
 #if !defined(DS2I_TU_TMAX)
 extern "C" {
 
-// tmax_class: 0 -> TMAX 2, 1 -> TMAX 4, 2 -> TMAX 8, 3 -> TMAX 16 (LDS footprint per wave grows with TMAX)
+// tmax_class: 0 -> TMAX 2, 1 -> TMAX 4, 2 -> TMAX 8, 3 -> TMAX 16 (LDS footprint per wave grows with TMAX),
+// 4 -> more than 16 terms (state in global scratch)
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
     switch (tmax_class) {
     case 0: return ds2i_launch::launch_t<2>(op, a, grid, s);
     case 1: return ds2i_launch::launch_t<4>(op, a, grid, s);
     case 2: return ds2i_launch::launch_t<8>(op, a, grid, s);
-    default: return ds2i_launch::launch_t<16>(op, a, grid, s);
+    case 3: return ds2i_launch::launch_t<16>(op, a, grid, s);
+    default: return ds2i_launch::launch_long(op, a, grid, s);
     }
+}
+
+uint32_t ds2i_meta_words(void) { return (uint32_t)M_WORDS; }
+
+hipError_t ds2i_launch_block_max_weights(const void* args, unsigned grid, hipStream_t s) {
+    const BmwArgs& a = *(const BmwArgs*)args;
+    hipLaunchKernelGGL(k_block_max_weights, dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ds2i_launch_list_top_bmw(const float* bmw, const void* lists, uint32_t nlists, float* out, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_list_top_bmw, dim3(grid), dim3(64), 0, s, bmw, (const QTerm*)lists, nlists, out);
+    return hipGetLastError();
 }
 
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s) {
@@ -1006,6 +1349,11 @@ hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t 
 
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(64), 0, s, in, out);
+    return hipGetLastError();
+}
+
+hipError_t ds2i_launch_selftest_bm25(const uint32_t* freqs, const float* norm_lens, float* out, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_bm25, dim3((n + 63) / 64), dim3(64), 0, s, freqs, norm_lens, out, n);
     return hipGetLastError();
 }
 

@@ -51,6 +51,10 @@ void ds2i_wand_free(ds2i_wand_builder* w);
  * sum_of_values == 0xFFFFFFFF means "unknown" like the reference. Returns a blob. */
 int ds2i_encode_block(int codec, const uint32_t* values, uint32_t sum_of_values, uint32_t n, ds2i_blob** out);
 int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out);
+/* bm25::query_term_weight / doc_term_weight (bm25.hpp:11-24), element-wise, as the host side of the query path
+ * computes them (float32) */
+int ds2i_bm25_query_term_weight(const uint64_t* qtf, const uint64_t* df, uint64_t num_docs, uint64_t n, float* out);
+int ds2i_bm25_doc_term_weight(const uint64_t* freq, const float* norm_len, uint64_t n, float* out);
 int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const uint32_t* freqs, ds2i_blob** out);
 
 /* The chunk directory ds2i_hip_index_open builds for one list of an opt image (inspection / test hook):

@@ -49,7 +49,10 @@ enum ds2i_hip_op {
     /* OR this flag into any operator to run the reference's
        one-document-per-step traversal on the GPU instead of the block-synchronous kernel (same results; used to
        cross-check and to count the reference traversal's algorithmic bytes on the device). */
-    DS2I_OP_REFERENCE_ORDER = 0x100
+    DS2I_OP_REFERENCE_ORDER = 0x100,
+    /* OR this flag into the operator of ds2i_hip_query_batch / ds2i_hip_pipeline_submit to run the kernels compiled
+       without the statistics counters even though a stats struct is passed (it then carries kernel_ms only). */
+    DS2I_OP_NO_COUNTERS = 0x200
 };
 
 enum ds2i_hip_error {
@@ -59,11 +62,14 @@ enum ds2i_hip_error {
     DS2I_ETERM = -3,    /* term id >= index size (UB + assert in the reference, block_freq_index.hpp:87) */
     DS2I_EDEVICE = -4,  /* HIP runtime error or no usable device */
     DS2I_ENOWAND = -5,  /* ranked operator without wand data (queries.cpp:108-116 logs "Unsupported") */
-    DS2I_ETOOLONG = -6, /* query has more than DS2I_HIP_MAX_TERMS distinct terms */
-    DS2I_ENOMEM = -7
+    DS2I_ETOOLONG = -6, /* query has more than DS2I_HIP_MAX_TERMS_LONG distinct terms */
+    DS2I_ENOMEM = -7,
+    DS2I_EBUSY = -8     /* pipeline: every slot is in flight -- collect the oldest ticket first */
 };
 
-#define DS2I_HIP_MAX_TERMS 16 /* distinct terms per query held in LDS by one wavefront */
+#define DS2I_HIP_MAX_TERMS 16        /* distinct terms per query held in LDS by one wavefront (the fast kernels) */
+#define DS2I_HIP_MAX_TERMS_LONG 1024 /* beyond 16 distinct terms a query runs the one-document-per-step traversal with
+                                        its enumerator state in global memory (the reference has no limit, queries.hpp:35-86) */
 #define DS2I_HIP_MAX_K 64     /* top-k kept one score per lane */
 
 typedef struct ds2i_hip_index ds2i_hip_index;
@@ -102,9 +108,13 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
 
 /* One-shot batched query operator: for each query q (terms[query_offsets[q] .. query_offsets[q+1]))
  *   out_count[q]    the operator's return value (matches for and/or, top-k size for ranked ops)
- *   out_topk        nq*k floats, each query's scores descending, padded with -inf (may be NULL for and/or)
+ *   out_topk        nq*k floats, each query's scores descending, padded with -inf. Ranked operators only:
+ *                   and / or produce no top-k, ignore k and never touch out_topk (may be NULL)
  *   out_topk_len    nq (may be NULL)
- * Host terms -> HBM, kernels, results -> host. stats may be NULL. */
+ * Host terms -> HBM, kernels, results -> host. The batch slot (pinned staging, device blocks, events) is cached in
+ * the index handle: repeated calls allocate nothing. stats may be NULL; when given, the instrumented kernels run
+ * (counters filled) unless DS2I_OP_NO_COUNTERS is set. A query may have any number of distinct terms up to
+ * DS2I_HIP_MAX_TERMS_LONG (the reference has no limit); beyond DS2I_HIP_MAX_TERMS it takes the slower long path. */
 int ds2i_hip_query_batch(ds2i_hip_index* idx, int op, uint32_t k, const uint32_t* terms,
                          const uint32_t* query_offsets, uint32_t nq, uint64_t* out_count, float* out_topk,
                          uint32_t* out_topk_len, ds2i_hip_stats* stats);
@@ -130,7 +140,7 @@ int ds2i_hip_batch_set_instrumented(ds2i_hip_batch* b, int on);
 int ds2i_hip_batch_enable_block_profile(ds2i_hip_batch* b);
 int ds2i_hip_batch_block_profile(ds2i_hip_batch* b, uint32_t* counts, uint64_t capacity, uint64_t* total_blocks);
 /* per kernel class of the last run (class 0: <=2 distinct terms, 1: 3..4, 2: 5..8, 3: 9..16 -- four
- * template instantiations with different LDS footprints, launched concurrently on four streams) */
+ * template instantiations with different LDS footprints -- 4: more than 16; launched concurrently on their own streams) */
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
 /* diagnostic build only (-DDS2I_PHASE_TIMING): per-phase shader-cycle sums {total, docs decode, freqs
  * decode, block search, membership, scoring, top-k} of class cls; zeros otherwise */
@@ -142,10 +152,32 @@ int ds2i_hip_batch_match_total(ds2i_hip_batch* b, uint64_t* total);
 int ds2i_hip_batch_fetch_matches(ds2i_hip_batch* b, uint64_t* match_offsets, uint32_t* matches);
 void ds2i_hip_batch_free(ds2i_hip_batch* b);
 
+/* Pipelined form -- the serving loop. A pipeline owns `depth` reusable batch slots. submit() does the host half of
+ * the operator (query normalisation, BM25 query weights, work-unit planning: queries.hpp:29-33,136-150,357-360),
+ * then enqueues ONE async H2D copy, the kernels and ONE async D2H copy of the results and returns without waiting
+ * for the device: the host plans batch i+1 while the kernels of batch i run, and the kernels of consecutive batches
+ * overlap on the device. wait() blocks until the ticket's batch is complete and copies its results out (same
+ * meaning as ds2i_hip_query_batch). Tickets must be collected before their slot comes round again (submit() returns
+ * DS2I_EBUSY otherwise). This is the loop queries.cpp:25-35 becomes: every query is timed fresh, nothing is
+ * pre-staged on the device. */
+typedef struct ds2i_hip_pipeline ds2i_hip_pipeline;
+int ds2i_hip_pipeline_create(ds2i_hip_index* idx, uint32_t depth, ds2i_hip_pipeline** out);
+int ds2i_hip_pipeline_submit(ds2i_hip_pipeline* p, int op, uint32_t k, const uint32_t* terms,
+                             const uint32_t* query_offsets, uint32_t nq, uint64_t* ticket);
+int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_count, float* out_topk,
+                           uint32_t* out_topk_len, ds2i_hip_stats* stats);
+/* like ds2i_hip_batch_class_stats, for the ticket collected last */
+int ds2i_hip_pipeline_class_stats(ds2i_hip_pipeline* p, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
+/* default off: pipelines run the kernels compiled without counters */
+int ds2i_hip_pipeline_set_instrumented(ds2i_hip_pipeline* p, int on);
+void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p);
+
 /* profiling aid: streams the whole index arena once with the decoders' load shape (calibrates FETCH_SIZE) */
 int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read);
 /* GPU unit-test hook: wave64 inclusive prefix sum over rows of 64 values */
 int ds2i_hip_selftest_scan(int device, const uint32_t* in, uint32_t* out, uint32_t rows);
+/* GPU unit-test hook: the kernels' bm25::doc_term_weight (bm25.hpp:11-15), element-wise */
+int ds2i_hip_selftest_bm25(int device, const uint32_t* freqs, const float* norm_lens, float* out, uint32_t n);
 
 #ifdef __cplusplus
 }

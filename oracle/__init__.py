@@ -50,6 +50,10 @@ def lib(path=None):
     L.oracle_decode_block.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint64)]
     L.oracle_decode_vbyte.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.oracle_qmx_decode_stream.argtypes = [vp, vp, C.c_uint64]
+    L.oracle_bm25_doc_term_weight.argtypes = [vp, vp, C.c_uint64, vp]
+    L.oracle_bm25_doc_term_weight.restype = None
+    L.oracle_bm25_query_term_weight.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
+    L.oracle_bm25_query_term_weight.restype = None
     L.oracle_qmx_decode_stream.restype = None
     L.oracle_index_open.argtypes = [C.c_int, vp, C.c_uint64, vp, C.c_uint64]
     L.oracle_index_open.restype = vp
@@ -73,6 +77,42 @@ def lib(path=None):
     if path is None:
         _lib = L
     return L
+
+
+def bm25_doc_term_weight(freq, norm_len):
+    """oracle.cpp's bm25::doc_term_weight, element-wise (float32)."""
+    f = np.ascontiguousarray(freq, dtype=np.uint64)
+    nl = np.ascontiguousarray(norm_len, dtype=np.float32)
+    out = np.zeros(len(f), dtype=np.float32)
+    lib().oracle_bm25_doc_term_weight(_p(f), _p(nl), len(f), _p(out))
+    return out
+
+
+def bm25_query_term_weight(qtf, df, num_docs):
+    q = np.ascontiguousarray(qtf, dtype=np.uint64)
+    d = np.ascontiguousarray(df, dtype=np.uint64)
+    out = np.zeros(len(q), dtype=np.float32)
+    lib().oracle_bm25_query_term_weight(_p(q), _p(d), int(num_docs), len(q), _p(out))
+    return out
+
+
+_ref_bm25 = None
+
+
+def ref_bm25():
+    """The reference's own bm25.hpp (oracle/_ref/libbm25_ref.so) or None when it was never built."""
+    global _ref_bm25
+    if _ref_bm25 is None:
+        p = os.path.join(_HERE, "_ref", "libbm25_ref.so")
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_bm25_doc_term_weight.argtypes = [C.c_uint64, C.c_float]
+        R.ref_bm25_doc_term_weight.restype = C.c_float
+        R.ref_bm25_query_term_weight.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        R.ref_bm25_query_term_weight.restype = C.c_float
+        _ref_bm25 = R
+    return _ref_bm25
 
 
 def ref_qmx():

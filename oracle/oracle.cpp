@@ -966,6 +966,13 @@ int oracle_decode_vbyte(const uint8_t* in, uint32_t* value) {
 }
 // raw QMX stream decode (for comparison with oracle/_ref): out must hold 128+512 values
 void oracle_qmx_decode_stream(uint32_t* out, const uint8_t* src, uint64_t len) { qmx_decode_stream(out, src, len); }
+// the restated scorer (bm25.hpp:7-25), element-wise: pinned against the reference's own bm25.hpp by tests/golden/bm25_reference.json
+void oracle_bm25_doc_term_weight(const uint64_t* freq, const float* norm_len, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) out[i] = bm25::doc_term_weight(freq[i], norm_len[i]);
+}
+void oracle_bm25_query_term_weight(const uint64_t* qtf, const uint64_t* df, uint64_t num_docs, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) out[i] = bm25::query_term_weight(qtf[i], df[i], num_docs);
+}
 
 void* oracle_index_open(int kind, const void* image, uint64_t bytes, const void* wand, uint64_t wand_bytes) {
     try {

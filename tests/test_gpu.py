@@ -39,6 +39,22 @@ def test_wave_scan_primitive(built_lib):
     assert np.array_equal(out, np.cumsum(x, axis=1, dtype=np.uint32))
 
 
+def test_device_bm25_equals_reference_fixture(built_lib):
+    """The kernels' doc_term_weight against outputs of the reference's own bm25.hpp (tests/golden/bm25_reference.json,
+    generated from /root/reference/bm25.hpp compiled as-is): bit-exact float32."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bm25_reference.json")))
+    dtw = np.array(g["doc_term_weight"], dtype=np.uint64)
+    dtw = dtw[dtw[:, 0] < (1 << 32)]
+    f = np.ascontiguousarray(dtw[:, 0].astype(np.uint32))
+    nl = np.ascontiguousarray(dtw[:, 1].astype(np.uint32).view(np.float32))
+    out = np.zeros(len(f), dtype=np.float32)
+    rc = built_lib.ds2i_hip_selftest_bm25(0, f.ctypes.data, nl.ctypes.data, out.ctypes.data, len(f))
+    assert rc == 0, built_lib.ds2i_hip_last_error()
+    assert np.array_equal(out.view(np.uint32), dtw[:, 2].astype(np.uint32))
+
+
 @pytest.mark.parametrize("codec", CODECS)
 def test_decode_every_list(coll, images, codec):
     idx = d.Index(codec, images[0][codec])
@@ -118,7 +134,7 @@ def test_uninstrumented_kernels_give_the_same_results(coll, queries, images, cod
     assert st2.kernel_ms > 0
     b.set_instrumented(True)
     st3 = b.run()
-    if op != "wand":  # the parts of a split wand query race for the shared floor: same results, varying work
+    if op not in ("wand", "ranked_and"):  # the parts of a split ranked query race for the shared floor: same results, varying work
         assert st3.docs_blocks_decoded == st.docs_blocks_decoded and st3.algorithmic_bytes == st.algorithmic_bytes
     b.close()
 
@@ -138,7 +154,8 @@ def test_reference_order_kernel_and_algorithmic_bytes(coll, queries, images, op)
     # block-synchronous kernel: a superset of those blocks, never fewer docs blocks
     b = d.Batch(gidx, op, queries)
     st2 = b.run()
-    assert st2.docs_blocks_decoded >= prof["docs_blocks"] * 0.85  # lazy binding skips unneeded block-0 decodes
+    if op != "ranked_and":  # ranked_and additionally skips blocks whose score bound cannot enter the heap
+        assert st2.docs_blocks_decoded >= prof["docs_blocks"] * 0.85  # lazy binding skips unneeded block-0 decodes
     assert st2.docs_blocks_decoded <= prof["docs_blocks"] * 1.5 + 16
 
 
@@ -171,13 +188,104 @@ def test_error_behaviour(coll, images):
     with pytest.raises(d.Ds2iError) as e:
         gidx.query_batch("ranked_and", [[1, 2]])
     assert e.value.code == -5  # ranked op without wand data (queries.cpp:108-116)
+    count, _, _, _ = gidx.query_batch("and", [list(range(17)) * 70])  # 1190 terms, 17 distinct: the long path answers
+    assert count[0] == len(brute_and(coll, list(range(17))))
+    # DS2I_HIP_MAX_TERMS_LONG distinct terms is the only length limit
+    many = [(np.array([7], np.uint32), np.array([1], np.uint32))] * 1100
+    tiny = d.Index("block_varint", d.build_index("block_varint", 100, many))
+    count, _, _, _ = tiny.query_batch("and", [list(range(1024)), [3]])
+    assert list(count) == [1, 1]
     with pytest.raises(d.Ds2iError) as e:
-        gidx.query_batch("and", [list(range(17))])
+        tiny.query_batch("and", [[3], list(range(1025))])
     assert e.value.code == -6
     with pytest.raises(d.Ds2iError):
         d.Index("block_optpfor", b"\x00" * 10)
     count, _, _, _ = gidx.query_batch("and", [])
     assert len(count) == 0
+
+
+def test_long_queries_more_than_16_terms(coll, queries, images):
+    """The reference's functors take any number of terms (queries.hpp:35-86). Queries with more than 16 distinct terms
+    run the one-document-per-step traversal with their enumerator state in global memory -- and the rest of the batch
+    is answered as usual."""
+    rng = np.random.default_rng(5)
+    T = coll.p.num_terms
+    dense = list(range(0, 24))                      # the 24 longest lists: a non-empty 24-term conjunction is plausible
+    longq = [dense, dense[:17], list(rng.choice(T, 40, replace=False)), list(rng.choice(T, 100, replace=False)) + [3, 3],
+             list(range(17)) * 3]
+    mixed = queries[:40] + longq + queries[40:60]
+    for codec in ("block_optpfor", "opt", "block_mixed"):
+        gidx = d.Index(codec, images[0][codec], images[1])
+        oidx = o.Index(codec, images[0][codec], images[1])
+        for op in ALL_OPS:
+            _check_against_oracle(gidx, oidx, op, mixed)
+        _check_against_oracle(gidx, oidx, "ranked_or", longq, k=64)
+        _check_against_oracle(gidx, oidx, "and", longq, reference_order=True)
+
+
+def test_pipeline_matches_one_shot_and_reuses_slots(coll, images):
+    """ds2i_hip_pipeline_*: distinct batches submitted back to back (three in flight) give exactly the one-shot
+    answers; a fourth submit without collecting is refused; slots are reused across operators and batch sizes."""
+    gidx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    batches = [queries_for(coll, n, seed=0x51E21 + i) for i, n in enumerate((300, 17, 1, 640, 300, 0, 45))]
+    pipe = d.Pipeline(gidx, depth=3)
+    for op in ("ranked_and", "and", "wand", "or_freq"):
+        expect = [gidx.query_batch(op, b, k=10)[:3] for b in batches]
+        tickets, got = [], []
+        for i, b in enumerate(batches):
+            if len(tickets) == 3:
+                got.append(pipe.wait(tickets.pop(0)))
+            tickets.append(pipe.submit(op, b, k=10))
+        with pytest.raises(d.Ds2iError) as e:
+            pipe.submit(op, batches[0], k=10)
+        assert e.value.code == -8  # DS2I_EBUSY
+        while tickets:
+            got.append(pipe.wait(tickets.pop(0)))
+        for (c, t, l), (ec, et, el) in zip(got, expect):
+            assert np.array_equal(c, ec) and np.array_equal(l, el)
+            if op in ("ranked_and", "wand"):
+                f = np.isfinite(et)
+                assert np.array_equal(f, np.isfinite(t))
+                np.testing.assert_allclose(t[f], et[f], rtol=1e-6 if op == "wand" else 0)
+    with pytest.raises(d.Ds2iError):
+        pipe.wait(12345)
+    pipe.close()
+
+
+def test_no_device_memory_leak(coll, queries, images):
+    """Every prepare / free cycle returns its device memory (round-1 leak: eight buffers per batch were never freed)."""
+    import torch
+    gidx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    def cycle(n):
+        for _ in range(n):
+            for op in ("ranked_and", "wand"):
+                b = d.Batch(gidx, op, queries, k=10)
+                b.run()
+                b.close()
+            gidx.query_batch("maxscore", queries[:50], k=10)
+    cycle(3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    cycle(40)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+def test_ranked_and_block_max_pruning_prunes(built_lib):
+    """ranked_and with the upload-time block-max weights scores a fraction of the postings an exhaustive traversal
+    scores (results are checked against the oracle by every ranked test; here: it really prunes)."""
+    p = d.SynthParams(seed=0xD52100BB, num_docs=400000, num_terms=64, zipf_exp=0.6, top_df_frac=0.5, min_len=20000,
+                      clustered_every=4)
+    img, wand, postings = d.synth_build(p, "block_optpfor")
+    gidx = d.Index("block_optpfor", img, wand)
+    oidx = o.Index("block_optpfor", img, wand)
+    qs = [[t] for t in range(0, 64, 3)] + [[a, a + 1] for a in range(0, 62, 5)] + [[1, 2, 3], [5, 9, 20, 33]]
+    st = _check_against_oracle(gidx, oidx, "ranked_and", qs, k=10)
+    ac, _, _, _ = gidx.query_batch("and", qs)
+    assert st.postings_scored < 0.5 * int(ac.sum()), (st.postings_scored, int(ac.sum()))
+    for k in (1, 64):
+        _check_against_oracle(gidx, oidx, "ranked_and", qs, k=k)
 
 
 def test_query_op_concept(coll, images):
@@ -368,8 +476,8 @@ def test_block_profile_and_hybrid_optimiser(coll, queries, images):
     nb_all = sum((len(dd) + 127) // 128 for dd, _ in coll.lists)
     assert prof.shape == (nb_all, 2)
     assert int(prof[:, 0].sum()) == st.docs_blocks_decoded and int(prof[:, 1].sum()) == st.freqs_blocks_decoded
-    st2 = b.run()  # accumulates
-    assert int(b.block_profile()[:, 0].sum()) == 2 * st.docs_blocks_decoded
+    st2 = b.run()  # accumulates (a second run may decode a few blocks more or fewer: the parts of a split query race for their shared floor)
+    assert int(b.block_profile()[:, 0].sum()) == st.docs_blocks_decoded + st2.docs_blocks_decoded
     b.close()
     # wand profile includes its ranked_and seed pass
     bw = d.Batch(gidx, "wand", queries, k=10)
