@@ -7,7 +7,7 @@ All query results come from the HIP kernels; there is no CPU fallback.
 import os as _os
 
 # see capi.cpp (ds2i_hip_more_hw_queues): must be in the environment before the HIP runtime initialises
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .api import (  # noqa: F401
     CODECS, BLOCK_CODECS, FREQ_INDEX_KINDS, OPS, REFERENCE_ORDER, NO_COUNTERS, Ds2iError, Index, Batch, Pipeline, flatten_queries, lib, library_path,

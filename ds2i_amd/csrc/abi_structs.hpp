@@ -47,6 +47,7 @@ struct BatchArgs {
     const uint8_t* bits0;     // opt index: docs bit vector words
     const uint8_t* bits1;     // opt index: freqs bit vector words
     const float* norm_lens;
+    float min_norm_len;       // smallest norm_len of the collection: doc_term_weight(f, min_norm_len) bounds any document's term weight
     const QTerm* qterms;      // terms of all queries, already in enumerator order
     const uint32_t* q_off;    // nq+1 offsets into qterms
     const Unit* units;        // all units, grouped by query

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -142,7 +143,7 @@ const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
 // The kernel classes of a batch run on one stream each, uploads and merges on two more; with the HIP default of 4
 // hardware queues several of them end up sharing one (the null stream owns a queue) and serialise. Ask for more
 // before the runtime initialises; an explicit setting of the user wins.
-__attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int ds2i_hip_device_count(void) {
     int n = 0;
@@ -321,9 +322,28 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     if (x->has_wand) {
         HIP_OK(hipMalloc((void**)&x->d_norm_lens, 4 * (wv.num_docs + 1)));
         HIP_OK(hipMemcpy(x->d_norm_lens, wv.norm_lens, 4 * wv.num_docs, hipMemcpyHostToDevice));
+        float mn = std::numeric_limits<float>::infinity();
+        for (uint64_t i = 0; i < wv.num_docs; ++i) {
+            float v;
+            std::memcpy(&v, (const uint8_t*)wv.norm_lens + 4 * i, 4);
+            mn = v < mn ? v : mn;
+        }
+        x->min_norm_len = wv.num_docs && mn >= 0.f ? mn : 0.f; // 0 is a valid lower bound for any collection
     }
     HIP_OK(hipMalloc((void**)&x->d_ticket, 64 * sizeof(unsigned int)));
-    for (auto& s : x->stream) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    {
+        // The many-list classes are few, LDS-hungry workgroups with long dependent chains; the <=2-list class is a
+        // flood of small ones. With equal priorities the flood starves the chains (class 2 alone: 4 ms, next to class
+        // 0: 21 ms), so the chain classes get the higher queue priority and finish inside the shadow of the flood.
+        int lo_pri = 0, hi_pri = 0; // numerically lower = higher priority
+        HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+        static const bool flat = std::getenv("DS2I_FLAT_PRIORITY") != nullptr;
+        for (int c = 0; c < NCLS; ++c) {
+            int pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
+            if (flat) pri = (lo_pri + hi_pri) / 2;
+            HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, pri));
+        }
+    }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));
     if (x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {

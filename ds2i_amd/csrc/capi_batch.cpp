@@ -422,8 +422,10 @@ int launch_batch(ds2i_hip_batch* b) {
     // batch): the block-synchronous conjunctions run 3 % faster when the issue-bound <=2-list class is enqueued first,
     // the disjunctive operators 2.5 % faster when the many-list classes are.
     const int base_op = b->op & 0xFF;
-    const bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
-                             (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND);
+    static const char* order_env = std::getenv("DS2I_LAUNCH_ORDER"); // "small" / "big": A/B switch
+    bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
+                       (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND);
+    if (order_env) small_first = order_env[0] == 's';
     static const bool no_skiptab = std::getenv("DS2I_NO_SKIPTAB") != nullptr;
     static const bool no_bmw_prune = std::getenv("DS2I_NO_BMW_PRUNE") != nullptr;
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
@@ -444,6 +446,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.bits0 = idx->d_bits0;
         a.bits1 = idx->d_bits1;
         a.norm_lens = idx->d_norm_lens;
+        a.min_norm_len = idx->min_norm_len;
         a.qterms = b->d_up.at<QTerm>(b->o_qterms);
         a.q_off = b->d_up.at<uint32_t>(b->o_qoff);
         a.units = b->d_up.at<Unit>(b->o_units);

@@ -83,6 +83,7 @@ struct ds2i_hip_index {
     uint8_t* d_arena = nullptr;
     uint64_t arena_bytes = 0;
     float* d_norm_lens = nullptr;
+    float min_norm_len = 0.f;       // smallest norm_len (upper-bounds doc_term_weight by the freq alone)
     bool has_wand = false;
     std::vector<uint64_t> list_off; // arena offsets, size+1 (list i spans [off[i], end[i]))
     std::vector<uint64_t> list_end;

@@ -20,15 +20,15 @@ using namespace ds2i_dev;
 
 namespace {
 
-template <int TMAX, bool META_IN_LDS = true>
+template <int TMAX, bool META_IN_LDS = true, bool WITH_POS = true>
 struct Lds {
     uint32_t docs[TMAX][128];
     uint32_t freqs[TMAX][128];
     uint32_t meta[META_IN_LDS ? TMAX : 1][META_IN_LDS ? M_WORDS : 1];
     uint32_t exc[EXC_LDS_DW]; // + the Simple16 field table (device_codecs.hpp)
     uint32_t st[STAGE_DW];
-    uint8_t pos[TMAX][128]; // match position of candidate c in list i (conjunctive scoring; row 0 unused
-                            // by the conjunctive kernel and reused as ord/ub by the daat kernel)
+    uint8_t pos[WITH_POS ? TMAX : 1][WITH_POS ? 128 : 4]; // match position of candidate c in list i (and_freq; row 0
+                            // unused by the conjunctive kernel and reused as ord/ub by the daat kernel)
     DS2I_DEV uint32_t* ord() { return (uint32_t*)&pos[0][0]; }       // daat: ordered_enums [TMAX<=16]
     DS2I_DEV float* ub() { return (float*)&pos[0][64]; }             // maxscore upper_bounds [TMAX<=16]
 };
@@ -111,20 +111,22 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
 // holds the maxima of the very doc_term_weight values the scoring code computes.
 static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 
-// Waves per SIMD the conjunctive kernels are compiled for. <=2 lists: 8 (64 VGPRs; latency hiding wins); beyond that
-// LDS caps the residency anyway (7 / 12 / 22 KiB per wave of the 160 KiB per CU), and without a bound the register
-// allocator lets the unrolled list loops balloon (237 VGPRs, 2 waves/SIMD for the 4-list kernel when left alone).
+// Waves per SIMD the conjunctive kernels are compiled for. <=2 lists: 6 (80 VGPRs, 12 B/lane of scratch; measured on the
+// GOV2-scale batch: 6 / 7 / 8 waves = 210 / 209 / 203 k queries/s -- the spills of the tighter budgets cost what the
+// extra waves hide); beyond that LDS caps the residency anyway (8 / 13 / 23 KiB per wave of the 160 KiB per CU), and
+// without a bound the register allocator lets the unrolled list loops balloon (237 VGPRs, 2 waves/SIMD for the 4-list
+// kernel when left alone).
 #ifndef DS2I_OCC2
-#define DS2I_OCC2 8
+#define DS2I_OCC2 6
 #endif
 #define CONJ_WAVES(T) ((T) <= 2 ? DS2I_OCC2 : (T) <= 4 ? 5 : (T) <= 8 ? 3 : 1)
 
-// LDS of the conjunctive kernels: the shared layout plus, for ranked_and's score-first rounds, the norm_len and the
-// list-0 term score of every posting of list 0's current block
+// LDS of the conjunctive kernels: the shared layout plus, for ranked_and, the norm_len of every posting of list 0's
+// current block (-1 = the posting was dropped by the freq-only bound and its norm_len never fetched); ranked_and has
+// no use for the match positions (it scores progressively). 5028 B for <=2 lists: 32 waves per CU.
 template <int TMAX, bool META_IN_LDS, bool RANKED>
-struct LdsConj : Lds<TMAX, META_IN_LDS> {
+struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED> {
     float nl[RANKED ? 128 : 1];
-    float part0[RANKED ? 128 : 1];
 };
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs 
         cx.s_bytes += 4;
         ++cx.s_bm_examined;
         uint32_t lo = 0;
-        uint32_t part_blk = 0xFFFFFFFFu; // block of list 0 whose norm_lens / list-0 scores are in L.nl / L.part0
+        uint32_t part_blk = 0xFFFFFFFFu; // block of list 0 whose norm_lens / list-0 scores are in L.nl
         // list 0 moves on: `want` = first block with block_max >= lo (or the unit's first block)
         uint32_t want = u.blk_begin;
         bool have_bi = false;
@@ -271,21 +273,35 @@ __global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs 
                     const uint32_t cur0 = cx.m(0, M_CUR);
                     if (part_blk != cur0) { // once per block of list 0: its freqs, the norm_lens and the list-0 term scores
                         if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
+                        PT_BEGIN(cx);
                         const float qw0 = __uint_as_float(cx.m(0, M_QW));
-                        const bool v0 = c0 != 0xFFFFFFFFu, v1 = c1 != 0xFFFFFFFFu;
-                        const float n0 = v0 ? a.norm_lens[c0] : 0.f, n1 = v1 ? a.norm_lens[c1] : 0.f;
-                        L.nl[lane] = n0;
-                        L.nl[lane + 64] = n1;
-                        L.part0[lane] = v0 ? qw0 * doc_term_weight(L.freqs[0][lane], n0) : 0.f;
-                        L.part0[lane + 64] = v1 ? qw0 * doc_term_weight(L.freqs[0][lane + 64], n1) : 0.f;
+                        bool v0 = c0 != 0xFFFFFFFFu, v1 = c1 != 0xFFFFFFFFu;
+                        const uint32_t f0 = L.freqs[0][lane], f1 = L.freqs[0][lane + 64];
+                        if (sf) {
+                            // The 4-byte norm_len gather is the path's largest source of memory traffic (a 64-byte
+                            // request each). doc_term_weight falls with norm_len, so the freq alone bounds the term
+                            // score: a posting whose bound (shortest document of the collection) cannot reach the heap
+                            // is dropped before its norm_len is fetched. The heap only tightens, so the verdict holds
+                            // for every later round of this block (-inf marks the dropped postings).
+                            const float suf0 = __uint_as_float(cx.m(0, M_SUF));
+                            v0 = v0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + suf0) * BOUND_SLACK);
+                            v1 = v1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + suf0) * BOUND_SLACK);
+                        }
+                        L.nl[lane] = v0 ? a.norm_lens[c0] : -1.f;
+                        L.nl[lane + 64] = v1 ? a.norm_lens[c1] : -1.f;
                         part_blk = cur0;
                         const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1)));
                         cx.s_bytes += 4ull * nv;
                         cx.s_scored += nv;
                         wave_sync();
+                        PT_END(cx, PH_SCORE);
                     }
-                    pa0 = L.part0[lane];
-                    pa1 = L.part0[lane + 64];
+                    {   // list-0 term scores of this lane's two candidates (-inf: dropped at block init)
+                        const float qw0 = __uint_as_float(cx.m(0, M_QW));
+                        const float n0 = L.nl[lane], n1 = L.nl[lane + 64];
+                        pa0 = n0 >= 0.f ? qw0 * doc_term_weight(L.freqs[0][lane], n0) : -__builtin_inff();
+                        pa1 = n1 >= 0.f ? qw0 * doc_term_weight(L.freqs[0][lane + 64], n1) : -__builtin_inff();
+                    }
                     have_p = true;
                     if (sf) {
                         const float suf0 = __uint_as_float(cx.m(0, M_SUF));
@@ -408,7 +424,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs 
                     }
                     return true;
                 }
-                if (WITH_FREQS) {
+                if constexpr (WITH_FREQS && !RANKED) {
                     if (al0) L.pos[i][lane] = (uint8_t)p0;
                     if (al1) L.pos[i][lane + 64] = (uint8_t)p1;
                 }
