@@ -214,6 +214,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    import zlib
+    # bit-level fingerprint of the first timed batch's answer (rank 0's batch; the gathered whole batch in strong mode):
+    # equal across --gpus for the same scaling mode, since every rank answers the same queries it would answer alone
+    checksum = zlib.crc32(np.ascontiguousarray(topk).tobytes(), zlib.crc32(np.ascontiguousarray(count).tobytes()))
     per_rank_q = (hi_ - lo_) if strong else args.batch
     total_q = (args.batch if strong else args.batch * world) * args.steps
     qps = total_q / elapsed
@@ -234,6 +238,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
         "timing": "end-to-end over %d distinct batches through ds2i_hip_pipeline_submit/wait (host planning + H2D + kernels + D2H), "
                   "%d in flight" % (args.steps, args.depth),
+        "first_batch_checksum": checksum,
         "kernel_resident_qps": per_rank_q * world / resident_s,  # one prepared batch re-run (rank 0's rate x ranks)
         "end_to_end_over_resident": qps / (per_rank_q * world / resident_s),
         "config": {"workload": "%s, %s, %s, batch=%d" % (W["label"], args.codec, args.op, args.batch), "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),

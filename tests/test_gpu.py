@@ -88,6 +88,36 @@ def _check_against_oracle(gidx, oidx, op, queries, k=10, reference_order=False):
     return st
 
 
+def _scale_properties(gidx, oidx, queries, nsample=48, k=10):
+    """Size-independent properties of a full batch + the oracle on a spread sample (the oracle needs seconds per
+    query at this scale)."""
+    and_count, _, _, _ = gidx.query_batch("and", queries)
+    rc, rtopk, rlen, _ = gidx.query_batch("ranked_and", queries, k=k)
+    assert np.array_equal(rlen, np.minimum(and_count, k).astype(np.uint32)) and np.array_equal(rc, rlen)
+    for i in range(len(queries)):
+        assert np.all(np.diff(rtopk[i, :rlen[i]]) <= 0)
+        assert np.all(np.isneginf(rtopk[i, rlen[i]:]))
+    rc2, rtopk2, rlen2, _ = gidx.query_batch("ranked_and", queries, k=k)  # idempotent, bit for bit
+    assert np.array_equal(rtopk, rtopk2) and np.array_equal(rlen, rlen2)
+    # a pipelined submission of the same batch in three pieces gives the same answers
+    pipe = d.Pipeline(gidx, depth=3)
+    cut = [0, len(queries) // 3, 2 * len(queries) // 3, len(queries)]
+    tickets = [pipe.submit("ranked_and", queries[cut[j]:cut[j + 1]], k=k) for j in range(3)]
+    parts = [pipe.wait(t) for t in tickets]
+    pipe.close()
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), rtopk)
+    step = max(1, len(queries) // nsample)
+    idxs = list(range(0, len(queries), step))[:nsample]
+    sample = [queries[i] for i in idxs]
+    oc, otk, otl, _, _ = oidx.query_batch("ranked_and", sample, k=k)
+    assert np.array_equal(rlen[idxs], otl)
+    f = np.isfinite(otk)
+    np.testing.assert_allclose(rtopk[idxs][f], otk[f], rtol=RTOL)
+    oac, _, _, _, _ = oidx.query_batch("and", sample)
+    assert np.array_equal(and_count[idxs], oac)
+    return rtopk, rlen
+
+
 @pytest.mark.parametrize("codec", CODECS)
 @pytest.mark.parametrize("op", ALL_OPS)
 def test_query_ops_match_oracle(coll, queries, images, codec, op):
@@ -505,44 +535,33 @@ def test_block_profile_and_hybrid_optimiser(coll, queries, images):
 
 
 def test_gov2_scale_properties(built_lib):
-    """BASELINE metric scale (25 M docs; the 8192 most frequent terms of the GOV2-scale synthetic collection, ~1 B
-    postings): size-independent properties over a 1024-query batch + the oracle on a 48-query sample."""
-    p = d.SynthParams(seed=0xD5210004, num_docs=25_000_000, num_terms=8192, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
+    """BASELINE metric configuration at its stated size (25 M docs, all 32 768 terms, ~1.7 B postings, block_optpfor,
+    4096-query batch): size-independent properties over the whole batch + the oracle on a 48-query sample; the
+    disjunctive operators on slices of the batch."""
+    p = d.SynthParams(seed=0xD5210004, num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
                       clustered_every=4)
     img, wand, postings = d.synth_build(p, "block_optpfor")
-    assert postings > 900_000_000
-    queries = d.synth_queries(0x51E21, p.num_terms, 1024)
+    assert postings > 1_500_000_000
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
     gidx = d.Index("block_optpfor", img, wand)
-    and_count, _, _, _ = gidx.query_batch("and", queries)
-    rc, rtopk, rlen, _ = gidx.query_batch("ranked_and", queries, k=10)
-    # ranked_and returns min(k, |AND|) scores, sorted descending; a second run is identical
-    assert np.array_equal(rlen, np.minimum(and_count, 10).astype(np.uint32)) and np.array_equal(rc, rlen)
-    for i in range(len(queries)):
-        assert np.all(np.diff(rtopk[i, :rlen[i]]) <= 0)
-    rc2, rtopk2, rlen2, _ = gidx.query_batch("ranked_and", queries, k=10)
-    assert np.array_equal(rtopk, rtopk2) and np.array_equal(rlen, rlen2)
+    oidx = o.Index("block_optpfor", img, wand)
+    rtopk, rlen = _scale_properties(gidx, oidx, queries)
+    and_count, _, _, _ = gidx.query_batch("and", queries[:256])
     # or >= and; wand == maxscore == ranked_or (test_ranked_queries.cpp:39-57), and they dominate ranked_and
     or_count, _, _, _ = gidx.query_batch("or", queries[:256])
-    assert np.all(or_count >= and_count[:256])
-    _, wt, wl, _ = gidx.query_batch("wand", queries, k=10)
-    _, mt, ml, _ = gidx.query_batch("maxscore", queries, k=10)
+    assert np.all(or_count >= and_count)
+    sub = queries[:1024]
+    _, wt, wl, _ = gidx.query_batch("wand", sub, k=10)
+    _, mt, ml, _ = gidx.query_batch("maxscore", sub, k=10)
     _, ot, ol, _ = gidx.query_batch("ranked_or", queries[:256], k=10)
     assert np.array_equal(wl, ml) and np.array_equal(wl[:256], ol)
     f = np.isfinite(wt)
     np.testing.assert_allclose(wt[f], mt[f], rtol=RTOL)
     f = np.isfinite(ot)
     np.testing.assert_allclose(wt[:256][f], ot[f], rtol=RTOL)
-    both = np.minimum(wl, rlen)
-    for i in range(len(queries)):
+    both = np.minimum(wl, rlen[:1024])
+    for i in range(len(sub)):
         assert np.all(wt[i, :both[i]] >= rtopk[i, :both[i]] * (1 - RTOL))
-    # the oracle on a sample (shortest queries first would be cheap; take a spread)
-    sample = queries[::21][:48]
-    oidx = o.Index("block_optpfor", img, wand)
-    oc, otk, otl, _, _ = oidx.query_batch("ranked_and", sample, k=10)
-    idxs = list(range(0, len(queries), 21))[:48]
-    assert np.array_equal(rlen[idxs], otl)
-    f = np.isfinite(otk)
-    np.testing.assert_allclose(rtopk[idxs][f], otk[f], rtol=RTOL)
 
 
 @pytest.mark.parametrize("codec", ["block_optpfor", "block_mixed"])
@@ -601,3 +620,82 @@ def test_bench_contract(built_lib):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", str(nproc)] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_device(built_lib):
+    """The N>1 path of bench.py on a single-GPU box: two ranks (gloo rendezvous, both on cuda:0), each with a full index
+    replica -- weak (every rank its own batches) and strong (one stream of batches cut with query_slice, results
+    gathered with gather_concat). The answers must be the 1-rank answers (profile_queries.cpp:21-39 shares one index
+    between threads the same way)."""
+    two = {"DS2I_BENCH_BACKEND": "gloo", "DS2I_BENCH_ONE_DEVICE": "1"}
+    common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    one_w = _run_bench(common)
+    two_w = _run_bench(common, nproc=2, env_extra=two)
+    assert one_w["n_gpus"] == 1 and two_w["n_gpus"] == 2 and two_w["scaling"] == "weak"
+    assert two_w["first_batch_checksum"] == one_w["first_batch_checksum"]  # rank 0 answers the batch it answers alone
+    assert two_w["config"]["batch_per_gpu"] == 4096 and two_w["value"] > 0.5 * one_w["value"]
+    assert two_w["cpu_baseline"] is None and two_w["roofline"]["frac"] > 0
+    one_s = _run_bench(common + ["--scaling", "strong"])
+    two_s = _run_bench(common + ["--scaling", "strong"], nproc=2, env_extra=two)
+    assert two_s["scaling"] == "strong" and two_s["config"]["batch_per_gpu"] == 2048
+    assert two_s["first_batch_checksum"] == one_s["first_batch_checksum"]  # gathered slices == the whole batch
+    assert two_s["value"] > 0
+
+
+def test_gov2_scale_opt_index_configs2(built_lib):
+    """BASELINE configs[2] at its stated size: GOV2-scale (25 M docs, all 32 768 terms, ~1.7 B postings) `opt`
+    partitioned-Elias-Fano index, ranked_and, 4096-query batch."""
+    p = d.SynthParams(seed=0xD5210004, num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
+                      clustered_every=4)
+    img, wand, postings = d.synth_build(p, "opt")
+    assert postings > 1_500_000_000
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
+    assert max(max(q) for q in queries if q) > 30000  # the whole vocabulary is in play
+    gidx = d.Index("opt", img, wand)
+    oidx = o.Index("opt", img, wand)
+    rtopk, rlen = _scale_properties(gidx, oidx, queries)
+    # wand == maxscore (test_ranked_queries.cpp:39-57) and they dominate ranked_and, on a slice of the batch
+    sub = queries[:512]
+    _, wt, wl, _ = gidx.query_batch("wand", sub, k=10)
+    _, mt, ml, _ = gidx.query_batch("maxscore", sub, k=10)
+    assert np.array_equal(wl, ml)
+    f = np.isfinite(wt)
+    np.testing.assert_allclose(wt[f], mt[f], rtol=RTOL)
+    both = np.minimum(wl, rlen[:512])
+    for i in range(len(sub)):
+        assert np.all(wt[i, :both[i]] >= rtopk[i, :both[i]] * (1 - RTOL))
+
+
+def test_clueweb_scale_block_mixed_configs4(built_lib):
+    """BASELINE configs[4] at its stated size (the per-GPU work of the 8-GPU run): ClueWeb09-B-scale (50 M docs, all
+    32 768 terms, ~3.5 B postings) block_mixed index out of the space/time optimiser, ranked_and, 4096-query batch.
+    (The sharding of the batch over ranks is covered at configs[1] scale by test_bench_two_ranks_on_one_device.)"""
+    p = d.SynthParams(seed=0xD5210005, num_docs=50_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096,
+                      clustered_every=4)
+    img, wand, postings, tc = d.synth_build_hybrid(p, budget_frac=0.5)
+    # the MI355X decode-time model never picks VarInt-G8IU (no wave64 pshufb): OptPFor and interpolative blocks mix
+    assert postings > 3_000_000_000 and sum(x > 0 for x in tc["docs"]) >= 2, tc
+    queries = d.synth_queries(0x51E21, p.num_terms, 4096)
+    gidx = d.Index("block_mixed", img, wand)
+    oidx = o.Index("block_mixed", img, wand)
+    _scale_properties(gidx, oidx, queries, nsample=32)
