@@ -197,8 +197,14 @@ def main():
     torch.cuda.synchronize()
     resident_s = (time.perf_counter() - t1) / args.steps
     count_r, topk_r, tlen_r, _ = batch.fetch()
-    assert np.array_equal(count, count_r) and np.array_equal(tlen, tlen_r) and np.array_equal(topk, topk_r), \
-        "pipelined / prepared-batch results disagree"
+    conj = args.op in ("and", "and_freq", "ranked_and")
+    if args.op in ("and", "and_freq", "or", "or_freq"):  # no top-k: counts only
+        topk = topk_r = np.zeros((len(count), 1), dtype=np.float32)
+    fin = np.isfinite(topk_r)
+    # the conjunctive operators are bit-stable from run to run; the parts of a split disjunctive query race for their
+    # shared floor, which decides the order a document's term scores are added in (same top-k up to re-association)
+    same = np.array_equal(topk, topk_r) if conj else (np.array_equal(fin, np.isfinite(topk)) and np.allclose(topk[fin], topk_r[fin], rtol=1e-6, atol=0))
+    assert np.array_equal(count, count_r) and np.array_equal(tlen, tlen_r) and same, "pipelined / prepared-batch results disagree"
     batch.set_instrumented(True)
     batch.run()
     count_i, topk_i, tlen_i, _ = batch.fetch()
@@ -276,8 +282,9 @@ def main():
         sample = queries[:nsample]
         oc, otopk, otlen, _, _ = oidx.query_batch(args.op, sample, k=10)
         assert np.array_equal(count[:nsample], oc), "GPU/oracle count mismatch"
-        fin = np.isfinite(otopk)
-        np.testing.assert_allclose(topk[:nsample][fin], otopk[fin], rtol=1e-5)
+        if args.op in ("ranked_and", "wand", "maxscore", "ranked_or"):
+            fin = np.isfinite(otopk)
+            np.testing.assert_allclose(topk[:nsample][fin], otopk[fin], rtol=1e-5)
         if not args.no_cpu_baseline and world == 1:
             # (3) cpu_baseline: the oracle driven like op_perftest (queries.cpp:13-62) on ONE core
             pt = oidx.perftest(args.op, sample, k=10, runs=2)

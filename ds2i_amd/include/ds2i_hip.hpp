@@ -17,6 +17,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ds2i_hip.h"
@@ -110,8 +111,10 @@ public:
         const uint32_t k = ranked() ? m_k : 1;
         std::vector<float> topk((size_t)nq * k, -std::numeric_limits<float>::infinity());
         std::vector<uint32_t> len(nq, 0);
-        check(ds2i_hip_query_batch(index.handle(), OP, k, terms.data(), offs.data(), nq, m_counts.data(), topk.data(),
-                                   len.data(), &m_stats),
+        // the device counters are an instrumentation option (the reference's block_profiler is a template flag too):
+        // off unless asked for, so timing loops run the uninstrumented kernels; kernel_ms is always filled
+        check(ds2i_hip_query_batch(index.handle(), OP | (m_counters ? 0 : DS2I_OP_NO_COUNTERS), k, terms.data(), offs.data(), nq,
+                                   m_counts.data(), topk.data(), len.data(), &m_stats),
               "ds2i_hip_query_batch");
         m_topk.assign(nq, std::vector<float>());
         if (ranked())
@@ -121,13 +124,61 @@ public:
     std::vector<float> const& topk() const { return m_topk.back(); }          // last query (reference shape)
     std::vector<std::vector<float>> const& topk_batch() const { return m_topk; }
     ds2i_hip_stats const& stats() const { return m_stats; }
+    void collect_counters(bool on) { m_counters = on; }
     static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
 
 private:
     uint32_t m_k;
+    bool m_counters = false;
     std::vector<uint64_t> m_counts;
     std::vector<std::vector<float>> m_topk;
     ds2i_hip_stats m_stats{};
+};
+
+// Pipelined serving loop over the C ABI's submit / wait (ds2i_hip_pipeline_*): `depth` batches in flight, the host
+// plans batch i+1 while the kernels of batch i run. Results arrive in submission order.
+class gpu_pipeline {
+public:
+    struct result {
+        std::vector<uint64_t> counts;
+        std::vector<float> topk; // nq * k, descending per query, padded with -inf (ranked operators)
+        std::vector<uint32_t> topk_len;
+        ds2i_hip_stats stats{};
+    };
+    gpu_pipeline(gpu_index const& index, uint32_t depth = 3) : m_depth(depth) {
+        check(ds2i_hip_pipeline_create(index.handle(), depth, &m_h), "ds2i_hip_pipeline_create");
+    }
+    gpu_pipeline(gpu_pipeline const&) = delete;
+    gpu_pipeline& operator=(gpu_pipeline const&) = delete;
+    ~gpu_pipeline() { ds2i_hip_pipeline_destroy(m_h); }
+    uint32_t depth() const { return m_depth; }
+    uint64_t submit(int op, uint32_t k, std::vector<term_id_vec> const& queries) {
+        std::vector<uint32_t> terms, offs(queries.size() + 1, 0);
+        for (size_t q = 0; q < queries.size(); ++q) {
+            terms.insert(terms.end(), queries[q].begin(), queries[q].end());
+            offs[q + 1] = (uint32_t)terms.size();
+        }
+        if (terms.empty()) terms.push_back(0);
+        uint64_t ticket = 0;
+        check(ds2i_hip_pipeline_submit(m_h, op, k, terms.data(), offs.data(), (uint32_t)queries.size(), &ticket), "ds2i_hip_pipeline_submit");
+        if (m_meta.size() <= ticket % m_depth) m_meta.resize(m_depth);
+        m_meta[ticket % m_depth] = {(uint32_t)queries.size(), ((op & 0xFF) >= DS2I_OP_RANKED_AND) ? k : 1u};
+        return ticket;
+    }
+    result wait(uint64_t ticket) {
+        const auto meta = m_meta.at(ticket % m_depth);
+        result r;
+        r.counts.assign(meta.first, 0);
+        r.topk.assign((size_t)meta.first * meta.second, -std::numeric_limits<float>::infinity());
+        r.topk_len.assign(meta.first, 0);
+        check(ds2i_hip_pipeline_wait(m_h, ticket, r.counts.data(), r.topk.data(), r.topk_len.data(), &r.stats), "ds2i_hip_pipeline_wait");
+        return r;
+    }
+
+private:
+    ds2i_hip_pipeline* m_h = nullptr;
+    uint32_t m_depth;
+    std::vector<std::pair<uint32_t, uint32_t>> m_meta;
 };
 
 typedef gpu_query_op<DS2I_OP_AND> and_query;

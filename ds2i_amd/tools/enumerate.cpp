@@ -1,0 +1,51 @@
+// enumerate -- walks one posting list through the reference's document_enumerator API (block_posting_list.hpp:84-186:
+// docid(), freq(), next(), next_geq(), move(), position(), size(); exhausted <=> docid() == num_docs()) as presented by
+// ds2i_hip::gpu_index::operator[]. Prints "docid freq" per posting for `next` mode, or the landing (docid, position) of
+// every probe for `next_geq` / `move` mode. Used by the tests to hold the adaptor's enumerator against the raw lists.
+//
+//   enumerate <index_type> <index_file> <term> next
+//   enumerate <index_type> <index_file> <term> next_geq <lower_bound>...
+//   enumerate <index_type> <index_file> <term> move <position>...
+#include <cstdlib>
+
+#include "../include/ds2i_hip.hpp"
+#include "tool_util.hpp"
+
+int main(int argc, const char** argv) {
+    if (argc < 5) {
+        std::cerr << "usage: " << argv[0] << " <index_type> <index_file> <term> next|next_geq|move [args...]\n";
+        return 1;
+    }
+    const int kind = tool::kind_of(argv[1]);
+    if (kind < 0) {
+        tool::logger(std::string("ERROR: Unknown type ") + argv[1]);
+        return 0;
+    }
+    try {
+        tool::mapped_file m(argv[2]);
+        ds2i_hip::gpu_index index(kind, m.data, m.size);
+        auto e = index[(size_t)std::strtoull(argv[3], nullptr, 10)];
+        const std::string mode = argv[4];
+        std::printf("size %llu num_docs %llu\n", (unsigned long long)e.size(), (unsigned long long)index.num_docs());
+        if (mode == "next") {
+            for (; e.docid() < index.num_docs(); e.next())
+                std::printf("%llu %llu\n", (unsigned long long)e.docid(), (unsigned long long)e.freq());
+        } else if (mode == "next_geq") {
+            for (int i = 5; i < argc; ++i) { // forward-only, like the reference (block_posting_list.hpp:124-126)
+                e.next_geq(std::strtoull(argv[i], nullptr, 10));
+                std::printf("%llu %llu\n", (unsigned long long)e.docid(), (unsigned long long)e.position());
+            }
+        } else if (mode == "move") {
+            for (int i = 5; i < argc; ++i) {
+                e.move(std::strtoull(argv[i], nullptr, 10));
+                std::printf("%llu %llu\n", (unsigned long long)e.docid(), (unsigned long long)e.position());
+            }
+            e.reset();
+            std::printf("%llu %llu\n", (unsigned long long)e.docid(), (unsigned long long)e.position());
+        }
+    } catch (std::exception const& ex) {
+        tool::logger(std::string("ERROR: ") + ex.what());
+        return 2;
+    }
+    return 0;
+}

@@ -18,6 +18,10 @@ using namespace ds2i_hip;
 template <class Op>
 void op_perftest(gpu_index const& index, Op&& op, std::vector<term_id_vec> const& queries, std::string const& type,
                  std::string const& query_type, size_t runs) {
+    if (queries.empty()) { // nothing to time (the reference would divide by zero here, queries.cpp:36-40)
+        tool::logger("---- " + type + " " + query_type + ": empty query log, nothing to do");
+        return;
+    }
     double total = 0, kernel_ms = 0;
     for (size_t run = 0; run <= runs; ++run) {
         double tick = tool::get_time_usecs();
@@ -35,7 +39,8 @@ void op_perftest(gpu_index const& index, Op&& op, std::vector<term_id_vec> const
         lat.push_back(tool::get_time_usecs() - tick);
     }
     std::sort(lat.begin(), lat.end());
-    const double q50 = lat[lat.size() / 2], q90 = lat[90 * lat.size() / 100], q95 = lat[95 * lat.size() / 100];
+    auto quantile = [&](size_t pct) { return lat[std::min(lat.size() - 1, pct * lat.size() / 100)]; };
+    const double q50 = quantile(50), q90 = quantile(90), q95 = quantile(95);
     std::ostringstream os;
     os << "---- " << type << " " << query_type << "\nMean: " << avg << "\n50% quantile: " << q50
        << "\n90% quantile: " << q90 << "\n95% quantile: " << q95;

@@ -68,6 +68,31 @@ def test_golden_appendix_c(built_lib):
     assert d.encode_posting_list(pl["codec"], pl["docs"], pl["freqs"]).hex() == pl["hex"]
 
 
+def test_golden_appendix_c_qmx_rows_live(built_lib):
+    """The QMX rows of appendix_c.json regenerated from the reference's own encoder (oracle/_ref): the only rows of that
+    fixture whose provenance is reproducible here (the others are survey-session values, see its _provenance)."""
+    R = o.ref_qmx()
+    if R is None:
+        pytest.skip("oracle/_ref/libqmx_ref.so not built (needs /root/reference at build time)")
+    g = json.load(open(GOLD))
+    n = 0
+    for case in g["blocks"]:
+        if case["codec"] != "block_qmx" or len(case["values"]) != 128:
+            continue
+        v = np.ascontiguousarray(case["values"], dtype=np.uint32)
+        buf = np.zeros(8192, dtype=np.uint8)
+        ln = R.ref_qmx_encode(buf.ctypes.data, v.ctypes.data)
+        live = (d.encode_vbyte(ln) + bytes(buf[:ln])).hex()
+        if "hex" in case:
+            assert live == case["hex"], case["name"]
+        if "len" in case:
+            assert len(live) // 2 == case["len"], case["name"]
+        if "prefix" in case:
+            assert live.startswith(case["prefix"]) and live.endswith(case["suffix"]), case["name"]
+        n += 1
+    assert n >= 3
+
+
 def test_qmx_against_reference_codec(built_lib):
     """oracle/_ref = the reference's qmx_codec.hpp compiled as-is: encoder bytes and decoder output must agree."""
     R = o.ref_qmx()

@@ -55,6 +55,33 @@ def test_device_bm25_equals_reference_fixture(built_lib):
     assert np.array_equal(out.view(np.uint32), dtw[:, 2].astype(np.uint32))
 
 
+def test_device_qmx_decodes_reference_encoder_bytes(built_lib):
+    """The HIP QMX decoder fed with byte streams written by the REFERENCE's own encoder (tests/golden/
+    qmx_reference_blocks.json, from /root/reference/qmx_codec.hpp compiled as-is): posting lists are assembled by hand
+    from those bytes (block_posting_list.hpp:13-53 layout), checked to be what the index image holds, and decoded on
+    the GPU."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qmx_reference_blocks.json")))
+    cases = [c for c in g["cases"] if c["mag"] <= 20]
+    lists, raw = [], []
+    for j in range(0, len(cases) - 1, 2):
+        gaps, fr = np.asarray(cases[j]["values"], np.uint64), np.asarray(cases[j + 1]["values"], np.uint64)
+        docs = (np.cumsum(gaps + 1) - 1).astype(np.uint32)          # docs block codes gap - 1
+        freqs = (fr + 1).astype(np.uint32)                            # freqs block codes freq - 1
+        lists.append((docs, freqs))
+        blk = lambda c: d.encode_vbyte(len(c["hex"]) // 2) + bytes.fromhex(c["hex"])  # qmx_block: vbyte(len) | stream
+        raw.append(d.encode_vbyte(128) + int(docs[-1]).to_bytes(4, "little") + blk(cases[j]) + blk(cases[j + 1]))
+    N = int(max(int(dd[-1]) for dd, _ in lists)) + 1
+    img = d.build_index("block_qmx", N, lists)
+    for r in raw:  # the image's list bytes ARE the reference encoder's bytes
+        assert r in img
+    gidx = d.Index("block_qmx", img)
+    for t, (docs, freqs) in enumerate(lists):
+        dd, ff = gidx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+
+
 @pytest.mark.parametrize("codec", CODECS)
 def test_decode_every_list(coll, images, codec):
     idx = d.Index(codec, images[0][codec])
@@ -491,6 +518,39 @@ def test_queries_cli_and_cpp_adaptor(coll, queries, images, tmp_path):
     assert "Unsupported query type: bogus" in r.stderr
     r = subprocess.run([tool, "no_such_index", "and", str(idx_path)], input=log, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "ERROR: Unknown type" in r.stderr  # queries.cpp:149-151
+
+
+def test_cpp_adaptor_document_enumerator(coll, images, tmp_path):
+    """ds2i_hip::gpu_index::operator[] -> document_enumerator (the Index concept of SURVEY.md 8b): next / next_geq / move /
+    reset / position / size and the exhaustion sentinel docid() == num_docs(), through the `enumerate` tool."""
+    import os
+    import subprocess
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ds2i_amd", "tools")
+    tool = os.path.join(tools, "enumerate")
+    subprocess.check_call(["make", "-C", tools, "-s"])
+    rng = np.random.default_rng(11)
+    for codec in ("block_optpfor", "opt"):
+        path = tmp_path / ("idx_" + codec)
+        path.write_bytes(images[0][codec])
+        for t in (0, 7, 150, 299):
+            docs, freqs = coll.lists[t]
+            out = subprocess.run([tool, codec, str(path), str(t), "next"], capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr
+            lines = out.stdout.split("\n")
+            assert lines[0] == "size %d num_docs %d" % (len(docs), coll.num_docs)
+            got = np.array([l.split() for l in lines[1:] if l], dtype=np.uint64)
+            assert np.array_equal(got[:, 0], docs) and np.array_equal(got[:, 1], freqs), (codec, t)
+            probes = np.sort(rng.integers(0, coll.num_docs + 50, 12))
+            out = subprocess.run([tool, codec, str(path), str(t), "next_geq"] + [str(x) for x in probes], capture_output=True, text=True, timeout=120)
+            got = np.array([l.split() for l in out.stdout.split("\n")[1:] if l], dtype=np.uint64)
+            pos = np.searchsorted(docs, probes)
+            exp = np.where(pos < len(docs), docs[np.minimum(pos, len(docs) - 1)], coll.num_docs)
+            assert np.array_equal(got[:, 0], exp) and np.array_equal(got[:, 1], pos), (codec, t)
+            ps = rng.integers(0, len(docs), 5)
+            out = subprocess.run([tool, codec, str(path), str(t), "move"] + [str(x) for x in ps], capture_output=True, text=True, timeout=120)
+            got = np.array([l.split() for l in out.stdout.split("\n")[1:] if l], dtype=np.uint64)
+            assert np.array_equal(got[:-1, 0], docs[ps]) and np.array_equal(got[:-1, 1], ps)
+            assert got[-1, 0] == docs[0] and got[-1, 1] == 0  # reset()
 
 
 def test_block_profile_and_hybrid_optimiser(coll, queries, images):
