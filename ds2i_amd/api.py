@@ -99,6 +99,9 @@ def lib():
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
         L.ds2i_hip_selftest_bm25.argtypes = [C.c_int, vp, vp, vp, C.c_uint32]
+        L.ds2i_hip_synth_encode.argtypes = [C.c_int, C.POINTER(SynthParams), C.c_int, C.POINTER(vp), C.POINTER(vp), u64p,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ds2i_hip_encode_index.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_double)]
         # build side
         L.ds2i_blob_data.argtypes = [vp]
         L.ds2i_blob_data.restype = vp
@@ -192,6 +195,30 @@ def build_index(codec, num_docs, lists):
         return _take_blob(h)
     finally:
         L.ds2i_builder_free(b)
+
+
+def gpu_encode_index(num_docs, lists, device=0, codec="block_optpfor"):
+    """The index image of `lists` (iterable of (docs, freqs)) encoded ON THE GPU (ds2i_hip_encode_index): byte-identical
+    to build_index(codec, num_docs, lists). Returns (image bytes, device milliseconds of the two kernel passes)."""
+    lists = [(_u32(dd), _u32(ff)) for dd, ff in lists]
+    offs = np.zeros(len(lists) + 1, dtype=np.uint64)
+    for i, (dd, _) in enumerate(lists):
+        offs[i + 1] = offs[i] + len(dd)
+    docs = np.concatenate([dd for dd, _ in lists]) if lists else np.zeros(1, np.uint32)
+    freqs = np.concatenate([ff for _, ff in lists]) if lists else np.zeros(1, np.uint32)
+    h, ms = C.c_void_p(), C.c_double()
+    _check(lib().ds2i_hip_encode_index(device, _codec(codec), num_docs, len(lists), _ptr(offs), _ptr(docs), _ptr(freqs),
+                                       C.byref(h), C.byref(ms)))
+    return _take_blob(h), ms.value
+
+
+def synth_build_gpu(p, device=0, threads=0):
+    """The synthetic collection as a block_optpfor index encoded on the GPU (ds2i_hip_synth_encode).
+    -> (index image, wand image, postings, dict(generate_s, device_ms))"""
+    hi, hw = C.c_void_p(), C.c_void_p()
+    n, gs, ms = C.c_uint64(), C.c_double(), C.c_double()
+    _check(lib().ds2i_hip_synth_encode(device, C.byref(p), threads, C.byref(hi), C.byref(hw), C.byref(n), C.byref(gs), C.byref(ms)))
+    return _take_blob(hi), _take_blob(hw), n.value, {"generate_s": gs.value, "device_ms": ms.value}
 
 
 def build_wand(doc_sizes, lists):

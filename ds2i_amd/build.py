@@ -11,10 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libds2i_hip.so")
 ARCH = "gfx950"
 
-# kernels.hip is compiled five times: once per list-count class (-DDS2I_TU_TMAX=n: the query kernels of that class)
-# and once for everything else; the translation units are built in parallel
-DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", [])]
-HOST_SRCS = ["capi.cpp", "capi_batch.cpp", "capi_build.cpp"]
+# kernels.hip is compiled six times: once per list-count class (-DDS2I_TU_TMAX=n: the query kernels of that class; 0 = the
+# long class) and once for everything else; encode_kernels.hip holds the index encoder; all units are built in parallel
+DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", []), ("encode_kernels.hip", "encode_kernels.hip", [])]
+HOST_SRCS = ["capi.cpp", "capi_batch.cpp", "capi_build.cpp", "capi_encode.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "../../include/ds2i_build.h"
+#include "capi_blob.hpp"
 #include "capi_error.hpp"
 #include "host_encode.hpp"
 #include "host_index.hpp"
@@ -16,7 +17,6 @@
 
 using namespace ds2i_host;
 
-struct ds2i_blob { bytes_t data; };
 struct ds2i_builder {
     std::unique_ptr<block_index_builder> b;   // kinds 0..4
     std::unique_ptr<opt_index_builder> opt;   // kinds 5..8 (DS2I_OPT / EF / SINGLE / UNIFORM)

@@ -165,6 +165,13 @@ public:
         m_lists.insert(m_lists.end(), data, data + len);
         m_endpoints.push_back(m_lists.size());
     }
+    // all lists at once, already encoded (the GPU encoder): `lists` = the concatenated list bytes, `ends` = the end
+    // offset of every list
+    void set_encoded_lists(bytes_t&& lists, std::vector<uint64_t> const& ends) {
+        m_lists = std::move(lists);
+        m_endpoints.assign(1, 0);
+        m_endpoints.insert(m_endpoints.end(), ends.begin(), ends.end());
+    }
     uint64_t lists() const { return m_endpoints.size() - 1; }
     // image = 5 B params | u64 m_size | u64 m_num_docs | bit_vector{u64 bits; u64 nwords; words} | u64 nbytes; bytes
     void freeze(bytes_t& out) const {

@@ -172,6 +172,23 @@ int ds2i_hip_pipeline_class_stats(ds2i_hip_pipeline* p, int cls, ds2i_hip_stats*
 int ds2i_hip_pipeline_set_instrumented(ds2i_hip_pipeline* p, int on);
 void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p);
 
+/* GPU index encoder (build side): block_posting_list::write (block_posting_list.hpp:13-53) with
+ * optpfor_block::encode + ds2i's findBestB (block_codecs.hpp:156-208) as HIP kernels, one wavefront per 128-posting
+ * block. Input: nlists posting lists in CSR form (list t = docs / freqs [list_offsets[t], list_offsets[t+1])), sorted
+ * doc-ids < num_docs, freqs >= 1. Output: the frozen block_freq_index<optpfor_block> image (ds2i_blob_* of
+ * ds2i_build.h release it), byte-identical to the host builder's (ds2i_builder_*). index_kind must be
+ * DS2I_BLOCK_OPTPFOR. device_ms (may be NULL) receives the hipEvent time of the two kernel passes. */
+typedef struct ds2i_blob ds2i_blob;
+int ds2i_hip_encode_index(int device, int index_kind, uint64_t num_docs, uint64_t nlists, const uint64_t* list_offsets,
+                          const uint32_t* docs, const uint32_t* freqs, ds2i_blob** image, double* device_ms);
+
+/* The synthetic collection of ds2i_build.h generated on `threads` host threads (<= 0: all) and encoded on the GPU;
+ * the same two images as ds2i_synth_build(p, DS2I_BLOCK_OPTPFOR, ...), byte for byte. wand_image, total_postings,
+ * generate_s (host seconds spent generating the lists) and device_ms may be NULL. */
+struct ds2i_synth_params;
+int ds2i_hip_synth_encode(int device, const struct ds2i_synth_params* p, int threads, ds2i_blob** index_image,
+                          ds2i_blob** wand_image, uint64_t* total_postings, double* generate_s, double* device_ms);
+
 /* profiling aid: streams the whole index arena once with the decoders' load shape (calibrates FETCH_SIZE) */
 int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read);
 /* GPU unit-test hook: wave64 inclusive prefix sum over rows of 64 values */

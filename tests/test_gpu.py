@@ -520,6 +520,51 @@ def test_queries_cli_and_cpp_adaptor(coll, queries, images, tmp_path):
     assert r.returncode == 0 and "ERROR: Unknown type" in r.stderr  # queries.cpp:149-151
 
 
+def test_gpu_encode_is_byte_identical(coll, images):
+    """SURVEY.md 8(f) item 2: block_posting_list::write + OptPFor findBestB / pack as HIP kernels. The image the GPU
+    encoder produces must be the host builder's image byte for byte -- tiny lists, partial (interpolative) tail blocks,
+    every exception regime, raw 32-bit blocks -- and the query path must run on it."""
+    img, ms = d.gpu_encode_index(coll.num_docs, coll.lists)
+    assert img == images[0]["block_optpfor"]
+    # exception-count sweep (0..110 exceptions per block, docs and freqs), huge values (b = 32 raw blocks), length-1 lists
+    rng = np.random.default_rng(99)
+    nblk = 111
+    freqs = rng.integers(1, 5, 128 * nblk).astype(np.uint32)
+    gaps = rng.integers(1, 5, 128 * nblk).astype(np.uint64)
+    for k in range(nblk):
+        pos = rng.choice(128, k, replace=False) + 128 * k
+        freqs[pos] = 1 + (1 << 10) + rng.integers(0, 1 << 9, k).astype(np.uint32)
+        pos = rng.choice(128, k, replace=False) + 128 * k
+        gaps[pos] = 1 + (1 << 9) + rng.integers(0, 1 << 8, k)
+    docs = (np.cumsum(gaps) - 1).astype(np.uint32)
+    big_d = (np.cumsum(rng.integers(1, 1 << 19, 128 * 3 + 5).astype(np.uint64)) - 1).astype(np.uint32)
+    big_f = rng.integers(1, (1 << 31) - 2, len(big_d)).astype(np.uint32)
+    big_f[384:] = rng.integers(1, 1 << 20, len(big_d) - 384)
+    lists = [(docs, freqs), (big_d, big_f), (np.array([7], np.uint32), np.array([3], np.uint32)),
+             (np.arange(0, 127, dtype=np.uint32), np.ones(127, np.uint32)), (np.arange(5, 5 + 128, dtype=np.uint32), np.full(128, 9, np.uint32))]
+    N = int(max(int(dd[-1]) for dd, _ in lists)) + 10
+    img2, _ = d.gpu_encode_index(N, lists)
+    assert img2 == d.build_index("block_optpfor", N, lists)
+    # configs[1]-shaped collection (1 M docs, Zipf lengths, clustered lists): 4096 terms of it
+    p = d.SynthParams(seed=0xD5210002, num_docs=1000000, num_terms=4096, zipf_exp=0.75, top_df_frac=0.5, min_len=128,
+                      clustered_every=4)
+    c2 = [d.synth_list(p, t) for t in range(p.num_terms)]
+    img3, ms3 = d.gpu_encode_index(p.num_docs, c2)
+    host_img, _, postings = d.synth_build(p, "block_optpfor")
+    assert img3 == host_img and ms3 > 0
+    gidx = d.Index("block_optpfor", img3)
+    dd, ff = gidx[17]
+    assert np.array_equal(dd, c2[17][0]) and np.array_equal(ff, c2[17][1])
+    # the whole configs[1] collection (65 536 terms, 52 M postings) through the one-call form
+    p = d.SynthParams(seed=0xD5210002, num_docs=1000000, num_terms=65536, zipf_exp=0.75, top_df_frac=0.5, min_len=128,
+                      clustered_every=4)
+    gi, gw, gn, info = d.synth_build_gpu(p)
+    hi, hw, hn = d.synth_build(p, "block_optpfor")
+    assert gn == hn and gi == hi and gw == hw and info["device_ms"] > 0
+    with pytest.raises(d.Ds2iError):
+        d.gpu_encode_index(10, [(np.zeros(0, np.uint32), np.zeros(0, np.uint32))])  # "List must be nonempty"
+
+
 def test_cpp_adaptor_document_enumerator(coll, images, tmp_path):
     """ds2i_hip::gpu_index::operator[] -> document_enumerator (the Index concept of SURVEY.md 8b): next / next_geq / move /
     reset / position / size and the exhaustion sentinel docid() == num_docs(), through the `enumerate` tool."""
