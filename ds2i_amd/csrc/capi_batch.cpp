@@ -201,6 +201,12 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             }
             if (qterms.size() - begin == 1)
                 qterms[begin].floor1 = qterms[begin].q_weight * idx->list_topbmw[(size_t)tf[0].first * DS2I_HIP_MAX_K + (k - 1)];
+            if (!conj) { // top-k of the UNION: any one term's k-th best block weight is a floor of the k-th score
+                float f = 0.f;
+                for (size_t i = 0; i < tf.size(); ++i)
+                    f = std::max(f, qterms[begin + i].q_weight * idx->list_topbmw[(size_t)tf[i].first * DS2I_HIP_MAX_K + (k - 1)]);
+                qterms[begin].floor1 = f;
+            }
         }
         qoff[q + 1] = (uint32_t)qterms.size();
         qcost[q] = cost;
@@ -320,7 +326,8 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     b->o_unit_topk_len = place(4 * nu1);
     b->o_unit_freq_sum = place(8 * nu1);
     // ranked_and: a 256-bucket score histogram per query (kernels.hip); the disjunctive operators: one floor word
-    const bool hist = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && idx->d_bmw && b->nsplit;
+    const bool disj_ranked = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
+    const bool hist = !(op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_ranked);
     b->o_qfloor = place(hist ? 1024 * nq1 : 4 * nq1);
     b->scr_bytes = o;
 
@@ -469,8 +476,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.seed_topk = b->use_seed ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
         a.seed_len = b->use_seed ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
         const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-        a.q_floor = (disj_topk && !(b->op & DS2I_OP_REFERENCE_ORDER)) ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
-        a.q_hist = (base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && idx->d_bmw && b->nsplit)
+        a.q_floor = nullptr;
+        a.q_hist = (!(b->op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_topk))
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
         a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
         a.skip = no_skiptab ? nullptr : idx->d_skip;

@@ -103,6 +103,46 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
             if (!body(i_)) break;                                    \
     }
 
+// Shared score histogram of the parts of a split ranked query: 256 buckets over [0, the query's score bound]. Every
+// score that enters a part's heap is counted; a part's floor is the lower edge of the highest bucket with >= k documents
+// at or above it -- a lower bound of the whole query's k-th score that tightens with every part's progress, not just
+// with the best single part. `relax` widens the edge for operators whose parts may add a document's term scores in
+// different orders (the disjunctive kernel); ranked_and's parts add them in the same order, bit for bit.
+struct ScoreHist {
+    unsigned int* h; // 256 counters of this query, or null
+    float scale, inv, relax;
+    DS2I_DEV void init(unsigned int* base, uint32_t q, float score_bound, float relax_) {
+        h = base ? base + 256u * q : nullptr;
+        scale = score_bound * (1.0f / 256.0f);
+        inv = score_bound > 0.f ? 256.0f / score_bound : 0.f;
+        relax = relax_;
+    }
+    // lower bound of the k-th score of the union, or -inf (relaxed agent-scope loads: the counters are updated by
+    // other CUs' atomics and must not come from a stale L1 line)
+    DS2I_DEV float floor(uint32_t k) const {
+        const uint32_t lane = lane_id();
+        const unsigned int* hp = h + 252u - 4u * lane; // lane l holds buckets 255-4l .. 252-4l: highest scores in lane 0
+        const uint32_t x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mine = x + y + z + w;
+        const uint32_t incl = wave_incl_scan(mine);
+        const uint64_t full = ballot(incl >= k);
+        if (!full) return -__builtin_inff();
+        const uint32_t fl = (uint32_t)__builtin_ctzll(full);
+        const uint32_t before = bcast(incl - mine, fl), bw = bcast(w, fl), bz = bcast(z, fl), by = bcast(y, fl);
+        uint32_t bucket = 255u - 4u * fl, c = before + bw; // inside lane fl the buckets from the top are w, z, y, x
+        if (c < k) { --bucket; c += bz; if (c < k) { --bucket; c += by; if (c < k) --bucket; } }
+        return (float)bucket * scale * relax;
+    }
+    DS2I_DEV void add(float v) const { // one lane
+        uint32_t b = (uint32_t)(v * inv);
+        b = b > 255u ? 255u : b;
+        __hip_atomic_fetch_add(h + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 // Slack of the ranked_and pruning bound. A document's score is the float32 sum of its term scores in list order
 // (queries.hpp:372-380); the bound adds, in a different association, the current blocks' weights of the lists already
 // positioned and one precomputed suffix sum for the lists still to come. Both evaluate the same real sum of <= 17
@@ -172,42 +212,16 @@ __global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs 
         const unsigned long long mbase = a.out_matches ? a.match_off[q] + 128ull * u.blk_begin : 0;
         const unsigned long long mcap = a.out_matches ? 128ull * (u.blk_end - u.blk_begin) : 0;
         // ---- pruning state (ranked_and with a bmw table)
-        // The parts of a split query share a SCORE HISTOGRAM (256 buckets over [0, the query's score bound]): every
-        // score that enters a part's heap is counted, and a part's floor is the lower edge of the highest bucket with
-        // >= k documents at or above it -- a lower bound of the whole query's k-th score that tightens with every part's
-        // progress, not just with the best single part (all parts add a document's terms in the same order, so the
-        // scores are comparable bit for bit; a dropped document scores <= the floor <= the final threshold).
+        // the parts of a split query share a score histogram (ScoreHist): the floor it yields is exact to compare against,
+        // since all parts add a document's terms in the same order (a dropped document scores <= floor <= final threshold)
         const bool shared_floor = RANKED && bmw && !whole && a.q_hist;
-        unsigned int* const hist = shared_floor ? a.q_hist + 256u * q : nullptr;
-        float h_scale = 0.f, h_inv = 0.f; // bucket b covers [b * h_scale, (b + 1) * h_scale)
-        if (shared_floor) {
-            const float mx = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw)));
-            h_scale = mx * (1.0f / 256.0f);
-            h_inv = mx > 0.f ? 256.0f / mx : 0.f;
-        }
+        ScoreHist sh;
+        sh.init(shared_floor ? a.q_hist : nullptr, q,
+                shared_floor ? __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw))) : 0.f,
+                1.0f - 1.0f / 1048576.0f);
         auto adopt_floor = [&]() __attribute__((always_inline)) {
-            // lane l reads buckets 255-4l .. 252-4l (highest scores in lane 0); suffix counts by one wave scan
-            // (relaxed agent-scope loads: the counts are updated by atomics of other CUs and must not come from a stale L1 line)
-            const unsigned int* hp = hist + 252u - 4u * lane;
-            uint4 hv;
-            hv.x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hv.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hv.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hv.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t mine = hv.x + hv.y + hv.z + hv.w;
-            const uint32_t incl = wave_incl_scan(mine);
-            const uint64_t full = ballot(incl >= tk.k);
-            if (full) {
-                const uint32_t fl = (uint32_t)__builtin_ctzll(full);
-                // inside lane fl: buckets from the top are w, z, y, x
-                const uint32_t before = bcast(incl - mine, fl);
-                const uint32_t bw = bcast(hv.w, fl), bz = bcast(hv.z, fl), by = bcast(hv.y, fl);
-                uint32_t bucket = 255u - 4u * fl;
-                uint32_t c = before + bw;
-                if (c < tk.k) { --bucket; c += bz; if (c < tk.k) { --bucket; c += by; if (c < tk.k) --bucket; } }
-                const float f = (float)bucket * h_scale * (1.0f - 1.0f / 1048576.0f);
-                if (f > tk.floor) tk.floor = f;
-            }
+            const float f = sh.floor(tk.k);
+            if (f > tk.floor) tk.floor = f;
         };
         if (RANKED && bmw && nt == 1) // k blocks of the list hold a document reaching floor1 (computed at upload)
             tk.floor = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1)));
@@ -480,11 +494,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs 
                             uint32_t src = (uint32_t)__builtin_ctzll(todo);
                             todo &= todo - 1;
                             const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
-                            if (tk.insert(v) && shared_floor && lane == 0) {
-                                uint32_t bkt = (uint32_t)(v * h_inv);
-                                bkt = bkt > 255u ? 255u : bkt;
-                                __hip_atomic_fetch_add(hist + bkt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
+                            if (tk.insert(v) && shared_floor && lane == 0) sh.add(v);
                         }
                     }
 #ifdef DS2I_PHASE_TIMING
@@ -873,6 +883,12 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             const float kth = a.seed_topk[(size_t)q * a.k + a.k - 1];
             tk.floor = __uint_as_float(uniform(__float_as_uint(kth * (1.0f - 1.0e-5f))));
         }
+        if (MODE == 0) {
+            // static floor (host, from the upload-time block weights): some term of the query has k blocks whose best
+            // posting alone scores >= floor1, and a document's score is >= any one of its term scores
+            const float f1 = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1)));
+            if (f1 > tk.floor) tk.floor = f1;
+        }
         if (lane == 0) {
             for (uint32_t i = 0; i < nt; ++i) { L.lord[i] = i; L.nomore[i] = 0xFFFFFFFFu; }
             for (uint32_t i = 1; i < nt; ++i) { // stable insertion sort by max score (queries.hpp:529-533)
@@ -922,9 +938,13 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             if (blk != cur) cx.decode_docs(x, blk, tabbed ? &bi : nullptr);
             return true;
         };
-        const bool shared_floor = MODE == 0 && !whole && a.q_floor;
-        auto adopt_floor = [&]() __attribute__((always_inline)) { // another part of this query may have raised the bar
-            const float f = __uint_as_float(uniform(__hip_atomic_load(a.q_floor + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        // the parts of a split query share a score histogram (ScoreHist). Parts may add a document's term scores in
+        // different orders (which lists are essential depends on each part's threshold), hence the 1e-5 relaxation
+        const bool shared_floor = MODE == 0 && !whole && a.q_hist;
+        ScoreHist sh;
+        sh.init(shared_floor ? a.q_hist : nullptr, q, shared_floor ? ubf(nt - 1) : 0.f, 1.0f - 1.0e-5f);
+        auto adopt_floor = [&]() __attribute__((always_inline)) { // the other parts of this query may have raised the bar
+            const float f = sh.floor(tk.k);
             if (f > tk.floor) { tk.floor = f; update_non_ess(); }
         };
         while (non_ess < nt && lo < N) {
@@ -1053,14 +1073,14 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     while (todo) {
                         const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1;
-                        inserted |= tk.insert(__uint_as_float(bcast(__float_as_uint(sc), src)));
+                        const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
+                        if (tk.insert(v)) {
+                            inserted = true;
+                            if (shared_floor && lane == 0) sh.add(v);
+                        }
                     }
                 }
-                if (inserted) {
-                    update_non_ess(); // queries.hpp:568-574
-                    if (shared_floor && tk.n >= tk.k && lane == 0)
-                        __hip_atomic_fetch_max(a.q_floor + q, __float_as_uint(tk.threshold()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (inserted) update_non_ess(); // queries.hpp:568-574
             }
             if (hi == 0xFFFFFFFFu) break;
             lo = hi + 1;
