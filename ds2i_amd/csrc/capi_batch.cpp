@@ -273,10 +273,17 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             // top-k (its own pruning threshold), the merge is exact
             const uint32_t N = (uint32_t)idx->num_docs;
             uint32_t parts = 1;
-            // every part re-seeks its lists (the parts of a query share their pruning floor through q_floor), and the
-            // many-list classes pay that per list: they want coarser parts than the one/two-list class (measured on
-            // the GOV2-scale batch)
-            static const double disj_scale[NCLS] = {8.0, 2.0, 1.0, 1.0, 1.0};
+            // every part re-seeks its lists; how fine the parts should be cut per class was measured on the GOV2-scale
+            // batch (wand, queries/s): {8,2,1,1} 50.6 k, {8,2,2,2} 54.5 k, {8,4,4,4} 55.4 k, {4,2,4,4} 55.7 k -- with the
+            // shared score histogram a part no longer has to warm up its own threshold, so the latency-bound many-list
+            // classes gain from finer parts
+            static double disj_scale[NCLS] = {4.0, 2.0, 4.0, 4.0, 1.0};
+            static const bool scale_from_env = [] { // DS2I_DISJ_SCALE="a,b,c,d": A/B knob
+                const char* e = std::getenv("DS2I_DISJ_SCALE");
+                if (e) std::sscanf(e, "%lf,%lf,%lf,%lf", &disj_scale[0], &disj_scale[1], &disj_scale[2], &disj_scale[3]);
+                return e != nullptr;
+            }();
+            (void)scale_from_env;
             const double dtarget = std::max(48.0, all_cost / (unit_factor * disj_scale[c] * resident));
             if (nt && N > 1)
                 parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));

@@ -999,7 +999,18 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                 }
                 uint32_t fm0 = 0, fm1 = 0; // lists (beyond e) each candidate occurs in
                 const float ub_ne = non_ess ? ubf(non_ess - 1) : 0.f;
-                float pb0 = maxw(e) + ub_ne, pb1 = pb0;
+                // The owner's term score is bounded by its freq alone (doc_term_weight falls with norm_len, so the
+                // collection's shortest document bounds it): most postings of a list have small freqs and fall below
+                // the threshold here -- before their norm_len is gathered or a non-essential list is probed for them.
+                if (!cx.m(e, M_FDEC)) cx.decode_freqs(e);
+                float pb0, pb1;
+                {
+                    const float we = qw(e), me = maxw(e);
+                    const float fb0 = we * doc_term_weight(L.freqs[e][lane], a.min_norm_len);
+                    const float fb1 = we * doc_term_weight(L.freqs[e][lane + 64], a.min_norm_len);
+                    pb0 = (fb0 < me ? fb0 : me) + ub_ne;
+                    pb1 = (fb1 < me ? fb1 : me) + ub_ne;
+                }
                 for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
                     const uint32_t x = slot_at(p2);
                     if (!((live >> x) & 1u)) continue;
@@ -1013,8 +1024,8 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     PT_END(cx, PH_MEMBER);
                 }
                 wave_sync();
-                // max-score bound first: nothing below it is decoded, gathered or scored
-                bool s0 = v0 && tk.would_enter(pb0), s1 = v1 && tk.would_enter(pb1);
+                // max-score bound first: nothing below it is gathered, scored or looked up in the non-essential lists
+                bool s0 = v0 && tk.would_enter(pb0 * BOUND_SLACK), s1 = v1 && tk.would_enter(pb1 * BOUND_SLACK);
                 uint64_t b0 = ballot(s0), b1 = ballot(s1);
                 if (!(b0 | b1)) continue;
                 const uint32_t ns = (uint32_t)(__builtin_popcountll(b0) + __builtin_popcountll(b1));
@@ -1022,7 +1033,6 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                 cx.s_scored += ns;
                 const float nl0 = s0 ? a.norm_lens[c0] : 0.f, nl1 = s1 ? a.norm_lens[c1] : 0.f;
                 float sc0 = 0.f, sc1 = 0.f;
-                if (!cx.m(e, M_FDEC)) cx.decode_freqs(e);
                 {
                     const float w = qw(e);
                     if (s0) sc0 = w * doc_term_weight(L.freqs[e][lane], nl0);
