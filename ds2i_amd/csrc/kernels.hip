@@ -160,6 +160,8 @@ static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 #define DS2I_OCC2 6
 #endif
 #define CONJ_WAVES(T) ((T) <= 2 ? DS2I_OCC2 : (T) <= 4 ? 5 : (T) <= 8 ? 3 : 1)
+// and / and_freq carry no scoring state: their <=2-list kernels fit 8 waves/SIMD (59-61 VGPRs, no scratch)
+#define CONJ_WAVES_R(RANKED, T) (!(RANKED) && (T) <= 2 ? 8 : CONJ_WAVES(T))
 
 // LDS of the conjunctive kernels: the shared layout plus, for ranked_and, the norm_len of every posting of list 0's
 // current block (-1 = the posting was dropped by the freq-only bound and its norm_len never fetched); ranked_and has
@@ -170,7 +172,7 @@ struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED> {
 };
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
-__global__ void __launch_bounds__(64, CONJ_WAVES(TMAX)) k_conjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
@@ -827,6 +829,16 @@ __global__ void __launch_bounds__(64) k_daat_long(BatchArgs a) {
     cx.flush_stats(a.stats);
 }
 
+// Order-independent score accumulation for the block-synchronous disjunctive kernel. Which of a document's lists are
+// essential when it is met -- hence the order its term scores would be added in -- depends on how far the pruning
+// threshold has risen, i.e. on the query's split into parts and on timing. Term scores (float32, computed exactly as
+// the reference computes them) are therefore summed in 2^-32 fixed point: integer addition is associative, so a
+// document's score is the same bits whatever the order, run to run and for wand / maxscore / ranked_or alike. The
+// result differs from the reference's sequential float sum by a few ulps at most (tests hold 1e-5; the reference's own
+// ranked test holds 1e-3, test_ranked_queries.cpp:52).
+DS2I_DEV unsigned long long fx_of(float term) { return (unsigned long long)((double)term * 4294967296.0); } // exact; term >= 0
+DS2I_DEV float fx_value(unsigned long long acc) { return (float)((double)acc * (1.0 / 4294967296.0)); }      // one rounding
+
 // ------------------------------------------------------------------ block-synchronous disjunctive top-k
 // wand / maxscore / ranked_or all return the top-k of the UNION of the query's lists (queries.hpp:200-319, 404-476,
 // 478-591; the reference's own ranked test holds them equal, test_ranked_queries.cpp:39-57). The document-at-a-time
@@ -886,7 +898,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         if (MODE == 0) {
             // static floor (host, from the upload-time block weights): some term of the query has k blocks whose best
             // posting alone scores >= floor1, and a document's score is >= any one of its term scores
-            const float f1 = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1)));
+            const float f1 = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1))) * (1.0f - 1.0e-5f);
             if (f1 > tk.floor) tk.floor = f1;
         }
         if (lane == 0) {
@@ -1032,11 +1044,12 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                 cx.s_bytes += 4ull * ns;
                 cx.s_scored += ns;
                 const float nl0 = s0 ? a.norm_lens[c0] : 0.f, nl1 = s1 ? a.norm_lens[c1] : 0.f;
+                unsigned long long a0 = 0, a1 = 0; // fixed-point sums (fx_of); sc0 / sc1 are their float values
                 float sc0 = 0.f, sc1 = 0.f;
                 {
                     const float w = qw(e);
-                    if (s0) sc0 = w * doc_term_weight(L.freqs[e][lane], nl0);
-                    if (s1) sc1 = w * doc_term_weight(L.freqs[e][lane + 64], nl1);
+                    if (s0) a0 = fx_of(w * doc_term_weight(L.freqs[e][lane], nl0));
+                    if (s1) a1 = fx_of(w * doc_term_weight(L.freqs[e][lane + 64], nl1));
                 }
                 for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
                     const uint32_t x = slot_at(p2);
@@ -1044,14 +1057,16 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     if (!(ballot(h0) | ballot(h1))) continue;
                     if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                     const float w = qw(x);
-                    if (h0) sc0 += w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0);
-                    if (h1) sc1 += w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1);
+                    if (h0) a0 += fx_of(w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0));
+                    if (h1) a1 += fx_of(w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1));
                 }
                 // non-essential lists, highest upper bound first; a candidate stops as soon as it cannot enter
                 for (uint32_t p2 = non_ess; p2-- > 0;) {
                     const float ubp = ubf(p2);
-                    s0 = s0 && tk.would_enter(sc0 + ubp);
-                    s1 = s1 && tk.would_enter(sc1 + ubp);
+                    sc0 = fx_value(a0);
+                    sc1 = fx_value(a1);
+                    s0 = s0 && tk.would_enter((sc0 + ubp) * BOUND_SLACK);
+                    s1 = s1 && tk.would_enter((sc1 + ubp) * BOUND_SLACK);
                     bool r0 = s0, r1 = s1; // still to be looked up in list x
                     if (!(ballot(r0) | ballot(r1))) break;
                     const uint32_t x = slot_at(p2);
@@ -1068,13 +1083,15 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                         if (ballot(f0) | ballot(f1)) {
                             if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                             const float w = qw(x);
-                            if (f0) sc0 += w * doc_term_weight(L.freqs[x][q0], nl0);
-                            if (f1) sc1 += w * doc_term_weight(L.freqs[x][q1], nl1);
+                            if (f0) a0 += fx_of(w * doc_term_weight(L.freqs[x][q0], nl0));
+                            if (f1) a1 += fx_of(w * doc_term_weight(L.freqs[x][q1], nl1));
                         }
                         r0 = r0 && !w0;
                         r1 = r1 && !w1;
                     }
                 }
+                sc0 = fx_value(a0);
+                sc1 = fx_value(a1);
                 bool inserted = false;
                 for (int half = 0; half < 2; ++half) {
                     const bool al = half ? s1 : s0;
