@@ -350,6 +350,15 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;
     }
+    x->term_proto.resize(V);
+    for (uint64_t t = 0; t < V; ++t) {
+        QTerm qt = ds2i_make_qterm(x.get(), (uint32_t)t);
+        qt.q_weight = x->has_wand ? x->max_term_weight[t] : 0.f;
+        qt.max_weight = x->d_bmw ? x->list_bmw[t] : 0.f;
+        const uint32_t nb = x->list_nb[t];
+        std::memcpy(&qt.floor1, &nb, 4);
+        x->term_proto[t] = qt;
+    }
     *out = x.release();
     return DS2I_OK;
 }

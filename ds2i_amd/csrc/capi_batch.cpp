@@ -6,6 +6,7 @@
 // blocks on the device -- the host plans batch i+1 while the kernels of batch i run.
 // There is NO CPU fallback: every query result comes from the HIP kernels or the call fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +109,7 @@ void order_by_cost(const std::vector<float>& cost, const std::vector<uint32_t>& 
 int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
                int want_matches) {
     ds2i_hip_index* idx = b->idx;
+    const auto plan_t0 = std::chrono::steady_clock::now();
     if (!query_offsets || (!terms && nq && query_offsets[nq] > 0))
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
     const int base_op = op & 0xFF;
@@ -156,14 +158,18 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             return ds2i_set_error(DS2I_ETOOLONG, "query has more than DS2I_HIP_MAX_TERMS_LONG distinct terms");
         const size_t begin = qterms.size();
         for (auto const& p : tf) {
-            QTerm qt = ds2i_make_qterm(idx, p.first);
+            QTerm qt = idx->term_proto[p.first]; // one cache line: see capi_internal.hpp
+            const float mtw = qt.q_weight, lbmw = qt.max_weight;
+            uint32_t nb;
+            std::memcpy(&nb, &qt.floor1, 4);
+            qt.q_weight = qt.max_weight = qt.floor1 = 0.f;
             if (ranked) {
                 qt.q_weight = ds2i_host::bm25::query_term_weight(p.second, qt.n, idx->num_docs);
-                qt.max_weight = qt.q_weight * idx->max_term_weight[p.first];
-                qt.max_bmw = idx->d_bmw ? qt.q_weight * idx->list_bmw[p.first] : std::numeric_limits<float>::infinity();
+                qt.max_weight = qt.q_weight * mtw;
+                qt.max_bmw = idx->d_bmw ? qt.q_weight * lbmw : std::numeric_limits<float>::infinity();
             }
             qterms.push_back(qt);
-            qnbs.push_back(idx->list_nb[p.first]);
+            qnbs.push_back(nb);
         }
         double cost = 0;
         if (conj) { // sort by increasing frequency (queries.hpp:53-56, 357-360); stable insertion sort of <= a few lists
@@ -305,8 +311,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
 
     static const bool debug_plan = std::getenv("DS2I_DEBUG_PLAN") != nullptr;
     if (debug_plan)
-        std::fprintf(stderr, "ds2i plan: op %d nq %u units %u (per class %u %u %u %u %u) split queries %u cost %.0f\n", op, nq, b->nunits,
-                     b->ncls[0], b->ncls[1], b->ncls[2], b->ncls[3], b->ncls[4], b->nsplit, all_cost);
+        std::fprintf(stderr, "ds2i plan: op %d nq %u units %u (per class %u %u %u %u %u) split queries %u cost %.0f, %.0f us\n", op, nq, b->nunits,
+                     b->ncls[0], b->ncls[1], b->ncls[2], b->ncls[3], b->ncls[4], b->nsplit, all_cost,
+                     1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - plan_t0).count());
 
     // ---- layouts
     size_t o = 0;

@@ -106,6 +106,11 @@ struct ds2i_hip_index {
     hipStream_t s_up = nullptr, s_merge = nullptr;
     unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
     ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)
+    // Planning reads one 64-byte record per query term instead of eight parallel arrays (a 4096-query batch has ~12 k
+    // terms; at configs[1] scale planning, not the kernels, bounds the end-to-end rate): the QTerm as the kernels want
+    // it, with the query-independent factors parked in the fields planning overwrites -- q_weight = max_term_weight,
+    // max_weight = list max block weight, floor1 = number of blocks (bit pattern).
+    std::vector<ds2i_dev::QTerm> term_proto;
 };
 
 void ds2i_batch_destroy(ds2i_hip_batch* b); // capi_batch.cpp
