@@ -78,7 +78,8 @@ struct BatchArgs {
     unsigned int* q_floor;     // nq or null
     // block-synchronous ranked_and: the parts of a split query share a 256-bucket histogram of the scores that entered
     // their heaps; the lower edge of the highest bucket with >= k documents at or above it is every part's floor
-    unsigned int* q_hist;      // nq * 256 or null
+    unsigned int* q_hist;      // (split queries) * 256 or null
+    const uint32_t* q_hist_slot; // nq: the query's histogram (rank among the split queries); unused for whole queries
     unsigned int* block_profile; // block indexes: 2 counters per block of the index (docs / freqs decodes) or null
     const void* skip;            // block indexes: interleaved {block_max, block end offset} per block (uint2) or null
     const float* bmw;            // per block / chunk of the index: max doc_term_weight of its postings, or null

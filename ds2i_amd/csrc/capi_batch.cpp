@@ -47,7 +47,7 @@ struct ds2i_hip_batch {
     std::vector<uint32_t> qnbs, qoff, qnb0, scratch_u32;
     std::vector<double> qcost;
     std::vector<Unit> units;
-    std::vector<uint32_t> q_unit_off, split_queries, single_queries, order[NCLS];
+    std::vector<uint32_t> q_unit_off, split_queries, single_queries, hist_slot, order[NCLS];
     std::vector<float> unit_cost;
     std::vector<unsigned long long> match_off;
     std::vector<uint32_t> seed_terms, seed_offs;
@@ -55,7 +55,7 @@ struct ds2i_hip_batch {
     uint32_t nqcls[NCLS] = {}; // queries per kernel class
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_order[NCLS] = {},
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {},
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -324,6 +324,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     b->o_q_unit_off = place(b->q_unit_off.size() * 4);
     b->o_split = place(b->split_queries.size() * 4);
     b->o_single = place(b->single_queries.size() * 4);
+    b->hist_slot.assign(nq ? nq : 1, 0xFFFFFFFFu); // a split query's score histogram = its rank among the split queries
+    for (uint32_t i = 0; i < b->nsplit; ++i) b->hist_slot[b->split_queries[i]] = i;
+    b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
     b->up_bytes = o + 16;
@@ -342,7 +345,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     // ranked_and: a 256-bucket score histogram per query (kernels.hip); the disjunctive operators: one floor word
     const bool disj_ranked = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
     const bool hist = !(op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_ranked);
-    b->o_qfloor = place(hist ? 1024 * nq1 : 4 * nq1);
+    b->o_qfloor = place(hist ? 1024 * (size_t)b->nsplit : 16);
     b->scr_bytes = o;
 
     b->use_seed = seeded;
@@ -412,6 +415,7 @@ int upload_batch(ds2i_hip_batch* b) {
     put(b->o_q_unit_off, b->q_unit_off.data(), b->q_unit_off.size() * 4);
     put(b->o_split, b->split_queries.data(), b->split_queries.size() * 4);
     put(b->o_single, b->single_queries.data(), b->single_queries.size() * 4);
+    put(b->o_hslot, b->hist_slot.data(), b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) put(b->o_order[c], b->order[c].data(), b->order[c].size() * 4);
     if (b->want_matches) put(b->o_match_off, b->match_off.data(), b->match_off.size() * 8);
     HIP_OK(hipMemcpyAsync(b->d_up.p, b->h_up.p, b->up_bytes, hipMemcpyHostToDevice, idx->s_up));
@@ -493,6 +497,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.q_floor = nullptr;
         a.q_hist = (!(b->op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_topk))
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
+        a.q_hist_slot = b->d_up.at<uint32_t>(b->o_hslot);
         a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
         a.skip = no_skiptab ? nullptr : idx->d_skip;
         a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;

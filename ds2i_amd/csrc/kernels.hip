@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         // since all parts add a document's terms in the same order (a dropped document scores <= floor <= final threshold)
         const bool shared_floor = RANKED && bmw && !whole && a.q_hist;
         ScoreHist sh;
-        sh.init(shared_floor ? a.q_hist : nullptr, q,
+        sh.init(shared_floor ? a.q_hist : nullptr, shared_floor ? a.q_hist_slot[q] : 0u,
                 shared_floor ? __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw))) : 0.f,
                 1.0f - 1.0f / 1048576.0f);
         auto adopt_floor = [&]() __attribute__((always_inline)) {
@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         // different orders (which lists are essential depends on each part's threshold), hence the 1e-5 relaxation
         const bool shared_floor = MODE == 0 && !whole && a.q_hist;
         ScoreHist sh;
-        sh.init(shared_floor ? a.q_hist : nullptr, q, shared_floor ? ubf(nt - 1) : 0.f, 1.0f - 1.0e-5f);
+        sh.init(shared_floor ? a.q_hist : nullptr, shared_floor ? a.q_hist_slot[q] : 0u, shared_floor ? ubf(nt - 1) : 0.f, 1.0f - 1.0e-5f);
         auto adopt_floor = [&]() __attribute__((always_inline)) { // the other parts of this query may have raised the bar
             const float f = sh.floor(tk.k);
             if (f > tk.floor) { tk.floor = f; update_non_ess(); }
