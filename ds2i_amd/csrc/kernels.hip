@@ -1,15 +1,21 @@
 // HIP kernels (gfx950 / CDNA4, wave64) for the ds2i batched query path.
-// One wavefront per query, persistent waves pulling query tickets; every memory
-// operation is wave-cooperative, control flow is wave-uniform. No MFMA (integer work).
+// One wavefront per WORK UNIT (a piece of a query: a block range of its shortest list, or a doc-id range), one unit
+// per single-wave workgroup; every memory operation is wave-cooperative, control flow is wave-uniform. No MFMA
+// (integer work).
 //
 //   k_conjunctive   and_query / ranked_and_query   reference queries.hpp:35-86, 322-401
 //                   block-synchronous intersection: each round intersects the window
 //                   [lo, min_i block_max_i] of all lists' current blocks at once (up to
-//                   128 candidates, two per lane) instead of one candidate per step.
-//   k_daat          or / ranked_or / wand / maxscore (+ reference-order and / ranked_and)
-//                   reference queries.hpp:88-131, 404-476, 200-319, 478-591
+//                   128 candidates, two per lane) instead of one candidate per step; ranked_and scores
+//                   progressively and prunes with exact bounds from the per-block max-weight table
+//   k_disjunctive   wand / maxscore / ranked_or (top-k of the union) and or / or_freq, block-synchronous
+//                   reference queries.hpp:88-131, 200-319, 404-476, 478-591
+//   k_daat          every operator in the reference's one-document-per-step order (DS2I_OP_REFERENCE_ORDER)
+//   k_daat_long     the same traversals for queries with more than 16 terms (state in global scratch)
+//   k_merge         partial results of split queries
 //   k_decode_list   full decode of one list (Index::operator[] + enumeration)
-//   k_selftest      primitives (scan, ballot) used by the GPU unit tests
+//   k_block_max_weights / k_list_top_bmw   upload-time block-max BM25 weights
+//   k_selftest*     primitives (scan, bm25) used by the GPU unit tests
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -56,12 +62,6 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
     c.skip = (const uint2*)a.skip;
     c.init_stats();
     return c;
-}
-
-DS2I_DEV uint32_t next_ticket(unsigned int* ticket) {
-    uint32_t t = 0;
-    if (lane_id() == 0) t = atomicAdd(ticket, 1u);
-    return bcast(t, 0);
 }
 
 DS2I_DEV void store_topk(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopK& tk) {
