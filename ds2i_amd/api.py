@@ -406,7 +406,7 @@ class Batch:
     def fetch(self):
         nq = max(self.nq, 1)
         count = np.zeros(nq, dtype=np.uint64)
-        topk = np.full((nq, min(self.k, 64)), -np.inf, dtype=np.float32)
+        topk = np.full((nq, self.k), -np.inf, dtype=np.float32)
         tlen = np.zeros(nq, dtype=np.uint32)
         fsum = np.zeros(nq, dtype=np.uint64)
         _check(lib().ds2i_hip_batch_fetch(self._h, _ptr(count), _ptr(topk), _ptr(tlen), _ptr(fsum)))

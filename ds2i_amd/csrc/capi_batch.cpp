@@ -118,7 +118,10 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     const bool conj = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
     const bool ranked = base_op >= DS2I_OP_RANKED_AND;
     if (ranked && !idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
-    if (ranked && (k == 0 || k > DS2I_HIP_MAX_K)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1,64]");
+    if (ranked && (k == 0 || k > DS2I_HIP_MAX_K_LONG)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1, DS2I_HIP_MAX_K_LONG]");
+    // k > 64 (one score per lane no longer suffices): every query takes the one-document-per-step kernel with a 16-scores-
+    // per-lane heap and its enumerator state in global scratch -- slower, same results (the reference has no limit on k)
+    const bool bigk = ranked && k > DS2I_HIP_MAX_K;
     if (!ranked) k = 1; // and / or return counts only: k is ignored, no top-k is produced or copied
 
     b->op = op;
@@ -216,8 +219,8 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         }
         qoff[q + 1] = (uint32_t)qterms.size();
         qcost[q] = cost;
-        total_cost[class_of(tf.size())] += cost;
-        if (tf.size() > DS2I_HIP_MAX_TERMS) b->long_terms = std::max<uint32_t>(b->long_terms, (uint32_t)tf.size());
+        total_cost[bigk ? CLS_LONG : class_of(tf.size())] += cost;
+        if (bigk || tf.size() > DS2I_HIP_MAX_TERMS) b->long_terms = std::max<uint32_t>(b->long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
     }
     for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
 
@@ -232,8 +235,8 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     for (int c = 0; c < NCLS; ++c) b->nqcls[c] = 0;
     // ranked_or takes the seed only in its block-synchronous form: its reference-order traversal stays the unpruned
     // exhaustive OR of queries.hpp:404-476 (the oracle the reference tests wand / maxscore against)
-    const bool seeded = nq && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
-                               (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
+    const bool seeded = nq && !bigk && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
+                                        (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
@@ -252,7 +255,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     };
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
-        const int c = class_of(nt);
+        const int c = bigk ? CLS_LONG : class_of(nt);
         // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
         const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : 4.0));
         ++b->nqcls[c];

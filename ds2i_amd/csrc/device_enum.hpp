@@ -608,4 +608,48 @@ struct TopK {
     }
 };
 
+// ---- top-k beyond 64 scores (k <= 64 * NK): score i of the descending order lives in register i / 64 of lane i % 64.
+// Same contract as TopK; used by the one-document-per-step kernels when a caller asks for k > 64 (the reference's
+// topk_queue has no limit, queries.hpp:152-197).
+template <int NK>
+struct TopKBig {
+    float v[NK];
+    uint32_t n, k;
+    float floor;
+    DS2I_DEV void init(uint32_t k_) {
+#pragma unroll
+        for (int r = 0; r < NK; ++r) v[r] = -__builtin_inff();
+        n = 0;
+        k = k_;
+        floor = -__builtin_inff();
+    }
+    DS2I_DEV float threshold() const {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < NK; ++r)
+            if ((uint32_t)r == ((k - 1) >> 6)) t = __uint_as_float(bcast(__float_as_uint(v[r]), (k - 1) & 63u));
+        return t;
+    }
+    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > threshold()); }
+    DS2I_DEV bool insert(float s) { // s wave-uniform
+        if (!would_enter(s)) return false;
+        const uint32_t lane = lane_id();
+        uint32_t p = 0; // scores >= s keep their place
+#pragma unroll
+        for (int r = 0; r < NK; ++r) p += (uint32_t)__builtin_popcountll(ballot((uint32_t)r * 64u + lane < n && v[r] >= s));
+#pragma unroll
+        for (int r = NK - 1; r >= 0; --r) { // descending: register r - 1 still holds its old values when r takes its carry
+            const float carry = r ? __uint_as_float(bcast(__float_as_uint(v[r > 0 ? r - 1 : 0]), 63)) : 0.f;
+            float up = __shfl_up(v[r], 1);
+            if (lane == 0) up = carry;
+            const uint32_t i = (uint32_t)r * 64u + lane;
+            float nv = (i < p) ? v[r] : (i == p) ? s : up;
+            if (i >= k) nv = -__builtin_inff();
+            v[r] = nv;
+        }
+        if (n < k) ++n;
+        return true;
+    }
+};
+
 } // namespace ds2i_dev

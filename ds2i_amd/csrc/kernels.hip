@@ -64,6 +64,14 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
     return c;
 }
 
+template <int NK>
+DS2I_DEV void store_topk(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopKBig<NK>& tk) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < NK; ++r)
+        if ((uint32_t)r * 64u + lane < k) topk[(size_t)slot * k + (uint32_t)r * 64u + lane] = tk.v[r];
+    if (lane == 0) topk_len[slot] = tk.n;
+}
 DS2I_DEV void store_topk(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopK& tk) {
     const uint32_t lane = lane_id();
     if (lane < k) topk[(size_t)slot * k + lane] = tk.v;
@@ -586,7 +594,7 @@ DS2I_DEV void sort_ord(uint32_t* ord, uint32_t n, Key key) {
 // One unit of a reference-order operator. The per-list enumerator state (`meta`: M_WORDS dwords per slot, the same
 // memory cx.meta points to), the list order `ord` and the maxscore upper bounds `ub` live wherever the caller keeps
 // them: LDS for the <=16-term classes (k_daat), a global scratch area for longer queries (k_daat_long).
-template <int OP, class CX>
+template <int OP, class TK = TopK, class CX>
 DS2I_DEV void daat_unit(CX& cx, const BatchArgs& a, const uint32_t uid, uint32_t* meta, uint32_t* ord, float* ubs, const uint32_t tmax) {
     const uint32_t lane = lane_id();
     constexpr bool RANKED = OP >= OP_RANKED_AND;
@@ -600,7 +608,7 @@ DS2I_DEV void daat_unit(CX& cx, const BatchArgs& a, const uint32_t uid, uint32_t
         cx.num_docs = N;
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
         unsigned long long count = 0, fsum = 0;
-        TopK tk;
+        TK tk;
         tk.init(a.k);
         if (nt == 0 || nt > tmax) {
             if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
@@ -795,7 +803,7 @@ struct LdsLong {
     uint32_t exc[EXC_LDS_DW];
     uint32_t st[STAGE_DW];
 };
-template <int OP>
+template <int OP, class TK = TopK>
 __global__ void __launch_bounds__(64) k_daat_long(BatchArgs a) {
     __shared__ LdsLong L;
     CtxT<-1, MetaLds> cx;
@@ -824,7 +832,7 @@ __global__ void __launch_bounds__(64) k_daat_long(BatchArgs a) {
         cx.meta.p = base + 256u * nt;
         uint32_t* ord = cx.meta.p + (uint32_t)M_WORDS * nt;
         float* ub = (float*)(ord + nt);
-        daat_unit<OP>(cx, a, uid, cx.meta.p, ord, ub, 0xFFFFFFFFu);
+        daat_unit<OP, TK>(cx, a, uid, cx.meta.p, ord, ub, 0xFFFFFFFFu);
     }
     cx.flush_stats(a.stats);
 }
@@ -1280,6 +1288,17 @@ struct Batch {
 #if defined(DS2I_TU_TMAX) && DS2I_TU_TMAX == 0
 hipError_t launch_long(int op, const BatchArgs& a, unsigned grid, hipStream_t s) {
     dim3 g(grid), b(64);
+    if (a.k > 64) { // top-k beyond one score per lane: 16 scores per lane (k <= 1024)
+        typedef TopKBig<16> BIG;
+        switch (op & 0xFF) {
+        case OP_RANKED_AND: hipLaunchKernelGGL((k_daat_long<OP_RANKED_AND, BIG>), g, b, 0, s, a); break;
+        case OP_WAND: hipLaunchKernelGGL((k_daat_long<OP_WAND, BIG>), g, b, 0, s, a); break;
+        case OP_MAXSCORE: hipLaunchKernelGGL((k_daat_long<OP_MAXSCORE, BIG>), g, b, 0, s, a); break;
+        case OP_RANKED_OR: hipLaunchKernelGGL((k_daat_long<OP_RANKED_OR, BIG>), g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (op & 0xFF) {
     case OP_AND: hipLaunchKernelGGL((k_daat_long<OP_AND>), g, b, 0, s, a); break;
     case OP_AND_FREQ: hipLaunchKernelGGL((k_daat_long<OP_AND_FREQ>), g, b, 0, s, a); break;

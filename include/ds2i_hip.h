@@ -70,7 +70,9 @@ enum ds2i_hip_error {
 #define DS2I_HIP_MAX_TERMS 16        /* distinct terms per query held in LDS by one wavefront (the fast kernels) */
 #define DS2I_HIP_MAX_TERMS_LONG 1024 /* beyond 16 distinct terms a query runs the one-document-per-step traversal with
                                         its enumerator state in global memory (the reference has no limit, queries.hpp:35-86) */
-#define DS2I_HIP_MAX_K 64     /* top-k kept one score per lane */
+#define DS2I_HIP_MAX_K 64            /* top-k kept one score per lane (the fast kernels) */
+#define DS2I_HIP_MAX_K_LONG 1024     /* beyond 64 a ranked batch runs the one-document-per-step kernel with 16 scores per
+                                        lane (the reference's topk_queue has no limit, queries.hpp:152-197) */
 
 typedef struct ds2i_hip_index ds2i_hip_index;
 typedef struct ds2i_hip_batch ds2i_hip_batch;
