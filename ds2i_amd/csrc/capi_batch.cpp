@@ -208,9 +208,10 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 qterms[i].suf_bmw = suf;
                 suf += qterms[i].max_bmw;
             }
-            if (qterms.size() - begin == 1)
+            // (list_topbmw holds DS2I_HIP_MAX_K entries per list; the k > 64 path does not use static floors)
+            if (!bigk && qterms.size() - begin == 1)
                 qterms[begin].floor1 = qterms[begin].q_weight * idx->list_topbmw[(size_t)tf[0].first * DS2I_HIP_MAX_K + (k - 1)];
-            if (!conj) { // top-k of the UNION: any one term's k-th best block weight is a floor of the k-th score
+            if (!bigk && !conj) { // top-k of the UNION: any one term's k-th best block weight is a floor of the k-th score
                 float f = 0.f;
                 for (size_t i = 0; i < tf.size(); ++i)
                     f = std::max(f, qterms[begin + i].q_weight * idx->list_topbmw[(size_t)tf[i].first * DS2I_HIP_MAX_K + (k - 1)]);
@@ -345,7 +346,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     b->o_unit_topk = place(4 * nu1 * k);
     b->o_unit_topk_len = place(4 * nu1);
     b->o_unit_freq_sum = place(8 * nu1);
-    // ranked_and: a 256-bucket score histogram per query (kernels.hip); the disjunctive operators: one floor word
+    // ranked_and / wand / maxscore / ranked_or: a 256-bucket score histogram per split query (kernels.hip, ScoreHist)
     const bool disj_ranked = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
     const bool hist = !(op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_ranked);
     b->o_qfloor = place(hist ? 1024 * (size_t)b->nsplit : 16);
@@ -542,13 +543,11 @@ int launch_batch(ds2i_hip_batch* b) {
 // ---------------------------------------------------------------- finish: wait for the batch, collect timings / counters
 int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     if (!b->launched) return ds2i_set_error(DS2I_EINVAL, "batch has not been launched");
-    double seed_ms = 0;
     HIP_OK(hipEventSynchronize(b->ev_done));
-    if (b->use_seed) {
+    if (b->use_seed) { // (its kernels ran inside this batch's [ev_clear, ev_done] window: not added to kernel_ms again)
         ds2i_hip_stats ss;
         int rc = finish_batch(b->seed, &ss);
         if (rc) return rc;
-        seed_ms = ss.kernel_ms;
     }
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, b->ev_clear, b->ev_done));
@@ -560,7 +559,7 @@ int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, b->d_stats.p, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     else std::memset(b->cls_stats, 0, sizeof(b->cls_stats));
     if (stats) {
-        stats->kernel_ms = ms + seed_ms;
+        stats->kernel_ms = ms;
         stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;
         stats->algorithmic_bytes = stats->postings_scored = stats->rounds = 0;
         for (int c = 0; c < NCLS; ++c) {
