@@ -53,16 +53,6 @@ struct MetaReg {
     // three VGPRs and wasted loads (same throughput without it, and the kernel no longer needs scratch). None with 3-4
     // lists, where the extra VGPRs cost more occupancy than the prefetch wins (measured).
     static constexpr int NPF = TMAX <= 2 ? 1 : 0;
-    static constexpr bool SKIPTAB = true; // use the interleaved skip table (find_block_info)
-    uint32_t* p;
-    DS2I_DEV uint32_t get(uint32_t s, int f) const { return uniform(p[s * M_WORDS + f]); }
-    DS2I_DEV void set(uint32_t s, int f, uint32_t v) { if (lane_id() == 0) p[s * M_WORDS + f] = v; }
-};
-template <int TMAX>
-struct MetaReg {
-    // prefetch slots: both lists of the <=2-list kernel; none with 3-4 lists, where the extra VGPRs cost more
-    // occupancy than the prefetch wins (measured)
-    static constexpr int NPF = TMAX <= 2 ? 1 : 0; // EXPERIMENT: list 0 only
     // the interleaved skip table saves the table round trip of a non-sequential decode; the <=2-list kernel decodes
     // sequentially through its prefetch and cannot afford the extra state (72 SGPRs)
     static constexpr bool SKIPTAB = TMAX > 2;
