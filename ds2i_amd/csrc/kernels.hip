@@ -172,11 +172,13 @@ static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 #define CONJ_WAVES_R(RANKED, T) (!(RANKED) && (T) <= 2 ? 8 : CONJ_WAVES(T))
 
 // LDS of the conjunctive kernels: the shared layout plus, for ranked_and, the norm_len of every posting of list 0's
-// current block (-1 = the posting was dropped by the freq-only bound and its norm_len never fetched); ranked_and has
-// no use for the match positions (it scores progressively). 5028 B for <=2 lists: 32 waves per CU.
+// current block (-1 = the posting was dropped by the freq-only bound and its norm_len never fetched) and its list-0 term
+// score; ranked_and has no use for the match positions (it scores progressively). 5540 B for <=2 lists: 29 waves per
+// CU fit, 24 (6 per SIMD) are used.
 template <int TMAX, bool META_IN_LDS, bool RANKED>
 struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED> {
     float nl[RANKED ? 128 : 1];
+    float part0[RANKED ? 128 : 1]; // list-0 term score of each posting of the block (-inf = dropped): read every round
 };
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
@@ -311,8 +313,11 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             v0 = v0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + suf0) * BOUND_SLACK);
                             v1 = v1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + suf0) * BOUND_SLACK);
                         }
-                        L.nl[lane] = v0 ? a.norm_lens[c0] : -1.f;
-                        L.nl[lane + 64] = v1 ? a.norm_lens[c1] : -1.f;
+                        const float n0 = v0 ? a.norm_lens[c0] : -1.f, n1 = v1 ? a.norm_lens[c1] : -1.f;
+                        L.nl[lane] = n0;
+                        L.nl[lane + 64] = n1;
+                        L.part0[lane] = v0 ? qw0 * doc_term_weight(f0, n0) : -__builtin_inff();
+                        L.part0[lane + 64] = v1 ? qw0 * doc_term_weight(f1, n1) : -__builtin_inff();
                         part_blk = cur0;
                         const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1)));
                         cx.s_bytes += 4ull * nv;
@@ -320,12 +325,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                         wave_sync();
                         PT_END(cx, PH_SCORE);
                     }
-                    {   // list-0 term scores of this lane's two candidates (-inf: dropped at block init)
-                        const float qw0 = __uint_as_float(cx.m(0, M_QW));
-                        const float n0 = L.nl[lane], n1 = L.nl[lane + 64];
-                        pa0 = n0 >= 0.f ? qw0 * doc_term_weight(L.freqs[0][lane], n0) : -__builtin_inff();
-                        pa1 = n1 >= 0.f ? qw0 * doc_term_weight(L.freqs[0][lane + 64], n1) : -__builtin_inff();
-                    }
+                    pa0 = L.part0[lane]; // list-0 term scores of this lane's two candidates (-inf: dropped at block init)
+                    pa1 = L.part0[lane + 64];
                     have_p = true;
                     if (sf) {
                         const float suf0 = __uint_as_float(cx.m(0, M_SUF));
