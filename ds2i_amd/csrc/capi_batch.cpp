@@ -258,7 +258,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = bigk ? CLS_LONG : class_of(nt);
         // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
-        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : 4.0));
+        static const char* ud = std::getenv("DS2I_UNIT_DIV");
+        static const double unit_div = ud && std::atof(ud) > 0 ? std::atof(ud) : 4.0;
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : unit_div));
         ++b->nqcls[c];
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);
