@@ -291,6 +291,40 @@ def test_disjunctive_scores_are_order_independent(coll, queries, images):
     pipe.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_ranked_and_pruning_fuzz_bit_identical(built_lib, seed):
+    """ranked_and prunes with bounds that are claimed to be exact: over random collections (sizes, densities, clustering,
+    doc-length spread), random and adversarial queries and several k, the top-k must equal the oracle's BIT FOR BIT -- not
+    merely within the 1e-5 the north star allows -- for the block and the Elias-Fano layouts, one-shot and pipelined."""
+    rng = np.random.default_rng(1000 + seed)
+    nd = int(rng.integers(3000, 120000))
+    nt = int(rng.integers(20, 200))
+    p = d.SynthParams(seed=0xF00D0000 + seed, num_docs=nd, num_terms=nt, zipf_exp=float(rng.uniform(0.3, 1.0)),
+                      top_df_frac=float(rng.uniform(0.2, 0.9)), min_len=int(rng.integers(1, 400)), clustered_every=int(rng.integers(0, 5)))
+    lists = [d.synth_list(p, t) for t in range(nt)]
+    sizes = d.synth_doc_sizes(p)
+    if seed % 2 == 0:  # extreme doc-length spread: tiny and huge norm_lens next to each other
+        sizes = np.where(rng.random(nd) < 0.1, 1, sizes).astype(np.uint32)
+    wand = d.build_wand(sizes, lists)
+    qs = d.synth_queries(0xABC0 + seed, nt, 300)
+    qs += [[int(t)] for t in rng.integers(0, nt, 20)] + [[0, 1], [0, 1, 2], [nt - 1, 0], list(range(min(nt, 6)))]
+    qs += [[int(x) for x in rng.integers(0, min(nt, 12), int(rng.integers(2, 5)))] for _ in range(80)]  # dense lists: big intersections
+    for codec in ("block_optpfor", "opt", "block_mixed"):
+        img = d.build_index(codec, nd, lists)
+        gidx = d.Index(codec, img, wand)
+        oidx = o.Index(codec, img, wand)
+        pipe = d.Pipeline(gidx, depth=2)
+        for k in (1, 2, 10, 64):
+            oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", qs, k=k)
+            gc, gtopk, gtlen, _ = gidx.query_batch("ranked_and", qs, k=k)
+            assert np.array_equal(gc, oc) and np.array_equal(gtlen, otlen), (codec, k)
+            assert np.array_equal(gtopk, otopk), (codec, k, np.argwhere(gtopk != otopk)[:3])
+            t = pipe.submit("ranked_and", qs, k=k)
+            _, ptopk, _ = pipe.wait(t)
+            assert np.array_equal(ptopk, otopk), (codec, k)
+        pipe.close()
+
+
 def test_long_queries_more_than_16_terms(coll, queries, images):
     """The reference's functors take any number of terms (queries.hpp:35-86). Queries with more than 16 distinct terms
     run the one-document-per-step traversal with their enumerator state in global memory -- and the rest of the batch
