@@ -56,7 +56,7 @@ struct BatchArgs {
     uint32_t num_docs;
     uint32_t k;
     int codec;
-    unsigned int* ticket;     // unused scratch word (kept for layout stability of the probes under profiles/)
+    unsigned long long* unit_clock; // diagnostic (DS2I_UNIT_CLOCK=1, instrumented kernels): {start, end} s_memrealtime of every unit, or null
     unsigned long long* out_count; // nq
     float* out_topk;          // nq*k, descending, padded with -inf
     uint32_t* out_topk_len;   // nq

@@ -61,7 +61,7 @@ struct ds2i_hip_batch {
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
     // ---- device-only scratch: per-unit partial results of split queries + the shared floors
     size_t o_unit_count = 0, o_unit_topk = 0, o_unit_topk_len = 0, o_unit_freq_sum = 0, o_qfloor = 0, scr_bytes = 0;
-    DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long;
+    DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long, d_clk;
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
     bool uploaded = false, launched = false;
@@ -456,9 +456,16 @@ int launch_batch(ds2i_hip_batch* b) {
     static const char* order_env = std::getenv("DS2I_LAUNCH_ORDER"); // "small" / "big": A/B switch
     bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
                        (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND);
+    const bool conj_op = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
     if (order_env) small_first = order_env[0] == 's';
     static const bool no_skiptab = std::getenv("DS2I_NO_SKIPTAB") != nullptr;
     static const bool no_bmw_prune = std::getenv("DS2I_NO_BMW_PRUNE") != nullptr;
+    static const bool unit_clock = std::getenv("DS2I_UNIT_CLOCK") != nullptr; // diagnostic: per-unit start / end times
+    if (unit_clock && b->instrument) {
+        HIP_OK(b->d_clk.reserve(16 * (size_t)(b->nunits ? b->nunits : 1)));
+        HIP_OK(hipMemsetAsync(b->d_clk.p, 0, 16 * (size_t)(b->nunits ? b->nunits : 1), idx->s_up));
+        HIP_OK(hipStreamSynchronize(idx->s_up));
+    }
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
     for (int c = 0; c < NCLS; ++c) {
         if (!b->ncls[c]) continue;
@@ -486,7 +493,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.num_docs = (uint32_t)idx->num_docs;
         a.k = b->k;
         a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
-        a.ticket = idx->d_ticket;
+        a.unit_clock = (unit_clock && b->instrument) ? (unsigned long long*)b->d_clk.p : nullptr;
         a.out_count = b->d_out.at<unsigned long long>(b->o_count);
         a.out_topk = b->d_out.at<float>(b->o_topk);
         a.out_topk_len = b->d_out.at<uint32_t>(b->o_topk_len);
@@ -505,7 +512,7 @@ int launch_batch(ds2i_hip_batch* b) {
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
         a.q_hist_slot = b->d_up.at<uint32_t>(b->o_hslot);
         a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
-        a.skip = no_skiptab ? nullptr : idx->d_skip;
+        a.skip = (no_skiptab && conj_op) ? nullptr : idx->d_skip; // (the union kernels are compiled for the table: they position before they decode)
         a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
@@ -560,6 +567,36 @@ int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     }
     if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, b->d_stats.p, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     else std::memset(b->cls_stats, 0, sizeof(b->cls_stats));
+    if (b->instrument && b->d_clk.p && std::getenv("DS2I_UNIT_CLOCK")) { // diagnostic: where each class kernel's time goes
+        std::vector<unsigned long long> clk(2 * (size_t)b->nunits);
+        HIP_OK(hipMemcpy(clk.data(), b->d_clk.p, 16 * (size_t)b->nunits, hipMemcpyDeviceToHost));
+        for (int c = 0; c < NCLS; ++c) {
+            if (!b->ncls[c]) continue;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double busy = 0;
+            std::vector<std::pair<unsigned long long, uint32_t>> durs;
+            for (uint32_t uid : b->order[c]) {
+                const unsigned long long s0 = clk[2 * (size_t)uid], e0 = clk[2 * (size_t)uid + 1];
+                if (!e0) continue;
+                t0 = std::min(t0, s0);
+                t1 = std::max(t1, e0);
+                busy += (double)(e0 - s0);
+                durs.push_back({e0 - s0, uid});
+            }
+            if (durs.empty()) continue;
+            std::sort(durs.begin(), durs.end());
+            const double tick_us = 0.01; // s_memrealtime: 100 MHz
+            std::fprintf(stderr, "ds2i unit clock: class %d: %zu units, span %.0f us, sum of unit times %.0f us (= %.0f waves busy on average), median unit %.1f us, p99 %.1f us\n",
+                         c, durs.size(), (t1 - t0) * tick_us, busy * tick_us, busy / (double)(t1 - t0), durs[durs.size() / 2].first * tick_us,
+                         durs[durs.size() * 99 / 100].first * tick_us);
+            for (size_t i = 0; i < 8 && i < durs.size(); ++i) {
+                const auto& d = durs[durs.size() - 1 - i];
+                const Unit& u = b->units[d.second];
+                std::fprintf(stderr, "    unit %u: query %u part [%u, %u) of %u parts, %.0f us, started at +%.0f us, ended at +%.0f us\n", d.second, u.q, u.blk_begin,
+                             u.blk_end, u.nparts, d.first * tick_us, (clk[2 * (size_t)d.second] - t0) * tick_us, (clk[2 * (size_t)d.second + 1] - t0) * tick_us);
+            }
+        }
+    }
     if (stats) {
         stats->kernel_ms = ms;
         stats->docs_blocks_decoded = stats->freqs_blocks_decoded = stats->block_max_examined = 0;

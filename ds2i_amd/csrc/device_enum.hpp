@@ -23,7 +23,9 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
        M_QW, M_MAXW, M_END_LO, M_END_HI, M_DBIT_LO, M_DBIT_HI, M_FBIT_LO, M_FBIT_HI, M_GPOS, M_NEXTEP, M_HINT, M_PBASE /* blocks (chunks) of all preceding lists: the list's base in the access profile, skip table, bmw[] */,
        M_CBW /* q_weight * bmw of the current block (float bits) */,
        M_SUF /* sum of the later lists' q_weight * list max bmw (float bits) */,
-       M_WORDS }; // 26 dwords per list slot
+       M_DDEC /* docs of block M_CUR are decoded (the disjunctive kernel positions a list on a block first and decodes it only if the block can matter) */,
+       M_EP, M_BASE /* table words of a positioned, not yet decoded block: start offset, first doc-id it can hold */,
+       M_WORDS }; // 29 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
 #define PT_BEGIN(cx) const unsigned long long pt_t0_ = __builtin_readcyclecounter()
@@ -150,6 +152,7 @@ struct CtxT {
         setm(s, M_POS, 0);
         setm(s, M_DOCID, first < num_docs ? first : num_docs);
         setm(s, M_FDEC, 0);
+        setm(s, M_DDEC, 1);
         setm(s, M_GPOS, gpos);
         wave_sync();
         ++s_docs_blocks;
@@ -286,6 +289,7 @@ struct CtxT {
         setm(s, M_FREQ_LO, (uint32_t)fo);
         setm(s, M_FREQ_HI, (uint32_t)(fo >> 32));
         setm(s, M_FDEC, 0);
+        setm(s, M_DDEC, 1);
         setm(s, M_GPOS, b * 128u);
         setm(s, M_NEXTEP, next_ep);
         setm(s, M_HINT, blk_bytes);
@@ -362,6 +366,7 @@ struct CtxT {
             setm(s, M_FDEC, 0);
             setm(s, M_PBASE, t.blk_base);
             setm(s, M_CBW, 0);
+            setm(s, M_DDEC, 0);
             setm(s, M_SUF, __float_as_uint(t.suf_bmw));
             wave_sync();
             s_bytes += 16 + 8; // two collection offsets + gamma(occurrences), n
@@ -383,6 +388,7 @@ struct CtxT {
         setm(s, M_FDEC, 0);
         setm(s, M_PBASE, t.blk_base);
         setm(s, M_CBW, 0);
+        setm(s, M_DDEC, 0);
         setm(s, M_SUF, __float_as_uint(t.suf_bmw));
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
@@ -512,6 +518,42 @@ struct CtxT {
         uint64_t hit = ballot(idx >= lo && idx < hi && e.x >= lb);
         if (!hit) return nb;
         return finish(e, first, hit);
+    }
+
+    // find_block_info for a list that moves to its NEXT blocks (from = current + 1, so every entry's block_max is >= lb
+    // anyway): the first block >= from that `stop(block_max, bmw)` accepts; the blocks it rejects are skipped without being
+    // decoded, 63 per probe. The caller's predicate says "this block could hold a result, or it ends the range the bound
+    // was computed for". Returns nb when every remaining block is rejected.
+    template <class STOP>
+    DS2I_DEV uint32_t find_block_where(uint32_t s, uint32_t from, uint32_t lb, BlockInfo& info, const float* wtab, float& w, STOP stop) {
+        const uint32_t nb = m(s, M_NB);
+        const uint32_t lane = lane_id();
+        w = 0.f;
+        if (from >= nb) return nb;
+        const uint2* tab = skip + m(s, M_PBASE);
+        uint32_t first = from ? from - 1 : 0; // lane 0 holds the entry before the first candidate
+        for (;;) {
+            const uint32_t idx = first + lane;
+            uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+            float wv = 0.f;
+            if (idx < nb) { e = tab[idx]; wv = wtab[idx]; }
+            const uint64_t hit = ballot(idx >= from && idx < nb && e.x >= lb && stop(e.x, wv));
+            if (hit) {
+                const uint32_t f = (uint32_t)__builtin_ctzll(hit);
+                const uint32_t blk = first + f;
+                w = __uint_as_float(bcast(__float_as_uint(wv), f));
+                info.bmax = bcast(e.x, f);
+                info.next_ep = bcast(e.y, f);
+                const uint32_t pf = f ? f - 1 : 0;
+                const uint32_t pmax = bcast(e.x, pf), pend = bcast(e.y, pf);
+                info.base = blk ? pmax + 1u : 0u;
+                info.ep = blk ? pend : 0u;
+                return blk;
+            }
+            if (first + 64 >= nb) return nb;
+            first += 63;
+            from = first + 1;
+        }
     }
 
     // ---- next_geq (block_posting_list.hpp:124-146)

@@ -127,13 +127,22 @@ struct ScoreHist {
     }
     // lower bound of the k-th score of the union, or -inf (relaxed agent-scope loads: the counters are updated by
     // other CUs' atomics and must not come from a stale L1 line)
-    DS2I_DEV float floor(uint32_t k) const {
-        const uint32_t lane = lane_id();
-        const unsigned int* hp = h + 252u - 4u * lane; // lane l holds buckets 255-4l .. 252-4l: highest scores in lane 0
-        const uint32_t x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    struct Snapshot { uint32_t x, y, z, w; }; // lane l: buckets 252-4l .. 255-4l (highest scores in lane 0)
+    DS2I_DEV Snapshot load() const {
+        const unsigned int* hp = h + 252u - 4u * lane_id();
+        Snapshot s;
+        s.x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return s;
+    }
+    DS2I_DEV float floor(uint32_t k) const { return floor(load(), k); }
+    // the floor a snapshot implies. Counters only grow and any floor ever valid stays valid, so a snapshot may be as old
+    // as the caller likes: the disjunctive kernel loads one per round and resolves it a round later, which takes the
+    // load's latency off the round's critical path
+    DS2I_DEV float floor(const Snapshot& sn, uint32_t k) const {
+        const uint32_t x = sn.x, y = sn.y, z = sn.z, w = sn.w;
         const uint32_t mine = x + y + z + w;
         const uint32_t incl = wave_incl_scan(mine);
         const uint64_t full = ballot(incl >= k);
@@ -202,6 +211,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
     // interleaves the workgroups of the concurrently running LDS classes as resources free up
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
+        const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
         const Unit u = a.units[uid];
 #ifdef DS2I_PHASE_TIMING
         const unsigned long long unit_t0 = __builtin_readcyclecounter();
@@ -532,6 +542,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             }
             if (RANKED) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
+        if (STATS && a.unit_clock && lane == 0) { a.unit_clock[2ull * uid] = t_unit; a.unit_clock[2ull * uid + 1] = wall_clock64(); }
     }
     cx.flush_stats(a.stats);
 }
@@ -841,12 +852,23 @@ __global__ void __launch_bounds__(64) k_daat_long(BatchArgs a) {
 // Order-independent score accumulation for the block-synchronous disjunctive kernel. Which of a document's lists are
 // essential when it is met -- hence the order its term scores would be added in -- depends on how far the pruning
 // threshold has risen, i.e. on the query's split into parts and on timing. Term scores (float32, computed exactly as
-// the reference computes them) are therefore summed in 2^-32 fixed point: integer addition is associative, so a
+// the reference computes them) are therefore summed in fixed point: integer addition is associative, so a
 // document's score is the same bits whatever the order, run to run and for wand / maxscore / ranked_or alike. The
-// result differs from the reference's sequential float sum by a few ulps at most (tests hold 1e-5; the reference's own
-// ranked test holds 1e-3, test_ranked_queries.cpp:52).
-DS2I_DEV unsigned long long fx_of(float term) { return (unsigned long long)((double)term * 4294967296.0); } // exact; term >= 0
-DS2I_DEV float fx_value(unsigned long long acc) { return (float)((double)acc * (1.0 / 4294967296.0)); }      // one rounding
+// fixed point is RELATIVE to the query: its unit is 2^-62 of the power of two above the query's score bound (the sum of
+// its lists' max scores, the same bits in every part of a split query), so the sum of <= 16 terms fits 63 bits and a term
+// loses nothing unless it is 2^-38 of the bound -- scores of 1e-6 (terms in most of the documents) are as exact as
+// scores of 20. The result differs from the reference's sequential float sum by a few ulps at most (tests hold 1e-5;
+// the reference's own ranked test holds 1e-3, test_ranked_queries.cpp:52).
+struct FxScale {
+    double to_fx, from_fx; // powers of two
+    DS2I_DEV void init(float bound) { // bound >= 0, wave-uniform
+        const unsigned long long eb = (__float_as_uint(bound) >> 23) & 0xFFu; // bound < 2^(eb - 126)
+        to_fx = __longlong_as_double((long long)((1211ull - eb) << 52));       // 2^(62 - (eb - 126))
+        from_fx = __longlong_as_double((long long)((835ull + eb) << 52));
+    }
+    DS2I_DEV unsigned long long of(float term) const { return (unsigned long long)((double)term * to_fx); } // term >= 0
+    DS2I_DEV float value(unsigned long long acc) const { return (float)((double)acc * from_fx); }
+};
 
 // ------------------------------------------------------------------ block-synchronous disjunctive top-k
 // wand / maxscore / ranked_or all return the top-k of the UNION of the query's lists (queries.hpp:200-319, 404-476,
@@ -865,6 +887,7 @@ template <int TMAX>
 struct LdsOr : Lds<TMAX, true> {
     uint32_t lord[16];   // list slots by increasing max score
     float lub[16];       // upper_bounds (prefix sums of max scores in that order)
+    float wub[16];       // the same prefix sums for the current window: essential lists by their current block's max weight
     uint32_t nomore[16]; // list has no posting >= this doc-id
     uint8_t dup[TMAX][128];
 };
@@ -872,13 +895,29 @@ struct LdsOr : Lds<TMAX, true> {
 // MODE 0: top-k (wand / maxscore / ranked_or). MODE 1: or_query (count of the union, queries.hpp:88-131): every list is
 // essential, owned candidates are counted. MODE 2: or_query<with_freqs>: additionally every freq of the window is
 // summed (the reference touches them all).
+// waves per SIMD the top-k instantiations are compiled for: the kernel waits on dependent round trips most of the time, so
+// residency is what hides them. <=2 lists: LDS (5.5 KiB per wave) would allow 7; beyond 4 lists LDS caps the residency first
+#ifndef DS2I_BLOCKMAX_TMAX
+#define DS2I_BLOCKMAX_TMAX 2 // block-max pruning in the top-k union kernels of up to this many lists (see k_disjunctive)
+#endif
+#ifndef DS2I_DISJ_WAVES2
+#define DS2I_DISJ_WAVES2 6
+#endif
+#ifndef DS2I_DISJ_WAVES4
+#define DS2I_DISJ_WAVES4 5
+#endif
+constexpr int DISJ_WAVES(int tmax, int mode) { return mode != 0 ? 1 : tmax <= 2 ? DS2I_DISJ_WAVES2 : tmax <= 4 ? DS2I_DISJ_WAVES4 : 1; }
 template <int TMAX, int CODEC_T, bool STATS = true, int MODE = 0>
-__global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
+__global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(BatchArgs a) {
     __shared__ LdsOr<TMAX> L;
     const uint32_t lane = lane_id();
     CtxT<CODEC_T, MetaLds, STATS> cx = make_ctx<CODEC_T, MetaLds, STATS>(L, a);
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
+        const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
+#ifdef DS2I_PHASE_TIMING
+        const unsigned long long pt_unit0 = __builtin_readcyclecounter();
+#endif
         const Unit u = a.units[uid];
         const uint32_t q = u.q;
         const bool whole = u.nparts == 1;
@@ -928,61 +967,161 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
         }
         wave_sync();
         auto ubf = [&](uint32_t i) { return __uint_as_float(uniform(__float_as_uint(L.lub[i]))); };
+        auto ubw = [&](uint32_t i) { // this window's bounds (block-max pruning) or the list-level upper_bounds
+            return __uint_as_float(uniform(__float_as_uint((MODE == 0 && TMAX <= DS2I_BLOCKMAX_TMAX) ? L.wub[i] : L.lub[i])));
+        };
         auto slot_at = [&](uint32_t p) { return uniform(L.lord[p]); };
         auto maxw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_MAXW)); };
         auto qw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_QW)); };
+        FxScale fx;
+        fx.init(ubf(nt - 1));
         uint32_t non_ess = 0;
         auto update_non_ess = [&]() __attribute__((always_inline)) { if (MODE == 0) while (non_ess < nt && !tk.would_enter(ubf(non_ess))) ++non_ess; };
         update_non_ess();
-        // positions list x on the first block whose block_max >= d; false when the list has no posting >= d
-        // always_inline: left to the inliner, the lambda (it contains the block decoder) becomes a real call once the
-        // decoder grows, and the call ABI costs this kernel half its throughput
-        auto seek = [&](uint32_t x, uint32_t d, bool may_go_back) __attribute__((always_inline)) -> bool {
+        auto cbw = [&](uint32_t x) { return __uint_as_float(cx.m(x, M_CBW)); }; // q_weight * bmw of the block list x is positioned on
+        // POSITIONS list x on the first block whose block_max >= d; false when the list has no posting >= d. With the
+        // interleaved skip table the block is only located (table words + its max weight into the list's state) and decoded
+        // later, by ensure_docs(), if it can still matter; without it (Elias-Fano layouts) it is decoded at once.
+        // `skipping`: the list moves on from its current block after a window that could not hold a result; blocks whose
+        // own best posting, added to `rest` (the bound of all the other lists, valid up to doc-id hi2), cannot enter are
+        // passed over unexamined (find_block_where).
+        // always_inline: left to the inliner, the lambda becomes a real call once it grows, and the call ABI costs this
+        // kernel half its throughput
+        // block codecs compiled for one codec always come with the table (launch_batch passes it to these kernels
+        // unconditionally), so the decode-at-once path is not even compiled into them: one copy less of the decoder
+        constexpr bool ALWAYS_TABBED = CODEC_T >= 0 && CODEC_T != CODEC_PEF;
+        const bool tabbed = ALWAYS_TABBED || (!cx.is_pef() && cx.skip);
+        // Block-max pruning (position first, decode if the block can matter; per-window bounds from the blocks' max weights)
+        // pays for queries of <= 2 lists: half the blocks are never decoded. With more lists the sum of the block maxima
+        // is rarely below the threshold (measured on the GOV2-scale batch: 3-4 lists decode 6 % fewer blocks, 5+ none) and
+        // the bookkeeping costs more than it saves, so those classes keep list-level bounds and decode as they position.
+        constexpr bool BLOCKMAX = MODE == 0 && TMAX <= DS2I_BLOCKMAX_TMAX;
+        auto position = [&](uint32_t x, uint32_t d, bool may_go_back, bool skipping, float rest, uint32_t hi2, bool eager_freqs) __attribute__((always_inline)) -> bool {
             if (d >= uniform(L.nomore[x])) return false;
             const uint32_t cur = cx.m(x, M_CUR);
             uint32_t from;
             if (cur == 0xFFFFFFFFu) from = 0;
             else if (d > cx.m(x, M_BMAX)) from = cur + 1;
-            else if (may_go_back && d < uniform(L.docs[x][0])) from = 0; // a non-essential list may have been moved ahead
+            else if (may_go_back && d < (tabbed ? cx.m(x, M_BASE) : uniform(L.docs[x][0]))) from = 0; // a non-essential list may have been moved ahead
             else return true;
-            uint32_t blk;
+            uint32_t blk, bmax_u;
+            float w = 0.f;
             typename decltype(cx)::BlockInfo bi;
-            const bool tabbed = !cx.is_pef() && cx.skip;
-            { PT_BEGIN(cx); blk = tabbed ? cx.find_block_info(x, from, d, bi) : cx.find_block(x, from, d); PT_END(cx, PH_FIND); }
+            const float* wtab = (BLOCKMAX && a.bmw) ? a.bmw + cx.m(x, M_PBASE) : nullptr;
+            {
+                PT_BEGIN(cx);
+                if (!ALWAYS_TABBED && !tabbed) blk = cx.find_block(x, from, d, bmax_u, wtab, w);
+                else if (BLOCKMAX && skipping && wtab) {
+                    const float qx = qw(x);
+                    blk = cx.find_block_where(x, from, d, bi, wtab, w, [&](uint32_t bm, float wv) { return bm >= hi2 || tk.would_enter((rest + qx * wv) * BOUND_SLACK); });
+                } else blk = cx.find_block_info(x, from, d, bi, wtab, w);
+                PT_END(cx, PH_FIND);
+            }
             if (blk >= cx.m(x, M_NB)) {
                 if (lane == 0) L.nomore[x] = d;
                 wave_sync();
                 return false;
             }
-            cx.s_bm_examined += 1;
+            cx.s_bm_examined += skipping ? blk - from + 1 : 1u;
             cx.s_bytes += 4;
-            if (blk != cur) cx.decode_docs(x, blk, tabbed ? &bi : nullptr);
+            if (blk != cur) {
+                if (BLOCKMAX && tabbed) {
+                    cx.setm(x, M_CUR, blk);
+                    cx.setm(x, M_BMAX, bi.bmax);
+                    cx.setm(x, M_EP, bi.ep);
+                    cx.setm(x, M_NEXTEP, bi.next_ep);
+                    cx.setm(x, M_BASE, bi.base);
+                    cx.setm(x, M_DDEC, 0);
+                    cx.setm(x, M_FDEC, 0);
+                } else if constexpr (!(BLOCKMAX && ALWAYS_TABBED)) {
+                    cx.decode_docs(x, blk, tabbed ? &bi : nullptr);
+                    if (tabbed) cx.setm(x, M_BASE, bi.base);
+                    // the path is bound by dependent round trips, not by instructions: an owner's freqs are wanted for the
+                    // freq-only bound of its first candidate, and decoding them now -- while the block's bytes are still
+                    // in the staging window -- saves the reload a later decode would wait for
+                    if (eager_freqs) cx.decode_freqs(x);
+                }
+                cx.setm(x, M_CBW, __float_as_uint(wtab ? qw(x) * w : maxw(x)));
+                wave_sync();
+            }
             return true;
+        };
+        auto ensure_docs = [&](uint32_t x) __attribute__((always_inline)) {
+            if constexpr (!BLOCKMAX) return;
+            if (cx.m(x, M_DDEC)) return;
+            typename decltype(cx)::BlockInfo bi;
+            bi.ep = cx.m(x, M_EP);
+            bi.next_ep = cx.m(x, M_NEXTEP);
+            bi.bmax = cx.m(x, M_BMAX);
+            bi.base = cx.m(x, M_BASE);
+            cx.decode_docs(x, cx.m(x, M_CUR), &bi);
         };
         // the parts of a split query share a score histogram (ScoreHist). Parts may add a document's term scores in
         // different orders (which lists are essential depends on each part's threshold), hence the 1e-5 relaxation
         const bool shared_floor = MODE == 0 && !whole && a.q_hist;
         ScoreHist sh;
         sh.init(shared_floor ? a.q_hist : nullptr, shared_floor ? a.q_hist_slot[q] : 0u, shared_floor ? ubf(nt - 1) : 0.f, 1.0f - 1.0e-5f);
+        ScoreHist::Snapshot hsnap = {0u, 0u, 0u, 0u};
+        if (shared_floor) hsnap = sh.load();
         auto adopt_floor = [&]() __attribute__((always_inline)) { // the other parts of this query may have raised the bar
-            const float f = sh.floor(tk.k);
+            const float f = sh.floor(hsnap, tk.k);
+            hsnap = sh.load(); // resolved a round from now
             if (f > tk.floor) { tk.floor = f; update_non_ess(); }
         };
+        uint32_t skip_x = 0xFFFFFFFFu, skip_hi2 = 0; // the list that moves on after a window that was passed over
+        float skip_rest = 0.f;
         while (non_ess < nt && lo < N) {
             ++cx.s_rounds;
-            if (shared_floor) adopt_floor();
+            if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_TOPK); }
             if (non_ess >= nt) break;
-            // ---- window: one block of every essential list
-            uint32_t hi = N - 1, live = 0; // live: bit x = essential list x has postings in or after the window
+            // ---- window: every essential list is positioned on its block at lo; [lo, hi] ends with the first of them
+            uint32_t hi = N - 1, hi2 = N - 1, xmin = 0xFFFFFFFFu, live = 0; // live: bit x = essential list x has postings in or after the window
             for (uint32_t p = non_ess; p < nt; ++p) {
                 const uint32_t x = slot_at(p);
-                if (!seek(x, lo, false)) continue;
+                if (!position(x, lo, false, x == skip_x, skip_rest, skip_hi2, MODE == 0)) continue;
                 live |= 1u << x;
                 const uint32_t bm = cx.m(x, M_BMAX);
-                hi = bm < hi ? bm : hi;
+                if (bm < hi || xmin == 0xFFFFFFFFu) { hi2 = hi; hi = bm < hi ? bm : hi; xmin = x; }
+                else if (bm < hi2) hi2 = bm;
+            }
+            skip_x = 0xFFFFFFFFu;
+            if (!live) break;
+            // ---- bounds of this window. wub[p] = the most the lists lord[0..p] can add to a document of the window: the
+            // non-essential lists by their list maxima, the essential ones by the max weight of the block they are
+            // positioned on (block-max maxscore). The first `ps` lists cannot lift a document into the heap on their own:
+            // inside this window they are treated like non-essential lists (looked up for the candidates of the others,
+            // decoded only if a candidate needs them); if that is all of them the window is passed over undecoded.
+            uint32_t ps = non_ess;
+            if constexpr (BLOCKMAX) {
+                float acc = 0.f, rest = 0.f;
+                ps = nt;
+                for (uint32_t p = 0; p < nt; ++p) {
+                    const uint32_t x = slot_at(p);
+                    const float bnd = p < non_ess ? maxw(x) : (((live >> x) & 1u) ? cbw(x) : 0.f);
+                    acc = p ? acc + bnd : bnd;
+                    if (x != xmin) rest += bnd;
+                    if (lane == 0) L.wub[p] = acc;
+                    if (ps == nt && p >= non_ess && tk.would_enter(acc * BOUND_SLACK)) ps = p;
+                }
+                wave_sync();
+                if (ps == nt) { // no document of [lo, hi] can enter: move the list that ends the window, skipping by weight
+                    skip_x = xmin;
+                    skip_rest = rest;
+                    skip_hi2 = hi2;
+                    if (hi == 0xFFFFFFFFu) break;
+                    lo = hi + 1;
+                    continue;
+                }
+            }
+            for (uint32_t p = ps; p < nt; ++p) {
+                const uint32_t x = slot_at(p);
+                if (!((live >> x) & 1u)) continue;
+                if (BLOCKMAX && !cx.m(x, M_DDEC)) { // docs, then freqs while the block's bytes are in the staging window (see position())
+                    ensure_docs(x);
+                    cx.decode_freqs(x);
+                }
                 if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
             }
-            if (!live) break;
             wave_sync();
             if (MODE == 2) { // every freq of every list inside the window
                 unsigned long long fs = 0;
@@ -998,7 +1137,7 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                 for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
                 fsum += fs;
             }
-            for (uint32_t p = non_ess; p < nt; ++p) { // ---- owner list e: its postings in [lo, hi] not owned earlier
+            for (uint32_t p = ps; p < nt; ++p) { // ---- owner list e: its postings in [lo, hi] not owned earlier
                 if (p < non_ess) continue;             // became non-essential during this window
                 const uint32_t e = slot_at(p);
                 if (!((live >> e) & 1u)) continue;
@@ -1019,18 +1158,21 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     continue;
                 }
                 uint32_t fm0 = 0, fm1 = 0; // lists (beyond e) each candidate occurs in
-                const float ub_ne = non_ess ? ubf(non_ess - 1) : 0.f;
+                // lists below the first owner (non-essential, or unable to lift a document of this window): looked up last
+                const uint32_t fo = ps > non_ess ? ps : non_ess;
+                const float ub_low = fo ? ubw(fo - 1) : 0.f;
                 // The owner's term score is bounded by its freq alone (doc_term_weight falls with norm_len, so the
-                // collection's shortest document bounds it): most postings of a list have small freqs and fall below
-                // the threshold here -- before their norm_len is gathered or a non-essential list is probed for them.
+                // collection's shortest document bounds it) and by its block's max weight: most postings of a list have
+                // small freqs and fall below the threshold here -- before their norm_len is gathered or another list
+                // is probed for them.
                 if (!cx.m(e, M_FDEC)) cx.decode_freqs(e);
                 float pb0, pb1;
                 {
-                    const float we = qw(e), me = maxw(e);
+                    const float we = qw(e), me = cbw(e);
                     const float fb0 = we * doc_term_weight(L.freqs[e][lane], a.min_norm_len);
                     const float fb1 = we * doc_term_weight(L.freqs[e][lane + 64], a.min_norm_len);
-                    pb0 = (fb0 < me ? fb0 : me) + ub_ne;
-                    pb1 = (fb1 < me ? fb1 : me) + ub_ne;
+                    pb0 = (fb0 < me ? fb0 : me) + ub_low;
+                    pb1 = (fb1 < me ? fb1 : me) + ub_low;
                 }
                 for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
                     const uint32_t x = slot_at(p2);
@@ -1039,26 +1181,29 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     uint32_t q0, q1;
                     const bool f0 = member_bsearch(L.docs[x], c0, v0, q0);
                     const bool f1 = member_bsearch(L.docs[x], c1, v1, q1);
-                    const float mx = maxw(x);
+                    const float mx = cbw(x);
                     if (f0) { L.pos[x][lane] = (uint8_t)q0; L.dup[x][q0] = 1; fm0 |= 1u << x; pb0 += mx; }
                     if (f1) { L.pos[x][lane + 64] = (uint8_t)q1; L.dup[x][q1] = 1; fm1 |= 1u << x; pb1 += mx; }
                     PT_END(cx, PH_MEMBER);
                 }
                 wave_sync();
-                // max-score bound first: nothing below it is gathered, scored or looked up in the non-essential lists
+                // max-score bound first: nothing below it is gathered, scored or looked up in the lower lists
                 bool s0 = v0 && tk.would_enter(pb0 * BOUND_SLACK), s1 = v1 && tk.would_enter(pb1 * BOUND_SLACK);
                 uint64_t b0 = ballot(s0), b1 = ballot(s1);
                 if (!(b0 | b1)) continue;
                 const uint32_t ns = (uint32_t)(__builtin_popcountll(b0) + __builtin_popcountll(b1));
                 cx.s_bytes += 4ull * ns;
                 cx.s_scored += ns;
-                const float nl0 = s0 ? a.norm_lens[c0] : 0.f, nl1 = s1 ? a.norm_lens[c1] : 0.f;
-                unsigned long long a0 = 0, a1 = 0; // fixed-point sums (fx_of); sc0 / sc1 are their float values
-                float sc0 = 0.f, sc1 = 0.f;
+                unsigned long long a0 = 0, a1 = 0; // fixed-point sums (FxScale); sc0 / sc1 are their float values
+                float sc0 = 0.f, sc1 = 0.f, nl0, nl1;
                 {
+                    PT_BEGIN(cx);
+                    nl0 = s0 ? a.norm_lens[c0] : 0.f;
+                    nl1 = s1 ? a.norm_lens[c1] : 0.f;
                     const float w = qw(e);
-                    if (s0) a0 = fx_of(w * doc_term_weight(L.freqs[e][lane], nl0));
-                    if (s1) a1 = fx_of(w * doc_term_weight(L.freqs[e][lane + 64], nl1));
+                    if (s0) a0 = fx.of(w * doc_term_weight(L.freqs[e][lane], nl0));
+                    if (s1) a1 = fx.of(w * doc_term_weight(L.freqs[e][lane + 64], nl1));
+                    PT_END(cx, PH_SCORE);
                 }
                 for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
                     const uint32_t x = slot_at(p2);
@@ -1066,14 +1211,16 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                     if (!(ballot(h0) | ballot(h1))) continue;
                     if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                     const float w = qw(x);
-                    if (h0) a0 += fx_of(w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0));
-                    if (h1) a1 += fx_of(w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1));
+                    if (h0) a0 += fx.of(w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0));
+                    if (h1) a1 += fx.of(w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1));
                 }
-                // non-essential lists, highest upper bound first; a candidate stops as soon as it cannot enter
-                for (uint32_t p2 = non_ess; p2-- > 0;) {
-                    const float ubp = ubf(p2);
-                    sc0 = fx_value(a0);
-                    sc1 = fx_value(a1);
+                // the lower lists, highest bound first; a candidate stops as soon as it cannot enter (queries.hpp:553-564).
+                // A list is first only positioned: its block is decoded if some candidate could still enter with the
+                // block's best weight on top of its score.
+                for (uint32_t p2 = fo; p2-- > 0;) {
+                    const float ubp = ubw(p2), lowb = p2 ? ubw(p2 - 1) : 0.f;
+                    sc0 = fx.value(a0);
+                    sc1 = fx.value(a1);
                     s0 = s0 && tk.would_enter((sc0 + ubp) * BOUND_SLACK);
                     s1 = s1 && tk.would_enter((sc1 + ubp) * BOUND_SLACK);
                     bool r0 = s0, r1 = s1; // still to be looked up in list x
@@ -1083,24 +1230,35 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
                         const uint64_t rb0 = ballot(r0), rb1 = ballot(r1);
                         if (!(rb0 | rb1)) break;
                         const uint32_t amin = rb0 ? bcast(c0, (uint32_t)__builtin_ctzll(rb0)) : bcast(c1, (uint32_t)__builtin_ctzll(rb1));
-                        if (!seek(x, amin, true)) break; // nothing >= amin in list x
+                        if (!position(x, amin, true, false, 0.f, 0u, false)) break; // nothing >= amin in list x
                         const uint32_t bm = cx.m(x, M_BMAX);
                         const bool w0 = r0 && c0 <= bm, w1 = r1 && c1 <= bm;
-                        uint32_t q0, q1;
-                        const bool f0 = member_bsearch(L.docs[x], c0, w0, q0);
-                        const bool f1 = member_bsearch(L.docs[x], c1, w1, q1);
-                        if (ballot(f0) | ballot(f1)) {
-                            if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
-                            const float w = qw(x);
-                            if (f0) a0 += fx_of(w * doc_term_weight(L.freqs[x][q0], nl0));
-                            if (f1) a1 += fx_of(w * doc_term_weight(L.freqs[x][q1], nl1));
+                        bool t0 = w0, t1 = w1;
+                        if constexpr (BLOCKMAX) {
+                            const float cb = cbw(x) + lowb;
+                            t0 = w0 && tk.would_enter((sc0 + cb) * BOUND_SLACK);
+                            t1 = w1 && tk.would_enter((sc1 + cb) * BOUND_SLACK);
                         }
+                        if (ballot(t0) | ballot(t1)) {
+                            ensure_docs(x);
+                            uint32_t q0, q1;
+                            const bool f0 = member_bsearch(L.docs[x], c0, t0, q0);
+                            const bool f1 = member_bsearch(L.docs[x], c1, t1, q1);
+                            if (ballot(f0) | ballot(f1)) {
+                                if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
+                                const float w = qw(x);
+                                if (f0) a0 += fx.of(w * doc_term_weight(L.freqs[x][q0], nl0));
+                                if (f1) a1 += fx.of(w * doc_term_weight(L.freqs[x][q1], nl1));
+                            }
+                        }
+                        s0 = s0 && !(w0 && !t0); // cannot enter even with this block's best posting
+                        s1 = s1 && !(w1 && !t1);
                         r0 = r0 && !w0;
                         r1 = r1 && !w1;
                     }
                 }
-                sc0 = fx_value(a0);
-                sc1 = fx_value(a1);
+                sc0 = fx.value(a0);
+                sc1 = fx.value(a1);
                 bool inserted = false;
                 for (int half = 0; half < 2; ++half) {
                     const bool al = half ? s1 : s0;
@@ -1128,6 +1286,10 @@ __global__ void __launch_bounds__(64) k_disjunctive(BatchArgs a) {
             if (lane == 0) { a.unit_count[uid] = MODE == 0 ? tk.n : count; a.unit_freq_sum[uid] = fsum; }
             if (MODE == 0) store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
         }
+        if (STATS && a.unit_clock && lane == 0) { a.unit_clock[2ull * uid] = t_unit; a.unit_clock[2ull * uid + 1] = wall_clock64(); }
+#ifdef DS2I_PHASE_TIMING
+        cx.s_phase[PH_TOTAL] += __builtin_readcyclecounter() - pt_unit0;
+#endif
     }
     cx.flush_stats(a.stats);
 }

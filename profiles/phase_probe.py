@@ -1,18 +1,19 @@
-"""Per-phase cycle split of the conjunctive kernel per LDS class (needs a -DDS2I_PHASE_TIMING build:
+"""Per-phase cycle split of the class kernels of one operator (usage: phase_probe.py [codec] [op]) (needs a -DDS2I_PHASE_TIMING build:
 DS2I_EXTRA_CFLAGS=-DDS2I_PHASE_TIMING python ds2i_amd/build.py --force)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ds2i_amd as d
 codec = sys.argv[1] if len(sys.argv) > 1 else "block_optpfor"
+op = sys.argv[2] if len(sys.argv) > 2 else "ranked_and"
 p = d.SynthParams(seed=0xD5210004, num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4)
 img, wand, n = d.synth_build(p, codec)
 idx = d.Index(codec, img, wand)
 queries = d.synth_queries(0x51E21, p.num_terms, 4096)
 cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3
-names = ["total", "docs", "freqs", "find", "member", "score", "topk"]
+names = ["total", "docs", "freqs", "find", "member", "score", "topk/floor"]
 for c in range(3):
     qs = [q for q in queries if cls_of(len(set(q))) == c]
-    b = d.Batch(idx, "ranked_and", qs, k=10)
+    b = d.Batch(idx, op, qs, k=10)
     b.run(); b.run()
     t0 = time.perf_counter()
     st = b.run()

@@ -322,6 +322,15 @@ def test_ranked_and_pruning_fuzz_bit_identical(built_lib, seed):
             t = pipe.submit("ranked_and", qs, k=k)
             _, ptopk, _ = pipe.wait(t)
             assert np.array_equal(ptopk, otopk), (codec, k)
+            # the union operators: block-max pruned on the GPU; within 1e-5 of the oracle and bit-identical to each other
+            oc, otopk, otlen, _, _ = oidx.query_batch("ranked_or", qs, k=k)
+            ref = None
+            for op in ("wand", "maxscore", "ranked_or"):
+                gc, gtopk, gtlen, _ = gidx.query_batch(op, qs, k=k)
+                assert np.array_equal(gtlen, otlen), (codec, k, op, np.argwhere(gtlen != otlen)[:3])
+                assert np.allclose(gtopk, otopk, rtol=1e-5, atol=0), (codec, k, op, np.argwhere(~np.isclose(gtopk, otopk, rtol=1e-5, atol=0))[:3])
+                ref = gtopk if ref is None else ref
+                assert np.array_equal(gtopk, ref), (codec, k, op)
         pipe.close()
 
 
