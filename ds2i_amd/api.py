@@ -399,9 +399,10 @@ class Batch:
         return st, n.value
 
     def phase_cycles(self, cls):
-        out = np.zeros(7, dtype=np.uint64)
-        _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), 7))
-        return dict(zip(("total", "docs", "freqs", "find", "member", "score", "topk"), out.tolist()))
+        names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert")
+        out = np.zeros(len(names), dtype=np.uint64)
+        _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), len(names)))
+        return dict(zip(names, out.tolist()))
 
     def fetch(self):
         nq = max(self.nq, 1)

@@ -24,7 +24,7 @@ struct QTerm {
 };
 static_assert(sizeof(QTerm) == 64, "QTerm is a 64-byte device record");
 
-enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_COUNT };
+enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_PROLOG, PH_PROBE, PH_INSERT, PH_COUNT };
 struct Stats {
     unsigned long long docs_blocks, freqs_blocks, block_max_examined, algorithmic_bytes, postings_scored, rounds;
     unsigned long long phase_cycles[PH_COUNT]; // summed over waves; only filled with -DDS2I_PHASE_TIMING

@@ -1075,6 +1075,9 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
             if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_TOPK); }
             if (non_ess >= nt) break;
             // ---- window: every essential list is positioned on its block at lo; [lo, hi] ends with the first of them
+#ifdef DS2I_PHASE_TIMING
+            const unsigned long long pt_prolog0 = __builtin_readcyclecounter();
+#endif
             uint32_t hi = N - 1, hi2 = N - 1, xmin = 0xFFFFFFFFu, live = 0; // live: bit x = essential list x has postings in or after the window
             for (uint32_t p = non_ess; p < nt; ++p) {
                 const uint32_t x = slot_at(p);
@@ -1108,6 +1111,9 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     skip_x = xmin;
                     skip_rest = rest;
                     skip_hi2 = hi2;
+#ifdef DS2I_PHASE_TIMING
+                    cx.s_phase[PH_PROLOG] += __builtin_readcyclecounter() - pt_prolog0;
+#endif
                     if (hi == 0xFFFFFFFFu) break;
                     lo = hi + 1;
                     continue;
@@ -1123,6 +1129,9 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
             }
             wave_sync();
+#ifdef DS2I_PHASE_TIMING
+            cx.s_phase[PH_PROLOG] += __builtin_readcyclecounter() - pt_prolog0;
+#endif
             if (MODE == 2) { // every freq of every list inside the window
                 unsigned long long fs = 0;
                 for (uint32_t p = 0; p < nt; ++p) {
@@ -1217,6 +1226,9 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 // the lower lists, highest bound first; a candidate stops as soon as it cannot enter (queries.hpp:553-564).
                 // A list is first only positioned: its block is decoded if some candidate could still enter with the
                 // block's best weight on top of its score.
+#ifdef DS2I_PHASE_TIMING
+                const unsigned long long pt_probe0 = __builtin_readcyclecounter();
+#endif
                 for (uint32_t p2 = fo; p2-- > 0;) {
                     const float ubp = ubw(p2), lowb = p2 ? ubw(p2 - 1) : 0.f;
                     sc0 = fx.value(a0);
@@ -1257,6 +1269,10 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                         r1 = r1 && !w1;
                     }
                 }
+#ifdef DS2I_PHASE_TIMING
+                cx.s_phase[PH_PROBE] += __builtin_readcyclecounter() - pt_probe0;
+                const unsigned long long pt_ins0 = __builtin_readcyclecounter();
+#endif
                 sc0 = fx.value(a0);
                 sc1 = fx.value(a1);
                 bool inserted = false;
@@ -1275,6 +1291,9 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     }
                 }
                 if (inserted) update_non_ess(); // queries.hpp:568-574
+#ifdef DS2I_PHASE_TIMING
+                cx.s_phase[PH_INSERT] += __builtin_readcyclecounter() - pt_ins0;
+#endif
             }
             if (hi == 0xFFFFFFFFu) break;
             lo = hi + 1;

@@ -5,7 +5,7 @@ tmax = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 src = sys.argv[3] if len(sys.argv) > 3 else "/root/repo/ds2i_amd/csrc/kernels.hip"
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DDS2I_TU_TMAX=" + tmax,
-       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
+       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + sys.argv[4:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}

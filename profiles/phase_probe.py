@@ -10,7 +10,7 @@ img, wand, n = d.synth_build(p, codec)
 idx = d.Index(codec, img, wand)
 queries = d.synth_queries(0x51E21, p.num_terms, 4096)
 cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3
-names = ["total", "docs", "freqs", "find", "member", "score", "topk/floor"]
+names = ["total", "docs", "freqs", "find", "member", "score", "topk/floor", "prolog(incl find/docs)", "probe(incl find/docs/freqs)", "insert"]
 for c in range(3):
     qs = [q for q in queries if cls_of(len(set(q))) == c]
     b = d.Batch(idx, op, qs, k=10)
