@@ -1035,14 +1035,16 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     cx.setm(x, M_FDEC, 0);
                 } else if constexpr (!(BLOCKMAX && ALWAYS_TABBED)) {
                     cx.decode_docs(x, blk, tabbed ? &bi : nullptr);
-                    if (tabbed) cx.setm(x, M_BASE, bi.base);
+                    if (MODE == 0 && tabbed) cx.setm(x, M_BASE, bi.base); // (only the lower-list lookups of the top-k modes go back)
                     // the path is bound by dependent round trips, not by instructions: an owner's freqs are wanted for the
                     // freq-only bound of its first candidate, and decoding them now -- while the block's bytes are still
                     // in the staging window -- saves the reload a later decode would wait for
                     if (eager_freqs) cx.decode_freqs(x);
                 }
-                cx.setm(x, M_CBW, __float_as_uint(wtab ? qw(x) * w : maxw(x)));
-                wave_sync();
+                if (MODE == 0) {
+                    cx.setm(x, M_CBW, __float_as_uint(wtab ? qw(x) * w : maxw(x)));
+                    wave_sync();
+                }
             }
             return true;
         };
@@ -1086,6 +1088,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 const uint32_t bm = cx.m(x, M_BMAX);
                 if (bm < hi || xmin == 0xFFFFFFFFu) { hi2 = hi; hi = bm < hi ? bm : hi; xmin = x; }
                 else if (bm < hi2) hi2 = bm;
+                if (!BLOCKMAX && lane < 32) ((uint32_t*)L.dup[x])[lane] = 0; // (block-max windows clear the owners' flags below)
             }
             skip_x = 0xFFFFFFFFu;
             if (!live) break;
@@ -1119,14 +1122,16 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     continue;
                 }
             }
-            for (uint32_t p = ps; p < nt; ++p) {
-                const uint32_t x = slot_at(p);
-                if (!((live >> x) & 1u)) continue;
-                if (BLOCKMAX && !cx.m(x, M_DDEC)) { // docs, then freqs while the block's bytes are in the staging window (see position())
-                    ensure_docs(x);
-                    cx.decode_freqs(x);
+            if constexpr (BLOCKMAX) {
+                for (uint32_t p = ps; p < nt; ++p) {
+                    const uint32_t x = slot_at(p);
+                    if (!((live >> x) & 1u)) continue;
+                    if (!cx.m(x, M_DDEC)) { // docs, then freqs while the block's bytes are in the staging window (see position())
+                        ensure_docs(x);
+                        cx.decode_freqs(x);
+                    }
+                    if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
                 }
-                if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
             }
             wave_sync();
 #ifdef DS2I_PHASE_TIMING
