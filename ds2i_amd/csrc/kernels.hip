@@ -883,13 +883,35 @@ struct FxScale {
 //   * a candidate's max-score bound (lists it was found in + all non-essential lists) is tested first, the survivors
 //     are scored exactly: essential lists by position, non-essential lists probed from the highest bound down while
 //     score + upper_bound can still enter (queries.hpp:553-564), 128 candidates at a time.
+// Position (0..127) of one candidate in each of the query's lists, 7 bits per list slot, in registers: the union kernels
+// are capped by LDS per wave (residency hides their dependent round trips), so what a lane knows about its own two
+// candidates stays out of LDS. <=4 lists fit one dword, <=8 one qword, 16 two.
 template <int TMAX>
-struct LdsOr : Lds<TMAX, true> {
+struct PosPack {
+    typedef typename std::conditional<(TMAX <= 4), uint32_t, unsigned long long>::type word_t;
+    static constexpr int PER = TMAX <= 4 ? 4 : 9, NW = (TMAX + PER - 1) / PER;
+    word_t w[NW];
+    DS2I_DEV void clear() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = 0;
+    }
+    DS2I_DEV void set(uint32_t x, uint32_t pos) { // x wave-uniform
+        if (NW == 1 || x < (uint32_t)PER) w[0] |= (word_t)pos << (7u * x);
+        else w[NW - 1] |= (word_t)pos << (7u * (x - (uint32_t)PER));
+    }
+    DS2I_DEV uint32_t get(uint32_t x) const {
+        if (NW == 1 || x < (uint32_t)PER) return (uint32_t)(w[0] >> (7u * x)) & 127u;
+        return (uint32_t)(w[NW - 1] >> (7u * (x - (uint32_t)PER))) & 127u;
+    }
+};
+
+template <int TMAX>
+struct LdsOr : Lds<TMAX, true, false> {
     uint32_t lord[16];   // list slots by increasing max score
     float lub[16];       // upper_bounds (prefix sums of max scores in that order)
     float wub[16];       // the same prefix sums for the current window: essential lists by their current block's max weight
     uint32_t nomore[16]; // list has no posting >= this doc-id
-    uint8_t dup[TMAX][128];
+    uint32_t dupw[TMAX][4]; // bit i of list x: posting i of its current block is owned by an earlier list in this window
 };
 
 // MODE 0: top-k (wand / maxscore / ranked_or). MODE 1: or_query (count of the union, queries.hpp:88-131): every list is
@@ -1088,7 +1110,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 const uint32_t bm = cx.m(x, M_BMAX);
                 if (bm < hi || xmin == 0xFFFFFFFFu) { hi2 = hi; hi = bm < hi ? bm : hi; xmin = x; }
                 else if (bm < hi2) hi2 = bm;
-                if (!BLOCKMAX && lane < 32) ((uint32_t*)L.dup[x])[lane] = 0; // (block-max windows clear the owners' flags below)
+                if (!BLOCKMAX && lane < 4) L.dupw[x][lane] = 0; // (block-max windows clear the owners' flags below)
             }
             skip_x = 0xFFFFFFFFu;
             if (!live) break;
@@ -1130,7 +1152,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                         ensure_docs(x);
                         cx.decode_freqs(x);
                     }
-                    if (lane < 32) ((uint32_t*)L.dup[x])[lane] = 0;
+                    if (lane < 4) L.dupw[x][lane] = 0;
                 }
             }
             wave_sync();
@@ -1156,8 +1178,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 const uint32_t e = slot_at(p);
                 if (!((live >> e) & 1u)) continue;
                 const uint32_t c0 = L.docs[e][lane], c1 = L.docs[e][lane + 64];
-                bool v0 = c0 >= lo && c0 <= hi && !L.dup[e][lane];
-                bool v1 = c1 >= lo && c1 <= hi && !L.dup[e][lane + 64];
+                bool v0 = c0 >= lo && c0 <= hi && !((L.dupw[e][lane >> 5] >> (lane & 31u)) & 1u);
+                bool v1 = c1 >= lo && c1 <= hi && !((L.dupw[e][2u + (lane >> 5)] >> (lane & 31u)) & 1u);
                 if (!(ballot(v0) | ballot(v1))) continue;
                 if (MODE != 0) { // or_query: count the owned candidates, mark their copies in the later lists
                     count += (unsigned long long)(__builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1)));
@@ -1165,13 +1187,16 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                         const uint32_t x = slot_at(p2);
                         if (!((live >> x) & 1u)) continue;
                         uint32_t q0, q1;
-                        if (member_bsearch(L.docs[x], c0, v0, q0)) L.dup[x][q0] = 1;
-                        if (member_bsearch(L.docs[x], c1, v1, q1)) L.dup[x][q1] = 1;
+                        if (member_bsearch(L.docs[x], c0, v0, q0)) atomicOr(&L.dupw[x][q0 >> 5], 1u << (q0 & 31u));
+                        if (member_bsearch(L.docs[x], c1, v1, q1)) atomicOr(&L.dupw[x][q1 >> 5], 1u << (q1 & 31u));
                     }
                     wave_sync();
                     continue;
                 }
                 uint32_t fm0 = 0, fm1 = 0; // lists (beyond e) each candidate occurs in
+                PosPack<TMAX> pp0, pp1;   // ... and where
+                pp0.clear();
+                pp1.clear();
                 // lists below the first owner (non-essential, or unable to lift a document of this window): looked up last
                 const uint32_t fo = ps > non_ess ? ps : non_ess;
                 const float ub_low = fo ? ubw(fo - 1) : 0.f;
@@ -1196,8 +1221,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     const bool f0 = member_bsearch(L.docs[x], c0, v0, q0);
                     const bool f1 = member_bsearch(L.docs[x], c1, v1, q1);
                     const float mx = cbw(x);
-                    if (f0) { L.pos[x][lane] = (uint8_t)q0; L.dup[x][q0] = 1; fm0 |= 1u << x; pb0 += mx; }
-                    if (f1) { L.pos[x][lane + 64] = (uint8_t)q1; L.dup[x][q1] = 1; fm1 |= 1u << x; pb1 += mx; }
+                    if (f0) { pp0.set(x, q0); atomicOr(&L.dupw[x][q0 >> 5], 1u << (q0 & 31u)); fm0 |= 1u << x; pb0 += mx; }
+                    if (f1) { pp1.set(x, q1); atomicOr(&L.dupw[x][q1 >> 5], 1u << (q1 & 31u)); fm1 |= 1u << x; pb1 += mx; }
                     PT_END(cx, PH_MEMBER);
                 }
                 wave_sync();
@@ -1225,8 +1250,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     if (!(ballot(h0) | ballot(h1))) continue;
                     if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                     const float w = qw(x);
-                    if (h0) a0 += fx.of(w * doc_term_weight(L.freqs[x][L.pos[x][lane]], nl0));
-                    if (h1) a1 += fx.of(w * doc_term_weight(L.freqs[x][L.pos[x][lane + 64]], nl1));
+                    if (h0) a0 += fx.of(w * doc_term_weight(L.freqs[x][pp0.get(x)], nl0));
+                    if (h1) a1 += fx.of(w * doc_term_weight(L.freqs[x][pp1.get(x)], nl1));
                 }
                 // the lower lists, highest bound first; a candidate stops as soon as it cannot enter (queries.hpp:553-564).
                 // A list is first only positioned: its block is decoded if some candidate could still enter with the
