@@ -85,6 +85,7 @@ struct BatchArgs {
     const float* bmw;            // per block / chunk of the index: max doc_term_weight of its postings, or null
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
+    uint32_t dyn_lists;          // union kernels: list slots of decoded blocks in dynamic LDS (>= the longest query of the launch)
     Stats* stats;
 };
 

@@ -62,6 +62,10 @@ struct ds2i_hip_batch {
     // ---- device-only scratch: per-unit partial results of split queries + the shared floors
     size_t o_unit_count = 0, o_unit_topk = 0, o_unit_topk_len = 0, o_unit_freq_sum = 0, o_qfloor = 0, scr_bytes = 0;
     DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long, d_clk;
+    // union kernels (k_disjunctive) keep their decoded blocks in dynamic LDS sized per launch: a class's units are grouped
+    // by the list count of their query and every group is launched with just that many list slots
+    struct SubLaunch { uint32_t begin, end, lists; };
+    std::vector<SubLaunch> sub[NCLS];
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
     bool uploaded = false, launched = false;
@@ -313,6 +317,33 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     for (int c = 0; c < NCLS; ++c) {
         order_by_cost(b->unit_cost, cls_ids[c], b->order[c], b->scratch_u32); // costliest first
         b->ncls[c] = (uint32_t)b->order[c].size();
+        b->sub[c].clear();
+        if (!b->ncls[c]) continue;
+        // Residency hides the union kernels' dependent round trips and LDS per wave caps it. The <=2- and <=4-list kernels
+        // are capped by registers first (6 / 5 waves per SIMD), so only the many-list classes are cut into groups: the
+        // longest queries first, costliest first inside a group (stable). The groups of a class run back to back on its
+        // stream, so finer is not better: DS2I_DYN_GROUP = granularity in lists, measured on the GOV2-scale wand batch
+        // 0 (off) 60.6 k, 1: 60.0 k, 2: 62.4 k, 4: 61.0 k queries/s.
+        static const char* dg = std::getenv("DS2I_DYN_GROUP");
+        static const uint32_t dyn_group = dg ? (uint32_t)std::atoi(dg) : 2u;
+        const uint32_t cls_lists = c == 0 ? 2u : c == 1 ? 4u : c == 2 ? 8u : 16u;
+        const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
+        if (!union_kernel || c < 2 || dyn_group == 0) {
+            b->sub[c].push_back({0u, b->ncls[c], cls_lists});
+            continue;
+        }
+        auto lists_of = [&](uint32_t uid) {
+            const uint32_t q = b->units[uid].q, n = qoff[q + 1] - qoff[q];
+            return std::min(cls_lists, (n + dyn_group - 1) / dyn_group * dyn_group);
+        };
+        std::stable_sort(b->order[c].begin(), b->order[c].end(), [&](uint32_t x, uint32_t y) { return lists_of(x) > lists_of(y); });
+        for (uint32_t i = 0; i < b->ncls[c];) {
+            uint32_t j = i;
+            const uint32_t l = lists_of(b->order[c][i]);
+            while (j < b->ncls[c] && lists_of(b->order[c][j]) == l) ++j;
+            b->sub[c].push_back({i, j, l});
+            i = j;
+        }
     }
 
     static const bool debug_plan = std::getenv("DS2I_DEBUG_PLAN") != nullptr;
@@ -490,6 +521,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
         a.nslice = b->ncls[c];
+        a.dyn_lists = 0;
         a.num_docs = (uint32_t)idx->num_docs;
         a.k = b->k;
         a.codec = idx->kind >= DS2I_OPT ? (int)DS2I_OPT : idx->kind; // every freq_index layout decodes through the chunk directory
@@ -517,7 +549,13 @@ int launch_batch(ds2i_hip_batch* b) {
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;
-        HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, b->ncls[c], s));
+        const uint32_t* order_base = a.order;
+        for (const auto& sl : b->sub[c]) { // one launch per group of the class (a single group for everything but the union kernels)
+            a.order = order_base + sl.begin;
+            a.nslice = sl.end - sl.begin;
+            a.dyn_lists = sl.lists;
+            HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
+        }
         HIP_OK(hipEventRecord(b->ev_c1[c], s));
         HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[c], 0));
     }

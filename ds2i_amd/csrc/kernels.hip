@@ -43,10 +43,10 @@ DS2I_DEV void bind_meta(MetaLds& m, uint32_t* lds_meta) { m.p = lds_meta; }
 template <int T> DS2I_DEV void bind_meta(MetaReg<T>&, uint32_t*) {}
 
 template <int CODEC_T, class META, bool STATS = true, class LDS>
-DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
+DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a, uint32_t* docs, uint32_t* freqs) {
     CtxT<CODEC_T, META, STATS> c;
-    c.docs = &L.docs[0][0];
-    c.freqs = &L.freqs[0][0];
+    c.docs = docs;
+    c.freqs = freqs;
     bind_meta(c.meta, &L.meta[0][0]);
     c.exc = L.exc;
     s16_table_init(L.exc);
@@ -62,6 +62,10 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
     c.skip = (const uint2*)a.skip;
     c.init_stats();
     return c;
+}
+template <int CODEC_T, class META, bool STATS = true, class LDS>
+DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
+    return make_ctx<CODEC_T, META, STATS>(L, a, &L.docs[0][0], &L.freqs[0][0]);
 }
 
 template <int NK>
@@ -906,7 +910,10 @@ struct PosPack {
 };
 
 template <int TMAX>
-struct LdsOr : Lds<TMAX, true, false> {
+struct LdsOr { // (the decoded blocks are in dynamic shared memory, see k_disjunctive)
+    uint32_t meta[TMAX][M_WORDS];
+    uint32_t exc[EXC_LDS_DW]; // + the Simple16 field table (device_codecs.hpp)
+    uint32_t st[STAGE_DW];
     uint32_t lord[16];   // list slots by increasing max score
     float lub[16];       // upper_bounds (prefix sums of max scores in that order)
     float wub[16];       // the same prefix sums for the current window: essential lists by their current block's max weight
@@ -932,8 +939,14 @@ constexpr int DISJ_WAVES(int tmax, int mode) { return mode != 0 ? 1 : tmax <= 2 
 template <int TMAX, int CODEC_T, bool STATS = true, int MODE = 0>
 __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(BatchArgs a) {
     __shared__ LdsOr<TMAX> L;
+    // the decoded blocks live in DYNAMIC shared memory, sized by the launch for the longest query it contains
+    // (a.dyn_lists <= TMAX list slots: docs[dyn_lists][128] then freqs[dyn_lists][128]). Residency hides this kernel's
+    // dependent round trips and LDS per wave caps residency, so a 5-term query should not pay for 8 lists.
+    extern __shared__ uint32_t dyn_lds[];
+    uint32_t* const Ldocs = dyn_lds;
+    uint32_t* const Lfreqs = dyn_lds + 128u * a.dyn_lists;
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T, MetaLds, STATS> cx = make_ctx<CODEC_T, MetaLds, STATS>(L, a);
+    CtxT<CODEC_T, MetaLds, STATS> cx = make_ctx<CODEC_T, MetaLds, STATS>(L, a, Ldocs, Lfreqs);
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
         const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
@@ -949,7 +962,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
         TopK tk;
         tk.init(a.k);
         unsigned long long count = 0, fsum = 0;
-        if (nt == 0 || nt > (uint32_t)TMAX || N == 0) {
+        if (nt == 0 || nt > (uint32_t)TMAX || nt > a.dyn_lists || N == 0) {
             if (whole) {
                 if (lane == 0) { a.out_count[q] = 0; if (a.out_freq_sum) a.out_freq_sum[q] = 0; }
                 if (MODE == 0) store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
@@ -1024,7 +1037,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
             uint32_t from;
             if (cur == 0xFFFFFFFFu) from = 0;
             else if (d > cx.m(x, M_BMAX)) from = cur + 1;
-            else if (may_go_back && d < (tabbed ? cx.m(x, M_BASE) : uniform(L.docs[x][0]))) from = 0; // a non-essential list may have been moved ahead
+            else if (may_go_back && d < (tabbed ? cx.m(x, M_BASE) : uniform((Ldocs + 128u * x)[0]))) from = 0; // a non-essential list may have been moved ahead
             else return true;
             uint32_t blk, bmax_u;
             float w = 0.f;
@@ -1164,11 +1177,11 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 for (uint32_t p = 0; p < nt; ++p) {
                     const uint32_t x = slot_at(p);
                     if (!((live >> x) & 1u)) continue;
-                    const uint32_t c0 = L.docs[x][lane], c1 = L.docs[x][lane + 64];
+                    const uint32_t c0 = (Ldocs + 128u * x)[lane], c1 = (Ldocs + 128u * x)[lane + 64];
                     const bool i0 = c0 >= lo && c0 <= hi, i1 = c1 >= lo && c1 <= hi;
                     if (!(ballot(i0) | ballot(i1))) continue;
                     if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
-                    fs += (unsigned long long)(i0 ? L.freqs[x][lane] : 0u) + (i1 ? L.freqs[x][lane + 64] : 0u);
+                    fs += (unsigned long long)(i0 ? (Lfreqs + 128u * x)[lane] : 0u) + (i1 ? (Lfreqs + 128u * x)[lane + 64] : 0u);
                 }
                 for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
                 fsum += fs;
@@ -1177,7 +1190,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 if (p < non_ess) continue;             // became non-essential during this window
                 const uint32_t e = slot_at(p);
                 if (!((live >> e) & 1u)) continue;
-                const uint32_t c0 = L.docs[e][lane], c1 = L.docs[e][lane + 64];
+                const uint32_t c0 = (Ldocs + 128u * e)[lane], c1 = (Ldocs + 128u * e)[lane + 64];
                 bool v0 = c0 >= lo && c0 <= hi && !((L.dupw[e][lane >> 5] >> (lane & 31u)) & 1u);
                 bool v1 = c1 >= lo && c1 <= hi && !((L.dupw[e][2u + (lane >> 5)] >> (lane & 31u)) & 1u);
                 if (!(ballot(v0) | ballot(v1))) continue;
@@ -1187,8 +1200,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                         const uint32_t x = slot_at(p2);
                         if (!((live >> x) & 1u)) continue;
                         uint32_t q0, q1;
-                        if (member_bsearch(L.docs[x], c0, v0, q0)) atomicOr(&L.dupw[x][q0 >> 5], 1u << (q0 & 31u));
-                        if (member_bsearch(L.docs[x], c1, v1, q1)) atomicOr(&L.dupw[x][q1 >> 5], 1u << (q1 & 31u));
+                        if (member_bsearch((Ldocs + 128u * x), c0, v0, q0)) atomicOr(&L.dupw[x][q0 >> 5], 1u << (q0 & 31u));
+                        if (member_bsearch((Ldocs + 128u * x), c1, v1, q1)) atomicOr(&L.dupw[x][q1 >> 5], 1u << (q1 & 31u));
                     }
                     wave_sync();
                     continue;
@@ -1208,8 +1221,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 float pb0, pb1;
                 {
                     const float we = qw(e), me = cbw(e);
-                    const float fb0 = we * doc_term_weight(L.freqs[e][lane], a.min_norm_len);
-                    const float fb1 = we * doc_term_weight(L.freqs[e][lane + 64], a.min_norm_len);
+                    const float fb0 = we * doc_term_weight((Lfreqs + 128u * e)[lane], a.min_norm_len);
+                    const float fb1 = we * doc_term_weight((Lfreqs + 128u * e)[lane + 64], a.min_norm_len);
                     pb0 = (fb0 < me ? fb0 : me) + ub_low;
                     pb1 = (fb1 < me ? fb1 : me) + ub_low;
                 }
@@ -1218,8 +1231,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     if (!((live >> x) & 1u)) continue;
                     PT_BEGIN(cx);
                     uint32_t q0, q1;
-                    const bool f0 = member_bsearch(L.docs[x], c0, v0, q0);
-                    const bool f1 = member_bsearch(L.docs[x], c1, v1, q1);
+                    const bool f0 = member_bsearch((Ldocs + 128u * x), c0, v0, q0);
+                    const bool f1 = member_bsearch((Ldocs + 128u * x), c1, v1, q1);
                     const float mx = cbw(x);
                     if (f0) { pp0.set(x, q0); atomicOr(&L.dupw[x][q0 >> 5], 1u << (q0 & 31u)); fm0 |= 1u << x; pb0 += mx; }
                     if (f1) { pp1.set(x, q1); atomicOr(&L.dupw[x][q1 >> 5], 1u << (q1 & 31u)); fm1 |= 1u << x; pb1 += mx; }
@@ -1240,8 +1253,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     nl0 = s0 ? a.norm_lens[c0] : 0.f;
                     nl1 = s1 ? a.norm_lens[c1] : 0.f;
                     const float w = qw(e);
-                    if (s0) a0 = fx.of(w * doc_term_weight(L.freqs[e][lane], nl0));
-                    if (s1) a1 = fx.of(w * doc_term_weight(L.freqs[e][lane + 64], nl1));
+                    if (s0) a0 = fx.of(w * doc_term_weight((Lfreqs + 128u * e)[lane], nl0));
+                    if (s1) a1 = fx.of(w * doc_term_weight((Lfreqs + 128u * e)[lane + 64], nl1));
                     PT_END(cx, PH_SCORE);
                 }
                 for (uint32_t p2 = p + 1; p2 < nt; ++p2) {
@@ -1250,8 +1263,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     if (!(ballot(h0) | ballot(h1))) continue;
                     if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                     const float w = qw(x);
-                    if (h0) a0 += fx.of(w * doc_term_weight(L.freqs[x][pp0.get(x)], nl0));
-                    if (h1) a1 += fx.of(w * doc_term_weight(L.freqs[x][pp1.get(x)], nl1));
+                    if (h0) a0 += fx.of(w * doc_term_weight((Lfreqs + 128u * x)[pp0.get(x)], nl0));
+                    if (h1) a1 += fx.of(w * doc_term_weight((Lfreqs + 128u * x)[pp1.get(x)], nl1));
                 }
                 // the lower lists, highest bound first; a candidate stops as soon as it cannot enter (queries.hpp:553-564).
                 // A list is first only positioned: its block is decoded if some candidate could still enter with the
@@ -1284,13 +1297,13 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                         if (ballot(t0) | ballot(t1)) {
                             ensure_docs(x);
                             uint32_t q0, q1;
-                            const bool f0 = member_bsearch(L.docs[x], c0, t0, q0);
-                            const bool f1 = member_bsearch(L.docs[x], c1, t1, q1);
+                            const bool f0 = member_bsearch((Ldocs + 128u * x), c0, t0, q0);
+                            const bool f1 = member_bsearch((Ldocs + 128u * x), c1, t1, q1);
                             if (ballot(f0) | ballot(f1)) {
                                 if (!cx.m(x, M_FDEC)) cx.decode_freqs(x);
                                 const float w = qw(x);
-                                if (f0) a0 += fx.of(w * doc_term_weight(L.freqs[x][q0], nl0));
-                                if (f1) a1 += fx.of(w * doc_term_weight(L.freqs[x][q1], nl1));
+                                if (f0) a0 += fx.of(w * doc_term_weight((Lfreqs + 128u * x)[q0], nl0));
+                                if (f1) a1 += fx.of(w * doc_term_weight((Lfreqs + 128u * x)[q1], nl1));
                             }
                         }
                         s0 = s0 && !(w0 && !t0); // cannot enter even with this block's best posting
@@ -1533,6 +1546,7 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
 #if defined(DS2I_TU_TMAX) && DS2I_TU_TMAX > 0
 {
     dim3 g(grid), b(64);
+    const size_t dyn = 1024u * (size_t)a.dyn_lists; // union kernels: docs + freqs of dyn_lists list slots
     switch (op) {
     // the conjunctive kernels are specialised for block_optpfor (the benchmark codec), the freq_index family and
     // block_mixed (configs[4]; its three block types stay a run-time switch, QMX drops out); block_varint /
@@ -1563,19 +1577,19 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
         break;
     // the ranked disjunctive operators get the same two codec specialisations (BASELINE configs[3] runs them on
     // block_optpfor); or / or_freq and the reference-order conjunctions stay on the runtime-dispatch instantiation
-    case OP_OR: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 1>), g, b, 0, s, a); break;
-    case OP_OR_FREQ: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 2>), g, b, 0, s, a); break;
+    case OP_OR: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 1>), g, b, dyn, s, a); break;
+    case OP_OR_FREQ: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 2>), g, b, dyn, s, a); break;
     case 0x100 | OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
     case 0x100 | OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
     // wand / maxscore / ranked_or: the block-synchronous disjunctive kernel (identical results by definition)
     case OP_WAND:
     case OP_MAXSCORE:
     case OP_RANKED_OR:
-        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
-        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
-        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, 0, s, a);
-        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_MIXED>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, 0, s, a);
+        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, dyn, s, a);
+        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, dyn, s, a);
+        else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, dyn, s, a);
+        else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_MIXED>), g, b, dyn, s, a);
+        else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, dyn, s, a);
         break;
     // reference-order (one document per step) traversals of the same operators: op | OP_REFERENCE_ORDER
     case 0x100 | OP_WAND: hipLaunchKernelGGL((k_daat<OP_WAND, TMAX>), g, b, 0, s, a); break;
