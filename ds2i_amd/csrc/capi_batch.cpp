@@ -328,13 +328,16 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         static const uint32_t dyn_group = dg ? (uint32_t)std::atoi(dg) : 2u;
         const uint32_t cls_lists = c == 0 ? 2u : c == 1 ? 4u : c == 2 ? 8u : 16u;
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
-        if (!union_kernel || c < 2 || dyn_group == 0) {
+        static const char* dm = std::getenv("DS2I_DYN_MINCLS");
+        static const int dyn_mincls = dm ? std::atoi(dm) : 2;
+        if (!union_kernel || c < dyn_mincls || dyn_group == 0) {
             b->sub[c].push_back({0u, b->ncls[c], cls_lists});
             continue;
         }
         auto lists_of = [&](uint32_t uid) {
             const uint32_t q = b->units[uid].q, n = qoff[q + 1] - qoff[q];
-            return std::min(cls_lists, (n + dyn_group - 1) / dyn_group * dyn_group);
+            const uint32_t g = c == 1 ? 1u : dyn_group; // (3- and 4-list queries: exact)
+            return std::min(cls_lists, (n + g - 1) / g * g);
         };
         std::stable_sort(b->order[c].begin(), b->order[c].end(), [&](uint32_t x, uint32_t y) { return lists_of(x) > lists_of(y); });
         for (uint32_t i = 0; i < b->ncls[c];) {
