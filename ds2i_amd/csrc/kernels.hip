@@ -26,12 +26,14 @@ using namespace ds2i_dev;
 
 namespace {
 
-template <int TMAX, bool META_IN_LDS = true, bool WITH_POS = true>
+template <int TMAX, bool META_IN_LDS = true, bool WITH_POS = true, bool WITH_S16 = true>
 struct Lds {
     uint32_t docs[TMAX][128];
     uint32_t freqs[TMAX][128];
     uint32_t meta[META_IN_LDS ? TMAX : 1][META_IN_LDS ? M_WORDS : 1];
-    uint32_t exc[EXC_LDS_DW]; // + the Simple16 field table (device_codecs.hpp)
+    // + the Simple16 field table (device_codecs.hpp); kernels compiled for the Elias-Fano layouts never read it and leave
+    // it out: 928 B per wave, which takes the 3-4-list ranked kernel from 21 to 24 resident workgroups per CU
+    uint32_t exc[WITH_S16 ? EXC_LDS_DW : EXC_DW];
     uint32_t st[STAGE_DW];
     uint8_t pos[WITH_POS ? TMAX : 1][WITH_POS ? 128 : 4]; // match position of candidate c in list i (and_freq; row 0
                             // unused by the conjunctive kernel and reused as ord/ub by the daat kernel)
@@ -49,7 +51,7 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a, uint32_
     c.freqs = freqs;
     bind_meta(c.meta, &L.meta[0][0]);
     c.exc = L.exc;
-    s16_table_init(L.exc);
+    if constexpr (CODEC_T != CODEC_PEF) s16_table_init(L.exc);
     c.win.st = L.st;
     c.win.gbase = a.arena;
     c.win.nbytes = 0;
@@ -188,8 +190,8 @@ static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 // current block (-1 = the posting was dropped by the freq-only bound and its norm_len never fetched) and its list-0 term
 // score; ranked_and has no use for the match positions (it scores progressively). 5540 B for <=2 lists: 29 waves per
 // CU fit, 24 (6 per SIMD) are used.
-template <int TMAX, bool META_IN_LDS, bool RANKED>
-struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED> {
+template <int TMAX, bool META_IN_LDS, bool RANKED, bool WITH_S16 = true>
+struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED, WITH_S16> {
     float nl[RANKED ? 128 : 1];
     float part0[RANKED ? 128 : 1]; // list-0 term score of each posting of the block (-inf = dropped): read every round
 };
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
-    __shared__ LdsConj<TMAX, !REG, RANKED> L;
+    __shared__ LdsConj<TMAX, !REG, RANKED, CODEC_T != CODEC_PEF> L;
     const uint32_t lane = lane_id();
     CtxT<CODEC_T, META, STATS> cx = make_ctx<CODEC_T, META, STATS>(L, a);
     // ranked_and only: per-block max doc_term_weight table (null = no pruning). Three levels, all exact (the bounds
