@@ -74,8 +74,12 @@ struct NullCounter {
     DS2I_DEV operator unsigned long long() const { return 0; }
 };
 
-template <int CODEC_T, class META = MetaLds, bool STATS = true>
+// SHARE_F: the lists after list 0 decode their freqs into ONE shared buffer (slot 1) instead of one each; `fowner` says
+// whose block it holds. For the ranked conjunction, which uses a later list's freqs right where it decodes them: its
+// residency is capped by LDS, and 512 B per list beyond the second buys workgroups (kernels.hip, LdsConj).
+template <int CODEC_T, class META = MetaLds, bool STATS = true, bool SHARE_F = false>
 struct CtxT {
+    uint32_t fowner = 0; // SHARE_F: the list (>= 1) whose freqs are in the shared buffer (wave-uniform)
     uint32_t* docs;  // [TMAX][128]
     uint32_t* freqs; // [TMAX][128]
     META meta;       // [TMAX][M_WORDS]
@@ -98,7 +102,8 @@ struct CtxT {
     unsigned long long s_phase[PH_COUNT];
 
     DS2I_DEV uint32_t* D(uint32_t s) const { return docs + 128 * s; }
-    DS2I_DEV uint32_t* F(uint32_t s) const { return freqs + 128 * s; }
+    DS2I_DEV uint32_t* F(uint32_t s) const { return freqs + 128 * (SHARE_F ? (s ? 1u : 0u) : s); }
+    DS2I_DEV bool freqs_ready(uint32_t s) const { return m(s, M_FDEC) && (!SHARE_F || s == 0 || fowner == s); }
     DS2I_DEV uint32_t m(uint32_t s, int f) const { return meta.get(s, f); }
     DS2I_DEV void setm(uint32_t s, int f, uint32_t v) { meta.set(s, f, v); } // v must be wave-uniform
     DS2I_DEV const uint8_t* ptr(uint32_t s, int lo) const {
@@ -178,6 +183,7 @@ struct CtxT {
         dst[lane] = s0 - p0;
         dst[lane + 64] = s1 - p1;
         setm(s, M_FDEC, 1);
+        if (SHARE_F && s) fowner = s;
         wave_sync();
         ++s_freqs_blocks;
         s_bytes += ((bcast(ev, PC_SPANS) >> 16) + cnt * ((packed >> 18) & 63u) + 7) >> 3;
@@ -338,6 +344,7 @@ struct CtxT {
         dst[lane] = v0 + 1u;
         dst[lane + 64] = v1 + 1u;
         setm(s, M_FDEC, 1);
+        if (SHARE_F && s) fowner = s;
         wave_sync();
         ++s_freqs_blocks;
         if (STATS && block_profile && lane == 0) atomicAdd(block_profile + 2ull * (m(s, M_PBASE) + m(s, M_CUR)) + 1, 1u);
@@ -614,7 +621,7 @@ struct CtxT {
 
     // ---- freq (block_posting_list.hpp:165-171)
     DS2I_DEV uint32_t freq(uint32_t s) {
-        if (!m(s, M_FDEC)) decode_freqs(s);
+        if (!freqs_ready(s)) decode_freqs(s);
         return uniform(F(s)[m(s, M_POS)]);
     }
 };

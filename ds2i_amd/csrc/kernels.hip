@@ -26,10 +26,10 @@ using namespace ds2i_dev;
 
 namespace {
 
-template <int TMAX, bool META_IN_LDS = true, bool WITH_POS = true, bool WITH_S16 = true>
+template <int TMAX, bool META_IN_LDS = true, bool WITH_POS = true, bool WITH_S16 = true, int NF = TMAX>
 struct Lds {
     uint32_t docs[TMAX][128];
-    uint32_t freqs[TMAX][128];
+    uint32_t freqs[NF][128]; // NF < TMAX: the lists after list 0 share slot 1 (CtxT SHARE_F)
     uint32_t meta[META_IN_LDS ? TMAX : 1][META_IN_LDS ? M_WORDS : 1];
     // + the Simple16 field table (device_codecs.hpp); kernels compiled for the Elias-Fano layouts never read it and leave
     // it out: 928 B per wave, which takes the 3-4-list ranked kernel from 21 to 24 resident workgroups per CU
@@ -44,9 +44,9 @@ struct Lds {
 DS2I_DEV void bind_meta(MetaLds& m, uint32_t* lds_meta) { m.p = lds_meta; }
 template <int T> DS2I_DEV void bind_meta(MetaReg<T>&, uint32_t*) {}
 
-template <int CODEC_T, class META, bool STATS = true, class LDS>
-DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a, uint32_t* docs, uint32_t* freqs) {
-    CtxT<CODEC_T, META, STATS> c;
+template <int CODEC_T, class META, bool STATS = true, bool SHARE_F = false, class LDS>
+DS2I_DEV CtxT<CODEC_T, META, STATS, SHARE_F> make_ctx(LDS& L, const BatchArgs& a, uint32_t* docs, uint32_t* freqs) {
+    CtxT<CODEC_T, META, STATS, SHARE_F> c;
     c.docs = docs;
     c.freqs = freqs;
     bind_meta(c.meta, &L.meta[0][0]);
@@ -65,9 +65,9 @@ DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a, uint32_
     c.init_stats();
     return c;
 }
-template <int CODEC_T, class META, bool STATS = true, class LDS>
-DS2I_DEV CtxT<CODEC_T, META, STATS> make_ctx(LDS& L, const BatchArgs& a) {
-    return make_ctx<CODEC_T, META, STATS>(L, a, &L.docs[0][0], &L.freqs[0][0]);
+template <int CODEC_T, class META, bool STATS = true, bool SHARE_F = false, class LDS>
+DS2I_DEV CtxT<CODEC_T, META, STATS, SHARE_F> make_ctx(LDS& L, const BatchArgs& a) {
+    return make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a, &L.docs[0][0], &L.freqs[0][0]);
 }
 
 template <int NK>
@@ -191,7 +191,7 @@ static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 // score; ranked_and has no use for the match positions (it scores progressively). 5540 B for <=2 lists: 29 waves per
 // CU fit, 24 (6 per SIMD) are used.
 template <int TMAX, bool META_IN_LDS, bool RANKED, bool WITH_S16 = true>
-struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED, WITH_S16> {
+struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED, WITH_S16, (RANKED && TMAX > 2) ? 2 : TMAX> {
     float nl[RANKED ? 128 : 1];
     float part0[RANKED ? 128 : 1]; // list-0 term score of each posting of the block (-inf = dropped): read every round
 };
@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
     __shared__ LdsConj<TMAX, !REG, RANKED, CODEC_T != CODEC_PEF> L;
     const uint32_t lane = lane_id();
-    CtxT<CODEC_T, META, STATS> cx = make_ctx<CODEC_T, META, STATS>(L, a);
+    // ranked_and with 3+ lists: one freqs buffer for list 0, one shared by the others (each is used where it is decoded)
+    constexpr bool SHARE_F = RANKED && TMAX > 2;
+    CtxT<CODEC_T, META, STATS, SHARE_F> cx = make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a);
     // ranked_and only: per-block max doc_term_weight table (null = no pruning). Three levels, all exact (the bounds
     // are true upper bounds of the float32 score and topk_queue::insert is strict, queries.hpp:157-172):
     //   * blocks of list 0 whose bound cannot enter the heap are skipped without being decoded (skip_list0);
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (sf || nt == 1) {
                     const uint32_t cur0 = cx.m(0, M_CUR);
                     if (part_blk != cur0) { // once per block of list 0: its freqs, the norm_lens and the list-0 term scores
-                        if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
+                        if (!cx.freqs_ready(0)) cx.decode_freqs(0);
                         PT_BEGIN(cx);
                         const float qw0 = __uint_as_float(cx.m(0, M_QW));
                         bool v0 = c0 != 0xFFFFFFFFu, v1 = c1 != 0xFFFFFFFFu;
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if constexpr (RANKED) { // members take list i's term score at once
                     if (ballot(al0) | ballot(al1)) {
                         if (!have_p) { // (only possible at list 1) list-0 term scores of the surviving candidates
-                            if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
+                            if (!cx.freqs_ready(0)) cx.decode_freqs(0);
                             const float qw0 = __uint_as_float(cx.m(0, M_QW));
                             const float n0 = al0 ? a.norm_lens[c0] : 0.f, n1 = al1 ? a.norm_lens[c1] : 0.f;
                             L.nl[lane] = n0;
@@ -452,9 +454,9 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             cx.s_bytes += 4ull * nv;
                             cx.s_scored += nv;
                         }
-                        if (!cx.m(i, M_FDEC)) cx.decode_freqs(i);
+                        if (!cx.freqs_ready(i)) cx.decode_freqs(i);
                         const float qw = __uint_as_float(cx.m(i, M_QW));
-                        const uint32_t* f = L.freqs[i];
+                        const uint32_t* f = cx.F(i);
                         if (al0) pa0 = pa0 + qw * doc_term_weight(f[p0], L.nl[lane]);
                         if (al1) pa1 = pa1 + qw * doc_term_weight(f[p1], L.nl[lane + 64]);
                         if (sf) { // who cannot reach the heap any more drops out before the next list is touched
