@@ -398,6 +398,13 @@ def main():
                        "launches_timed": cls_ms[dom][1], "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
                        "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
                        "queries_in_kernel": cls_stats[dom][1], "per_class": per_class}
+    # the class kernels of a batch (and of the neighbouring batches) overlap, so one kernel's launch duration stretches
+    # when another class is given more of the GPU; the whole step is the figure that cannot: every class's algorithmic
+    # bytes over the wall time of a step
+    if out.get("a_skip_bytes_per_step"):
+        out["roofline"]["step_algorithmic_bytes"] = int(out["a_skip_bytes_per_step"])
+        out["roofline"]["step_achieved"] = out["a_skip_bytes_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9
+        out["roofline"]["step_frac"] = out["roofline"]["step_achieved"] / HBM_PEAK_GBS
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
     if dist is not None:
