@@ -818,6 +818,20 @@ def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
     return json.loads(lines[0])
 
 
+@pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_BMW_PRUNE=1", "DS2I_NO_SKIPTAB=1", "DS2I_DYN_GROUP=0", "DS2I_DYN_GROUP=1"])
+def test_alternative_paths_give_the_same_results(built_lib, knob):
+    """The library reads its A/B knobs once per process, so each alternative path -- no block-max table, table present but
+    unused, no interleaved skip table, union kernels without / with exact dynamic-LDS groups -- is driven through one
+    fuzz collection (every codec, k, operator; oracle-checked) in a process of its own."""
+    import os, subprocess, sys
+    env = dict(os.environ)
+    k, v = knob.split("=")
+    env[k] = v
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "fuzz and 2]"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_bench_two_ranks_on_one_device(built_lib):
     """The N>1 path of bench.py on a single-GPU box: two ranks (gloo rendezvous, both on cuda:0), each with a full index
     replica -- weak (every rank its own batches) and strong (one stream of batches cut with query_slice, results
