@@ -1551,6 +1551,7 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
 {
     dim3 g(grid), b(64);
     const size_t dyn = 1024u * (size_t)a.dyn_lists; // union kernels: docs + freqs of dyn_lists list slots
+    const size_t dyn_docs = 512u * (size_t)a.dyn_lists; // or_query never reads a freq: docs only
     switch (op) {
     // the conjunctive kernels are specialised for block_optpfor (the benchmark codec), the freq_index family and
     // block_mixed (configs[4]; its three block types stay a run-time switch, QMX drops out); block_varint /
@@ -1581,7 +1582,7 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
         break;
     // the ranked disjunctive operators get the same two codec specialisations (BASELINE configs[3] runs them on
     // block_optpfor); or / or_freq and the reference-order conjunctions stay on the runtime-dispatch instantiation
-    case OP_OR: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 1>), g, b, dyn, s, a); break;
+    case OP_OR: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 1>), g, b, dyn_docs, s, a); break;
     case OP_OR_FREQ: hipLaunchKernelGGL((k_disjunctive<TMAX, -1, true, 2>), g, b, dyn, s, a); break;
     case 0x100 | OP_OR: hipLaunchKernelGGL((k_daat<OP_OR, TMAX>), g, b, 0, s, a); break;
     case 0x100 | OP_OR_FREQ: hipLaunchKernelGGL((k_daat<OP_OR_FREQ, TMAX>), g, b, 0, s, a); break;
