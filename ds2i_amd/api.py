@@ -121,6 +121,7 @@ def lib():
         L.ds2i_wand_free.restype = None
         L.ds2i_encode_block.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.ds2i_encode_vbyte.argtypes = [C.c_uint32, C.POINTER(vp)]
+        L.ds2i_write_sequence.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint64, vp, C.POINTER(vp), u64p]
         L.ds2i_encode_posting_list.argtypes = [C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]
         L.ds2i_opt_list_directory.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(vp), u64p]
         L.ds2i_freq_list_directory.argtypes = [C.c_int, vp, C.c_size_t, C.c_uint32, C.POINTER(vp), C.POINTER(vp), u64p]
@@ -172,6 +173,26 @@ def encode_vbyte(value):
     h = C.c_void_p()
     _check(lib().ds2i_encode_vbyte(value, C.byref(h)))
     return _take_blob(h)
+
+
+SEQUENCE_KINDS = ("elias_fano", "ranked_bitvector", "indexed", "strict", "partitioned_indexed", "partitioned_strict",
+                  "uniform_indexed", "uniform_strict")
+
+
+def write_sequence(seq_kind, values, universe, params=None):
+    """One sequence of the Elias-Fano family written into a fresh bit string (ds2i_write_sequence).
+    Returns (u64 words, nbits). params = (ef_log_sampling0, ef_log_sampling1, rb_log_rank1_sampling,
+    rb_log_sampling1, log_partition_size) or None for global_parameters' defaults."""
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    h = C.c_void_p()
+    nbits = C.c_uint64()
+    pp = None
+    if params is not None:
+        pp = np.asarray(params, dtype=np.uint8)
+        assert pp.shape == (5,)
+    _check(lib().ds2i_write_sequence(SEQUENCE_KINDS.index(seq_kind), _ptr(v), len(v), int(universe),
+                                     _ptr(pp) if pp is not None else None, C.byref(h), C.byref(nbits)))
+    return np.frombuffer(_take_blob(h), dtype=np.uint64), int(nbits.value)
 
 
 def encode_posting_list(codec, docs, freqs):

@@ -128,6 +128,39 @@ int ds2i_bm25_doc_term_weight(const uint64_t* freq, const float* norm_len, uint6
     return 0;
 }
 
+int ds2i_write_sequence(int seq_kind, const uint64_t* values, uint64_t n, uint64_t universe, const uint8_t params[5],
+                        ds2i_blob** bits, uint64_t* nbits) {
+    if (!values || !bits || !nbits || !n) return ds2i_set_error(-1, "ds2i_write_sequence: bad argument");
+    DS2I_TRY
+    ds2i_host::global_parameters gp;
+    if (params) {
+        gp.ef_log_sampling0 = params[0];
+        gp.ef_log_sampling1 = params[1];
+        gp.rb_log_rank1_sampling = params[2];
+        gp.rb_log_sampling1 = params[3];
+        gp.log_partition_size = params[4];
+    }
+    ds2i_host::bitvec_builder bvb;
+    switch (seq_kind) {
+    case DS2I_SEQ_ELIAS_FANO: ds2i_host::ef_write(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_RANKED_BITVECTOR: ds2i_host::rb_write(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_INDEXED: ds2i_host::seq_write<false>(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_STRICT: ds2i_host::seq_write<true>(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_PARTITIONED_INDEXED: ds2i_host::partitioned_write<false>(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_PARTITIONED_STRICT: ds2i_host::partitioned_write<true>(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_UNIFORM_INDEXED: ds2i_host::uniform_write<false>(bvb, values, universe, n, gp); break;
+    case DS2I_SEQ_UNIFORM_STRICT: ds2i_host::uniform_write<true>(bvb, values, universe, n, gp); break;
+    default: return ds2i_set_error(-1, "ds2i_write_sequence: unknown sequence kind");
+    }
+    auto* blob = new ds2i_blob;
+    const uint8_t* w = (const uint8_t*)bvb.words().data();
+    blob->data.assign(w, w + 8 * bvb.words().size());
+    *nbits = bvb.size();
+    *bits = blob;
+    return 0;
+    DS2I_CATCH
+}
+
 int ds2i_encode_vbyte(uint32_t value, ds2i_blob** out) {
     if (!out) return ds2i_set_error(-1, "ds2i_encode_vbyte: null argument");
     auto* blob = new ds2i_blob;

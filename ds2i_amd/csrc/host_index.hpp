@@ -74,36 +74,49 @@ struct ef_offsets {
     }
 };
 
+// Sampled positions of a finished 0/1 array, straight from their definition (SURVEY.md Appendix A6, and what
+// test_compact_elias_fano.cpp:45-80 / test_compact_ranked_bitvector.cpp:36-68 check by a direct scan): walking the
+// `len` bits at `first`, on_one(pos, ones_before) is called for every 1 and on_zero(pos, zeros_before) for every 0.
+template <class OnOne, class OnZero>
+inline void scan_bits(bitvec_builder const& bv, uint64_t first, uint64_t len, OnOne on_one, OnZero on_zero) {
+    auto const& w = bv.words();
+    uint64_t ones = 0;
+    for (uint64_t pos = 0; pos < len; ++pos) {
+        const uint64_t at = first + pos;
+        if ((w[at >> 6] >> (at & 63)) & 1) on_one(pos, ones++);
+        else on_zero(pos, pos - ones);
+    }
+}
+
+// compact_elias_fano image of a sorted sequence (layout: `ef_offsets`): pointers0 | pointers1 | high bits | low bits.
+// Value i sets high bit (v_i >> l) + i + 1 and stores its l low bits at slot i. The two pointer arrays are filled in a
+// second pass over the finished high bits from what they MEAN: pointers1[k-1] = position of the 1 with k * 2^s1 ones
+// before it, pointers0[k-1] = position of the 0 with k * 2^s0 zeros before it (k >= 1; slots without such a bit stay 0).
 template <class It>
 inline void ef_write(bitvec_builder& bvb, It begin, uint64_t universe, uint64_t n, global_parameters const& params) {
-    const uint64_t base = bvb.size();
-    ef_offsets of(base, universe, n, params);
-    bvb.zero_extend(of.end - base);
-    const uint64_t sample1_mask = (uint64_t(1) << of.log_sampling1) - 1;
-    auto set_ptr0s = [&](uint64_t b, uint64_t e, uint64_t rank_end) {
-        uint64_t bz = b - rank_end, ez = e - rank_end;
-        for (uint64_t p0 = ceil_div(bz, uint64_t(1) << of.log_sampling0); (p0 << of.log_sampling0) < ez; ++p0) {
-            if (!p0) continue;
-            bvb.set_bits(of.pointers0_offset + (p0 - 1) * of.pointer_size, (p0 << of.log_sampling0) + rank_end,
-                         (unsigned)of.pointer_size);
-        }
-    };
-    uint64_t last = 0, last_high = 0;
+    const ef_offsets of(bvb.size(), universe, n, params);
+    bvb.zero_extend(of.end - of.pointers0_offset);
+    uint64_t prev = 0;
     It it = begin;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint64_t v = *it++;
-        if (i && v < last) throw std::runtime_error("Sequence is not sorted");
-        uint64_t high = (v >> of.lower_bits) + i + 1;
-        bvb.set(of.higher_bits_offset + high, 1);
+    for (uint64_t i = 0; i < n; ++i, ++it) {
+        const uint64_t v = *it;
+        if (v < prev) throw std::runtime_error("Sequence is not sorted");
+        prev = v;
+        bvb.set(of.higher_bits_offset + (v >> of.lower_bits) + i + 1, 1);
         bvb.set_bits(of.lower_bits_offset + i * of.lower_bits, v & of.mask, (unsigned)of.lower_bits);
-        if (i && (i & sample1_mask) == 0)
-            bvb.set_bits(of.pointers1_offset + ((i >> of.log_sampling1) - 1) * of.pointer_size, high,
-                         (unsigned)of.pointer_size);
-        set_ptr0s(last_high + 1, high, i);
-        last_high = high;
-        last = v;
     }
-    set_ptr0s(last_high + 1, of.higher_bits_length, n);
+    if (!of.pointers0 && !of.pointers1) return;
+    const uint64_t every1 = (uint64_t(1) << of.log_sampling1) - 1;
+    const uint64_t every0 = of.log_sampling0 < 64 ? (uint64_t(1) << of.log_sampling0) - 1 : ~uint64_t(0);
+    scan_bits(bvb, of.higher_bits_offset, of.higher_bits_length,
+              [&](uint64_t pos, uint64_t ones) {
+                  if (ones && !(ones & every1))
+                      bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
+              },
+              [&](uint64_t pos, uint64_t zeros) {
+                  if (zeros && !(zeros & every0))
+                      bvb.set_bits(of.pointers0_offset + ((zeros >> of.log_sampling0) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
+              });
 }
 
 // sequential decode of all n values (upload-time flattening of m_endpoints, a12)

@@ -63,32 +63,38 @@ struct rb_offsets {
 inline uint64_t rb_bitsize(global_parameters const& p, uint64_t u, uint64_t n) { return rb_offsets(0, u, n, p).end; }
 inline uint64_t ef_bitsize(global_parameters const& p, uint64_t u, uint64_t n) { return ef_offsets(0, u, n, p).end; }
 
+// compact_ranked_bitvector image (layout: `rb_offsets`): rank1_samples | pointers1 | the `universe`-bit characteristic
+// vector. As for Elias-Fano the auxiliary arrays are written from their meaning, in a second pass over the finished
+// vector: rank1_samples[k-1] = number of ones before position k * 2^r (k >= 1), pointers1[k-1] = position of the one
+// with k * 2^s1 ones before it.
 template <class It>
 inline void rb_write(bitvec_builder& bvb, It begin, uint64_t universe, uint64_t n, global_parameters const& params) {
-    const uint64_t base = bvb.size();
-    rb_offsets of(base, universe, n, params);
-    bvb.zero_extend(of.end - base);
-    auto set_rank1_samples = [&](uint64_t b, uint64_t e, uint64_t rank) {
-        if (of.log_rank1_sampling >= 64) return;
-        for (uint64_t sample = ceil_div(b, uint64_t(1) << of.log_rank1_sampling); (sample << of.log_rank1_sampling) < e; ++sample) {
-            if (!sample) continue;
-            bvb.set_bits(of.rank1_samples_offset + (sample - 1) * of.rank1_sample_size, rank, (unsigned)of.rank1_sample_size);
-        }
-    };
-    const uint64_t sample1_mask = (uint64_t(1) << of.log_sampling1) - 1;
-    uint64_t last = 0;
+    const rb_offsets of(bvb.size(), universe, n, params);
+    bvb.zero_extend(of.end - of.rank1_samples_offset);
+    uint64_t prev = 0;
     It it = begin;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint64_t v = *it++;
-        if (i && v == last) throw std::runtime_error("Duplicate element");
-        if (i && v < last) throw std::runtime_error("Sequence is not sorted");
+    for (uint64_t i = 0; i < n; ++i, ++it) {
+        const uint64_t v = *it;
+        if (i && v == prev) throw std::runtime_error("Duplicate element");
+        if (v < prev) throw std::runtime_error("Sequence is not sorted");
+        prev = v;
         bvb.set(of.bits_offset + v, 1);
-        if (i && (i & sample1_mask) == 0)
-            bvb.set_bits(of.pointers1_offset + ((i >> of.log_sampling1) - 1) * of.pointer_size, v, (unsigned)of.pointer_size);
-        set_rank1_samples(last + 1, v + 1, i);
-        last = v;
     }
-    set_rank1_samples(last + 1, universe, n);
+    if (!of.rank1_samples && !of.pointers1) return;
+    const uint64_t every1 = (uint64_t(1) << of.log_sampling1) - 1;
+    const uint64_t every_pos = of.log_rank1_sampling < 64 ? (uint64_t(1) << of.log_rank1_sampling) - 1 : ~uint64_t(0);
+    auto sample_rank = [&](uint64_t pos, uint64_t ones_before) {
+        if (pos && !(pos & every_pos))
+            bvb.set_bits(of.rank1_samples_offset + ((pos >> of.log_rank1_sampling) - 1) * of.rank1_sample_size, ones_before,
+                         (unsigned)of.rank1_sample_size);
+    };
+    scan_bits(bvb, of.bits_offset, universe,
+              [&](uint64_t pos, uint64_t ones) {
+                  sample_rank(pos, ones);
+                  if (ones && !(ones & every1))
+                      bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
+              },
+              [&](uint64_t pos, uint64_t zeros) { sample_rank(pos, pos - zeros); });
 }
 
 // ---------------------------------------------------------------- indexed / strict sequences
@@ -192,94 +198,73 @@ inline std::vector<uint32_t> optimal_partition(const uint64_t* seq, uint64_t uni
     return ends;
 }
 
-// ---------------------------------------------------------------- partitioned sequence
+// ---------------------------------------------------------------- partitioned sequences
+// On-disk layout shared by partitioned_sequence (partitioned_sequence.hpp:131-178 reads it) and
+// uniform_partitioned_sequence (uniform_partitioned_sequence.hpp:120-160), SURVEY.md Appendix A6:
+//
+//   gamma+(P)                                   P = number of partitions
+//   P == 1:  first value in ceil_log2(universe) bits | n > 1: delta(span), span = last - first, or 0 when the run
+//            reaches universe - 1 | base sequence of (v - first) over span + 1
+//   P  > 1:  gamma(endpoint_bits) | [EF of the P-1 inner partition END INDEXES over universe n -- optimal partitions
+//            only; fixed-size partitions need none] | EF of {first value, last value of partition 0, .., of partition
+//            P-1} over `universe` | P-1 end offsets (bits, relative to the first partition's image) of
+//            endpoint_bits each | the partitions' base sequences back to back; partition p stores v - (last value of
+//            partition p-1) - 1 (partition 0: v - first value) over (its last stored value + 1)
+//
+// `ends` = the exclusive end index of every partition (ends.back() == n).
+template <bool STRICT>
+inline void write_partition_table(bitvec_builder& out, const uint64_t* seq, uint64_t universe, uint64_t n,
+                                  std::vector<uint32_t> const& ends, bool with_sizes, global_parameters const& params) {
+    const uint64_t P = ends.size();
+    write_gamma_nonzero(out, P);
+    std::vector<uint64_t> rel;
+    // stores seq[from, to) relative to `origin` as one base sequence appended to `dst`
+    auto emit_partition = [&](bitvec_builder& dst, uint64_t from, uint64_t to, uint64_t origin) {
+        rel.resize(to - from);
+        for (uint64_t i = from; i < to; ++i) rel[i - from] = seq[i] - origin;
+        seq_write<STRICT>(dst, rel.data(), rel.back() + 1, to - from, params);
+    };
+    if (P == 1) {
+        const uint64_t first = seq[0], span = seq[n - 1] - first;
+        out.append_bits(first, (unsigned)ceil_log2(universe));
+        if (n > 1) write_delta(out, seq[n - 1] + 1 == universe ? 0 : span);
+        emit_partition(out, 0, n, first);
+        return;
+    }
+    bitvec_builder body;
+    std::vector<uint64_t> bounds(1, seq[0]), offsets_after, inner_ends(ends.begin(), ends.end());
+    for (uint64_t p = 0, from = 0; p < P; from = ends[p++]) {
+        emit_partition(body, from, ends[p], p ? seq[from - 1] + 1 : seq[0]);
+        offsets_after.push_back(body.size());
+        bounds.push_back(seq[ends[p] - 1]);
+    }
+    const unsigned endpoint_bits = (unsigned)ceil_log2(body.size() + 1);
+    write_gamma(out, endpoint_bits);
+    bitvec_builder table;
+    if (with_sizes) ef_write(table, inner_ends.begin(), n, P - 1, params);
+    ef_write(table, bounds.begin(), universe, P + 1, params);
+    bv_append(out, table);
+    for (uint64_t p = 0; p + 1 < P; ++p) out.append_bits(offsets_after[p], endpoint_bits);
+    bv_append(out, body);
+}
+
+// partitioned_sequence: end points from the (1+eps)-approximate shortest path (optimal_partition above)
 template <bool STRICT>
 inline void partitioned_write(bitvec_builder& bvb, const uint64_t* seq, uint64_t universe, uint64_t n,
                               global_parameters const& params, partition_config const& conf = partition_config()) {
     auto cost_fun = [&](uint64_t u, uint64_t m) { return seq_bitsize<STRICT>(params, u, m) + conf.fix_cost; };
-    std::vector<uint32_t> part = optimal_partition(seq, universe, n, cost_fun, conf.eps1, conf.eps2);
-    const uint64_t partitions = part.size();
-    write_gamma_nonzero(bvb, partitions);
-    std::vector<uint64_t> cur;
-    if (partitions == 1) {
-        const uint64_t cur_base = seq[0];
-        cur.resize(n);
-        for (uint64_t i = 0; i < n; ++i) cur[i] = seq[i] - cur_base;
-        bvb.append_bits(cur_base, (unsigned)ceil_log2(universe));
-        if (n > 1) {
-            if (cur_base + cur.back() + 1 == universe) write_delta(bvb, 0);
-            else write_delta(bvb, cur.back());
-        }
-        seq_write<STRICT>(bvb, cur.data(), cur.back() + 1, n, params);
-        return;
-    }
-    bitvec_builder bv_sequences;
-    std::vector<uint64_t> endpoints, upper_bounds, sizes(part.begin(), part.end());
-    uint64_t cur_i = 0, cur_base = seq[0];
-    upper_bounds.push_back(cur_base);
-    for (uint64_t p = 0; p < partitions; ++p) {
-        cur.clear();
-        uint64_t value = 0;
-        for (; cur_i < part[p]; ++cur_i) {
-            value = seq[cur_i];
-            cur.push_back(value - cur_base);
-        }
-        seq_write<STRICT>(bv_sequences, cur.data(), cur.back() + 1, cur.size(), params);
-        endpoints.push_back(bv_sequences.size());
-        upper_bounds.push_back(value);
-        cur_base = value + 1;
-    }
-    bitvec_builder bv_sizes, bv_ub;
-    ef_write(bv_sizes, sizes.begin(), n, partitions - 1, params);
-    ef_write(bv_ub, upper_bounds.begin(), universe, partitions + 1, params);
-    const uint64_t endpoint_bits = ceil_log2(bv_sequences.size() + 1);
-    write_gamma(bvb, endpoint_bits);
-    bv_append(bvb, bv_sizes);
-    bv_append(bvb, bv_ub);
-    for (uint64_t p = 0; p + 1 < endpoints.size(); ++p) bvb.append_bits(endpoints[p], (unsigned)endpoint_bits);
-    bv_append(bvb, bv_sequences);
+    write_partition_table<STRICT>(bvb, seq, universe, n, optimal_partition(seq, universe, n, cost_fun, conf.eps1, conf.eps2),
+                                  true, params);
 }
 
-// ---------------------------------------------------------------- uniform_partitioned_sequence (uniform_partitioned_sequence.hpp:19-111)
-// fixed partitions of 2^log_partition_size elements: no `sizes` sequence, otherwise the partitioned layout
+// uniform_partitioned_sequence: fixed partitions of 2^log_partition_size elements
 template <bool STRICT>
 inline void uniform_write(bitvec_builder& bvb, const uint64_t* seq, uint64_t universe, uint64_t n, global_parameters const& params) {
     const uint64_t psize = uint64_t(1) << params.log_partition_size;
-    const uint64_t partitions = ceil_div(n, psize);
-    write_gamma_nonzero(bvb, partitions);
-    std::vector<uint64_t> cur;
-    if (partitions == 1) {
-        const uint64_t cur_base = seq[0];
-        cur.resize(n);
-        for (uint64_t i = 0; i < n; ++i) cur[i] = seq[i] - cur_base;
-        bvb.append_bits(cur_base, (unsigned)ceil_log2(universe));
-        if (n > 1) {
-            if (cur_base + cur.back() + 1 == universe) write_delta(bvb, 0);
-            else write_delta(bvb, cur.back());
-        }
-        seq_write<STRICT>(bvb, cur.data(), cur.back() + 1, n, params);
-        return;
-    }
-    bitvec_builder bv_sequences;
-    std::vector<uint64_t> endpoints, upper_bounds;
-    uint64_t cur_base = seq[0];
-    upper_bounds.push_back(cur_base);
-    for (uint64_t p = 0; p < partitions; ++p) {
-        const uint64_t lo = p * psize, hi = std::min(n, lo + psize);
-        cur.clear();
-        for (uint64_t i = lo; i < hi; ++i) cur.push_back(seq[i] - cur_base);
-        seq_write<STRICT>(bv_sequences, cur.data(), cur.back() + 1, cur.size(), params);
-        endpoints.push_back(bv_sequences.size());
-        upper_bounds.push_back(seq[hi - 1]);
-        cur_base = seq[hi - 1] + 1;
-    }
-    bitvec_builder bv_ub;
-    ef_write(bv_ub, upper_bounds.begin(), universe, partitions + 1, params);
-    const uint64_t endpoint_bits = ceil_log2(bv_sequences.size() + 1);
-    write_gamma(bvb, endpoint_bits);
-    bv_append(bvb, bv_ub);
-    for (uint64_t p = 0; p + 1 < endpoints.size(); ++p) bvb.append_bits(endpoints[p], (unsigned)endpoint_bits);
-    bv_append(bvb, bv_sequences);
+    std::vector<uint32_t> ends;
+    for (uint64_t e = psize; e < n; e += psize) ends.push_back((uint32_t)e);
+    ends.push_back((uint32_t)n);
+    write_partition_table<STRICT>(bvb, seq, universe, n, ends, false, params);
 }
 
 // The four freq_index instantiations of index_types.hpp:18-32; numbered like enum ds2i_hip_index_kind.

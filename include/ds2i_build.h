@@ -57,6 +57,24 @@ int ds2i_bm25_query_term_weight(const uint64_t* qtf, const uint64_t* df, uint64_
 int ds2i_bm25_doc_term_weight(const uint64_t* freq, const float* norm_len, uint64_t n, float* out);
 int ds2i_encode_posting_list(int codec, uint32_t n, const uint32_t* docs, const uint32_t* freqs, ds2i_blob** out);
 
+/* One sequence of the Elias-Fano family written on its own into a fresh bit string (test hook for the reference's
+ * layout tests test_compact_elias_fano.cpp:45-80, test_compact_ranked_bitvector.cpp:36-68,
+ * test_partitioned_sequence.cpp:13-111, test_uniform_partitioned_sequence.cpp). seq_kind: */
+enum ds2i_sequence_kind {
+    DS2I_SEQ_ELIAS_FANO = 0,       /* compact_elias_fano */
+    DS2I_SEQ_RANKED_BITVECTOR = 1, /* compact_ranked_bitvector (strictly increasing values) */
+    DS2I_SEQ_INDEXED = 2,          /* indexed_sequence: 1 type bit + the cheapest of EF / ranked bitvector / all-ones */
+    DS2I_SEQ_STRICT = 3,           /* strict_sequence */
+    DS2I_SEQ_PARTITIONED_INDEXED = 4, /* partitioned_sequence<indexed_sequence> */
+    DS2I_SEQ_PARTITIONED_STRICT = 5,  /* partitioned_sequence<strict_sequence> */
+    DS2I_SEQ_UNIFORM_INDEXED = 6,     /* uniform_partitioned_sequence<indexed_sequence> */
+    DS2I_SEQ_UNIFORM_STRICT = 7       /* uniform_partitioned_sequence<strict_sequence> */
+};
+/* params = {ef_log_sampling0, ef_log_sampling1, rb_log_rank1_sampling, rb_log_sampling1, log_partition_size}
+ * (global_parameters.hpp:5-31; NULL = defaults). bits = the image as little-endian u64 words, *nbits its length. */
+int ds2i_write_sequence(int seq_kind, const uint64_t* values, uint64_t n, uint64_t universe, const uint8_t params[5],
+                        ds2i_blob** bits, uint64_t* nbits);
+
 /* The chunk directory ds2i_hip_index_open builds for one list of an opt image (inspection / test hook):
  * cmax = u32[nchunks] last doc-id per chunk, chunks = nchunks x 12 dwords (ds2i_amd/csrc/device_pef.hpp),
  * info = {n, docs_bit0, freqs_bit0, docs bit-vector byte offset in the image, freqs bit-vector byte offset} */

@@ -70,6 +70,7 @@ def lib(path=None):
     L.oracle_list_enumerate.restype = C.c_int64
     L.oracle_list_next_geq.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     L.oracle_list_move.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp]
+    L.oracle_sequence_selftest.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp]
     L.oracle_query.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, C.POINTER(Profile)]
     L.oracle_query.restype = C.c_int64
     L.oracle_query_batch.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(Profile)]
@@ -77,6 +78,16 @@ def lib(path=None):
     if path is None:
         _lib = L
     return L
+
+
+def sequence_selftest(kind, words, nbits, universe, seq, params=(9, 8, 9, 8, 7)):
+    """The reference's sequence tests (test_generic_sequence.hpp:28-164, test_partitioned_sequence.cpp:13-44) with the
+    oracle's enumerators reading `words` (u64 bit string). kind = index into ds2i_sequence_kind. Returns 0 or the code of
+    the first failed requirement."""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    v = np.ascontiguousarray(seq, dtype=np.uint64)
+    pp = np.asarray(params, dtype=np.uint8)
+    return int(lib().oracle_sequence_selftest(int(kind), _p(w), w.nbytes, int(nbits), int(universe), _p(v), len(v), _p(pp)))
 
 
 def bm25_doc_term_weight(freq, norm_len):

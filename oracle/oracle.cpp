@@ -1123,6 +1123,19 @@ int oracle_list_move(void* hv, uint64_t term, const uint32_t* positions, uint64_
     } catch (...) { return -1; }
 }
 
+// One stand-alone sequence of the Elias-Fano family (bits = little-endian u64 words) run through the reference's own
+// sequence tests (oracle_pef.hpp: test_generic_sequence.hpp / test_partitioned_sequence.cpp restated) with the oracle's
+// enumerators as readers. Returns 0, or the code of the first failed requirement.
+int oracle_sequence_selftest(int kind, const uint8_t* bits, uint64_t nbytes, uint64_t nbits, uint64_t universe, const uint64_t* seq,
+                             uint64_t n, const uint8_t* params) {
+    oracle::bitvec bv;
+    bv.bytes = bits;
+    bv.nbits = nbits;
+    bv.nbytes = nbytes;
+    oracle::pef_params p{params[0], params[1], params[2], params[3], params[4]};
+    try { return oracle::sequence_selftest(kind, bv, universe, seq, n, p); } catch (...) { return -2; }
+}
+
 // one query; topk holds k floats, matches (optional) holds match_cap doc-ids. Returns the operator's value.
 int64_t oracle_query(void* hv, int op, uint32_t k, const uint32_t* terms, uint32_t nterms, float* topk, uint32_t* topk_len,
                      uint32_t* matches, uint64_t match_cap, uint64_t* freq_sum, oracle_profile* prof) {

@@ -476,8 +476,11 @@ struct base_sequence {
 struct pef_profile { uint64_t partitions_entered = 0, algorithmic_bytes = 0; };
 
 // ---------------------------------------------------------------- partitioned_sequence
+struct partition_construction_test; // test_partitioned_sequence.cpp:13-44 restated (below)
+
 template <bool STRICT>
 class partitioned_enumerator {
+    friend struct partition_construction_test;
 public:
     typedef typename base_sequence<STRICT>::enumerator base_enum;
     partitioned_enumerator() {}
@@ -610,6 +613,7 @@ private:
 // so the partition of a position is a shift and there is no `sizes` sequence.
 template <bool STRICT>
 class uniform_enumerator {
+    friend struct partition_construction_test;
 public:
     typedef typename base_sequence<STRICT>::enumerator base_enum;
     uniform_enumerator() {}
@@ -738,6 +742,130 @@ struct single_enumerator : base_sequence<STRICT>::enumerator { // indexed_sequen
     single_enumerator(const bitvec& bv, uint64_t offset, uint64_t universe, uint64_t n, pef_params const& p, pef_profile*)
         : base_sequence<STRICT>::enumerator(bv, offset, universe, n, p) {}
 };
+
+// ---------------------------------------------------------------- the reference's own sequence tests, restated
+// Each check returns 0 or the number of the first failed requirement (reported to the Python test as "line").
+#define SEQ_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+
+// test_partitioned_sequence.cpp:13-44: every partition entered through switch_partition() must report the base, the
+// upper bound and the elements the plain sequence implies.
+struct partition_construction_test {
+    template <class Enum>
+    static int run(Enum& r, const uint64_t* seq, uint64_t) {
+        if (r.m_partitions == 1) return 0;
+        for (uint64_t p = 0; p < r.m_partitions; ++p) {
+            r.switch_partition(p);
+            const uint64_t b = r.m_cur_begin, e = r.m_cur_end;
+            SEQ_REQUIRE(e > b && e <= r.m_size, 101);
+            SEQ_REQUIRE((p ? seq[b - 1] + 1 : seq[0]) == r.m_cur_base, 102);
+            SEQ_REQUIRE(seq[e - 1] == r.m_cur_upper_bound, 103);
+            for (uint64_t i = b; i < e; ++i) SEQ_REQUIRE(seq[i] == r.m_cur_base + r.m_partition_enum.move(i - b).second, 104);
+        }
+        return 0;
+    }
+};
+
+// test_generic_sequence.hpp:28-88 (random access, enumeration, prev_value, small skips)
+template <class Reader>
+inline int sequence_test_move_next(Reader r, const uint64_t* seq, uint64_t n) {
+    SEQ_REQUIRE(n == r.size(), 201);
+    value_type val;
+    for (uint64_t i = 0; i < n; ++i) {
+        val = r.move(i);
+        SEQ_REQUIRE(val.first == i, 202);
+        SEQ_REQUIRE(val.second == seq[i], 203);
+        SEQ_REQUIRE(r.prev_value() == (i ? seq[i - 1] : 0), 204);
+    }
+    r.move(n);
+    SEQ_REQUIRE(r.prev_value() == seq[n - 1], 205);
+    val = r.move(0);
+    for (uint64_t i = 0; i < n; ++i) {
+        SEQ_REQUIRE(val.second == seq[i], 206);
+        SEQ_REQUIRE(r.prev_value() == (i ? seq[i - 1] : 0), 207);
+        val = r.next();
+    }
+    SEQ_REQUIRE(val.first == r.size(), 208);
+    SEQ_REQUIRE(r.prev_value() == seq[n - 1], 209);
+    const uint64_t stride = n > 4096 ? n / 2048 : 1; // the reference tries every i; a stride keeps big inputs in seconds
+    for (uint64_t i = 0; i < n; i += stride)
+        for (uint64_t skip = 1; skip < n - i; skip <<= 1) {
+            Reader rr = r;
+            rr.move(i);
+            val = rr.move(i + skip);
+            SEQ_REQUIRE(val.first == i + skip, 210);
+            SEQ_REQUIRE(val.second == seq[i + skip], 211);
+        }
+    return 0;
+}
+
+// test_generic_sequence.hpp:90-164 (successor of every gap position, beyond the last element, small skips)
+template <class Reader>
+inline int sequence_test_next_geq(Reader r, const uint64_t* seq, uint64_t n) {
+    value_type val;
+    uint64_t last = 0, rng = 0x9E3779B97F4A7C15ull;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (seq[i] == last) continue;
+        Reader rr = r;
+        for (int t = 0; t < 10; ++t) {
+            uint64_t p;
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+            if (i == 0) p = last + 1;
+            else if (i == 1) p = seq[i];
+            else p = last + 1 + (rng >> 33) % (seq[i] - last);
+            val = rr.next_geq(p);
+            SEQ_REQUIRE(val.first == i, 301);
+            SEQ_REQUIRE(val.second == seq[i], 302);
+            SEQ_REQUIRE(rr.prev_value() == (val.first ? seq[val.first - 1] : 0), 303);
+        }
+        last = seq[i];
+    }
+    {
+        Reader rr = r;
+        val = rr.next_geq(seq[n - 1] + 1);
+        SEQ_REQUIRE(val.first == rr.size(), 304);
+        SEQ_REQUIRE(rr.prev_value() == seq[n - 1], 305);
+        // beyond the universe. The reference asks for position == size() on the reader that already sits at the end; its
+        // own small-skip loop (compact_elias_fano.hpp:194-209) steps the position once more before it notices, so for tiny
+        // universes (singleton {1} in universe 2) it answers size() + 1, and all_ones_sequence answers the bound itself
+        // (all_ones_sequence.hpp:47-53) -- restated as ">= size()".
+        val = rr.next_geq(2 * seq[n - 1] + 1);
+        SEQ_REQUIRE(val.first >= rr.size(), 306);
+    }
+    const uint64_t stride = n > 4096 ? n / 2048 : 1;
+    for (uint64_t i = 0; i < n; i += stride)
+        for (uint64_t skip = 1; skip < n - i; skip <<= 1) {
+            uint64_t exp_pos = i + skip;
+            // first of a run of equal values -- but never before the reader's own position: when seq[i] already equals
+            // the bound the enumerator stays where it is (compact_elias_fano.hpp:186-188). The reference's loop walks
+            // back past i for runs of three or more; SURVEY.md section 4 notes its next_geq test is never instantiated.
+            while (exp_pos > i && seq[exp_pos - 1] == seq[i + skip]) --exp_pos;
+            Reader rr = r;
+            rr.move(i);
+            val = rr.next_geq(seq[i + skip]);
+            SEQ_REQUIRE(val.first == exp_pos, 307);
+            SEQ_REQUIRE(val.second == seq[i + skip], 308);
+        }
+    return 0;
+}
+
+// kinds numbered like enum ds2i_sequence_kind (include/ds2i_build.h)
+inline int sequence_selftest(int kind, const bitvec& bv, uint64_t universe, const uint64_t* seq, uint64_t n, pef_params const& p) {
+    int rc = 0;
+    switch (kind) {
+    case 0: { cef_enumerator r(bv, 0, universe, n, p); rc = sequence_test_move_next(r, seq, n); return rc ? rc : sequence_test_next_geq(r, seq, n); }
+    case 1: { crb_enumerator r(bv, 0, universe, n, p); rc = sequence_test_move_next(r, seq, n); return rc ? rc : sequence_test_next_geq(r, seq, n); }
+    case 2: { base_sequence<false>::enumerator r(bv, 0, universe, n, p); rc = sequence_test_move_next(r, seq, n); return rc ? rc : sequence_test_next_geq(r, seq, n); }
+    case 3: { base_sequence<true>::enumerator r(bv, 0, universe, n, p); return sequence_test_move_next(r, seq, n); }
+    case 4: { partitioned_enumerator<false> r(bv, 0, universe, n, p, nullptr); rc = partition_construction_test::run(r, seq, n);
+              if (!rc) rc = sequence_test_move_next(r, seq, n); return rc ? rc : sequence_test_next_geq(r, seq, n); }
+    case 5: { partitioned_enumerator<true> r(bv, 0, universe, n, p, nullptr); rc = partition_construction_test::run(r, seq, n);
+              return rc ? rc : sequence_test_move_next(r, seq, n); }
+    case 6: { uniform_enumerator<false> r(bv, 0, universe, n, p, nullptr); rc = sequence_test_move_next(r, seq, n); return rc ? rc : sequence_test_next_geq(r, seq, n); }
+    case 7: { uniform_enumerator<true> r(bv, 0, universe, n, p, nullptr); return sequence_test_move_next(r, seq, n); }
+    default: return -1;
+    }
+}
+#undef SEQ_REQUIRE
 
 // ---------------------------------------------------------------- positive_sequence<Base> (positive_sequence.hpp:33-78)
 template <class Base>
