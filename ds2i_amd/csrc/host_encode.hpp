@@ -413,37 +413,31 @@ inline void mixed_encode_type(mixed_type t, int pfor_b, const uint32_t* in, uint
     }
 }
 
-// Deterministic per-block policy standing in for optimal_hybrid_index.cpp (out of scope,
-// SURVEY.md §2): a fixed space/time trade-off -- varint (fastest decoder) when it costs at most
-// 25% more bytes than pfor, interpolative only when it is more than 1.5x smaller than that choice.
-inline void mixed_encode(const uint32_t* in, uint32_t sum, size_t n, bytes_t& out) {
+// Deterministic per-block policy for block_mixed images that do not come out of the optimiser (host_hybrid.hpp), the
+// one SURVEY.md section 8(d) fixes for the C5 configuration: every 16th block of a list (1, 17, ..) interpolative, otherwise
+// VarInt-G8IU when every value fits 8 bits (the reference's fastest decoder on its CPU, mixed_block.hpp:198-217 lists it
+// first) and OptPFor (findBestB) when not. An index written this way holds a substantial share of all three types.
+inline void mixed_encode(const uint32_t* in, uint32_t sum, size_t n, bytes_t& out, uint64_t block_no = 0) {
     if (n < BLOCK) { mixed_encode_type(MIXED_INTERP, -1, in, sum, n, out); return; }
-    bytes_t a, b, c;
-    varint_g8iu_encode(in, sum, n, a);
-    optpfor_encode(in, sum, n, b);
     uint64_t total = 0;
-    for (size_t i = 0; i < n; ++i) total += in[i];
-    const bool interp_ok = total < 0xFFFFFFFFull; // interpolative codes u32 prefix sums
-    if (interp_ok) interpolative_encode(in, sum, n, c);
-    mixed_type t = (4 * a.size() <= 5 * b.size()) ? MIXED_VARINT : MIXED_PFOR;
-    size_t best = t == MIXED_VARINT ? a.size() : b.size();
-    if (interp_ok && 3 * c.size() < 2 * best) t = MIXED_INTERP;
-    const bytes_t& src = t == MIXED_VARINT ? a : t == MIXED_PFOR ? b : c;
-    out.push_back((uint8_t)t);
-    out.insert(out.end(), src.begin(), src.end());
+    uint32_t any = 0;
+    for (size_t i = 0; i < n; ++i) { total += in[i]; any |= in[i]; }
+    mixed_type t = any < 256u ? MIXED_VARINT : MIXED_PFOR;
+    if ((block_no & 15u) == 1u && total < 0xFFFFFFFFull) t = MIXED_INTERP; // blocks 1, 17, 33, ..; interpolative codes u32 prefix sums
+    mixed_encode_type(t, -1, in, sum, n, out);
 }
 
 enum codec_kind : int {
     CODEC_OPTPFOR = 0, CODEC_VARINT = 1, CODEC_INTERPOLATIVE = 2, CODEC_QMX = 3, CODEC_MIXED = 4
 };
 
-inline void block_encode(int codec, const uint32_t* in, uint32_t sum, size_t n, bytes_t& out) {
+inline void block_encode(int codec, const uint32_t* in, uint32_t sum, size_t n, bytes_t& out, uint64_t block_no = 0) {
     switch (codec) {
     case CODEC_OPTPFOR: optpfor_encode(in, sum, n, out); break;
     case CODEC_VARINT: varint_g8iu_encode(in, sum, n, out); break;
     case CODEC_INTERPOLATIVE: interpolative_encode(in, sum, n, out); break;
     case CODEC_QMX: qmx_encode(in, sum, n, out); break;
-    case CODEC_MIXED: mixed_encode(in, sum, n, out); break;
+    case CODEC_MIXED: mixed_encode(in, sum, n, out, block_no); break;
     default: throw std::invalid_argument("unknown codec");
     }
 }

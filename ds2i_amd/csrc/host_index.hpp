@@ -44,8 +44,8 @@ inline void write_posting_list(int codec, bytes_t& out, uint32_t n, const uint32
             fbuf[i] = freqs[k] - 1;
         }
         std::memcpy(&out[begin_maxs + 4 * b], &last_doc, 4);
-        block_encode(codec, dbuf, last_doc - block_base - (cur - 1), cur, out);
-        block_encode(codec, fbuf, uint32_t(-1), cur, out);
+        block_encode(codec, dbuf, last_doc - block_base - (cur - 1), cur, out, b);
+        block_encode(codec, fbuf, uint32_t(-1), cur, out, b);
         if (b != blocks - 1) {
             uint32_t ep = (uint32_t)(out.size() - begin_blocks);
             std::memcpy(&out[begin_endpoints + 4 * b], &ep, 4);

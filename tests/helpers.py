@@ -100,3 +100,40 @@ def brute_ranked(coll, terms, k, conjunctive, order="size"):
 
 def queries_for(coll, nq=200, seed=0x51E21):
     return d.synth_queries(seed, coll.p.num_terms, nq)
+
+
+def mixed_block_type_counts(image, oracle_mod, max_blocks=20000):
+    """Full blocks of a block_mixed image by type byte (mixed_block.hpp:38-66: 0 = OptPFor, 1 = VarInt-G8IU,
+    2 = interpolative), walked straight off the on-disk layout: 5 B params | u64 size |
+    u64 num_docs | bit_vector m_endpoints | u64 bytes | m_lists. Returns {"docs": [..3], "freqs": [..3]}; at most
+    `max_blocks` blocks are visited (spread over the lists). The docs part's length -- needed to find the freqs part's
+    type byte -- comes from the oracle's block decoder."""
+    img = np.frombuffer(image, dtype=np.uint8)
+    u64 = lambda off: int(np.frombuffer(img[off:off + 8].tobytes(), dtype=np.uint64)[0])
+    size = u64(5)
+    words = u64(5 + 8 + 8 + 8)           # after m_endpoints' bit count: its word vector
+    lists_at = 5 + 8 + 8 + 8 + 8 + 8 * words
+    nbytes = u64(lists_at)
+    lists = img[lists_at + 8:lists_at + 8 + nbytes]
+    oidx = oracle_mod.Index("block_mixed", image)
+    counts = {"docs": [0, 0, 0], "freqs": [0, 0, 0]}
+    visited = 0
+    per_list = max(1, max_blocks // max(size, 1))
+    for t in range(size):
+        off = int(oidx.list_offset(t))
+        n, vl = oracle_mod.decode_vbyte(lists[off:off + 5].tobytes())
+        nb = (n + 127) // 128
+        maxs = np.frombuffer(lists[off + vl:off + vl + 4 * nb].tobytes(), dtype=np.uint32)
+        eps = np.frombuffer(lists[off + vl + 4 * nb:off + vl + 4 * nb + 4 * (nb - 1)].tobytes(), dtype=np.uint32)
+        data = off + vl + 4 * nb + 4 * (nb - 1)
+        full = n // 128
+        for b in list(range(0, full, max(1, full // per_list)))[:per_list]:
+            start = data + (int(eps[b - 1]) if b else 0)
+            base = int(maxs[b - 1]) + 1 if b else 0
+            blk = lists[start:start + 2048].tobytes()
+            _, consumed = oracle_mod.decode_block("block_mixed", blk, 128, int(maxs[b]) - base - 127)
+            counts["docs"][blk[0]] += 1
+            counts["freqs"][blk[consumed]] += 1
+            visited += 1
+    assert visited > 0
+    return counts

@@ -155,7 +155,7 @@ def test_mixed_block_types(built_lib):
             seen.add(enc[0])
             dec, consumed = o.decode_block("block_mixed", enc, 128, 0xFFFFFFFF)
             assert np.array_equal(dec, v) and consumed == len(enc)
-    assert {0, 1} <= seen  # both pfor and varint blocks occur
+    assert {0, 1} <= seen  # both pfor and varint blocks occur (SURVEY.md 8(d) policy: values < 256 -> varint)
     v = rng.integers(0, 50, size=77, dtype=np.uint64).astype(np.uint32)
     enc = d.encode_block("block_mixed", v, int(v.sum()))
     dec, consumed = o.decode_block("block_mixed", enc, 77, int(v.sum()))

@@ -7,7 +7,7 @@ import pytest
 
 import ds2i_amd as d
 import oracle as o
-from helpers import Collection, brute_and, brute_ranked, queries_for, small_params
+from helpers import Collection, brute_and, brute_ranked, mixed_block_type_counts, queries_for, small_params
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
@@ -142,7 +142,45 @@ def _scale_properties(gidx, oidx, queries, nsample=48, k=10):
     np.testing.assert_allclose(rtopk[idxs][f], otk[f], rtol=RTOL)
     oac, _, _, _, _ = oidx.query_batch("and", sample)
     assert np.array_equal(and_count[idxs], oac)
+    _and_match_lists_equal_oracle(gidx, oidx, sample)
     return rtopk, rlen
+
+
+def _and_match_lists_equal_oracle(gidx, oidx, sample):
+    """north_star: and_query doc-id LISTS bit-exact (not only their lengths), at whatever scale the index has"""
+    b = d.Batch(gidx, "and", sample, want_matches=True)
+    b.run()
+    count = b.fetch()[0]
+    got = b.fetch_matches(count)
+    b.close()
+    for i, q in enumerate(sample):
+        exp = oidx.query("and", q, want_matches=True)["matches"]
+        assert len(got[i]) == len(exp) and np.array_equal(got[i], exp), q
+
+
+def _union_topk_equals_oracle(gidx, oidx, queries, nsample=32, k=10, ops=("wand", "maxscore")):
+    """wand / maxscore against the ORACLE (not against each other) on a spread sample of the batch"""
+    step = max(1, len(queries) // nsample)
+    idxs = list(range(0, len(queries), step))[:nsample]
+    sample = [queries[i] for i in idxs]
+    assert len(sample) >= min(32, len(queries)) and sum(len(set(q)) > 2 for q in sample) >= 4
+    for op in ops:
+        _, gt, gl, _ = gidx.query_batch(op, sample, k=k)
+        _, ot, ol, _, _ = oidx.query_batch(op, sample, k=k)
+        assert np.array_equal(gl, ol), op
+        f = np.isfinite(ot)
+        assert np.array_equal(np.isfinite(gt), f), op
+        np.testing.assert_allclose(gt[f], ot[f], rtol=RTOL, err_msg=op)
+
+
+def test_block_mixed_image_holds_all_three_block_types(images):
+    """The block_mixed index every test of this module runs on dispatches to all three decoders: > 5 % of its full
+    blocks are OptPFor, > 5 % VarInt-G8IU, > 5 % interpolative (docs parts; the freqs parts mix too)."""
+    tc = mixed_block_type_counts(images[0]["block_mixed"], o)
+    nd, nf = sum(tc["docs"]), sum(tc["freqs"])
+    assert nd > 500
+    assert all(c > 0.05 * nd for c in tc["docs"]), tc
+    assert sum(c > 0.05 * nf for c in tc["freqs"]) >= 2, tc
 
 
 @pytest.mark.parametrize("codec", CODECS)
@@ -548,6 +586,8 @@ def test_full_size_c2_properties(built_lib):
     oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", queries)
     oac, _, _, _, _ = oidx.query_batch("and", queries)
     assert np.array_equal(acount, oac)
+    _and_match_lists_equal_oracle(gidx, oidx, queries)            # every doc-id list of the batch, bit-exact
+    _union_topk_equals_oracle(gidx, oidx, queries, nsample=256)
     assert np.array_equal(rcount, oc) and np.array_equal(tlen, otlen)
     assert np.array_equal(rcount, np.minimum(acount, 10))          # ranked_and keeps min(k, |AND|) scores
     with np.errstate(invalid="ignore"):  # -inf padding minus -inf
@@ -722,6 +762,7 @@ def test_gov2_scale_properties(built_lib):
     gidx = d.Index("block_optpfor", img, wand)
     oidx = o.Index("block_optpfor", img, wand)
     rtopk, rlen = _scale_properties(gidx, oidx, queries)
+    _union_topk_equals_oracle(gidx, oidx, queries, nsample=40)     # configs[3]: wand + maxscore vs the oracle at 25 M docs
     and_count, _, _, _ = gidx.query_batch("and", queries[:256])
     # or >= and; wand == maxscore == ranked_or (test_ranked_queries.cpp:39-57), and they dominate ranked_and
     or_count, _, _, _ = gidx.query_batch("or", queries[:256])
@@ -864,6 +905,7 @@ def test_gov2_scale_opt_index_configs2(built_lib):
     gidx = d.Index("opt", img, wand)
     oidx = o.Index("opt", img, wand)
     rtopk, rlen = _scale_properties(gidx, oidx, queries)
+    _union_topk_equals_oracle(gidx, oidx, queries, nsample=32)
     # wand == maxscore (test_ranked_queries.cpp:39-57) and they dominate ranked_and, on a slice of the batch
     sub = queries[:512]
     _, wt, wl, _ = gidx.query_batch("wand", sub, k=10)
