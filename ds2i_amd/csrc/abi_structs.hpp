@@ -21,8 +21,14 @@ struct QTerm {
     float max_bmw;     // q_weight * (max over the list's blocks of bmw[]): device-computed list bound (ranked_and pruning)
     float suf_bmw;     // sum of max_bmw over the LATER lists of the query (enumerator order)
     float floor1;      // one-term ranked queries: q_weight * (k-th largest bmw of the list) -- k documents reach it
+    // doc-id-range max-weight table of the list (rmw, see BatchArgs::rmw): entry (doc >> rmw_shift) of the byte array at
+    // rmw + 64 * rmw_off64; rmw_scale * entry bounds q_weight * doc_term_weight of any posting of that doc-id range
+    uint32_t rmw_off64;
+    uint32_t rmw_shift;
+    float rmw_scale;   // q_weight * (list max block weight) / 255
+    uint32_t nblocks;  // blocks (block indexes) / chunks (freq_index layouts) of the list
 };
-static_assert(sizeof(QTerm) == 64, "QTerm is a 64-byte device record");
+static_assert(sizeof(QTerm) == 80, "QTerm is an 80-byte device record");
 
 enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_PROLOG, PH_PROBE, PH_INSERT, PH_COUNT };
 struct Stats {
@@ -83,6 +89,13 @@ struct BatchArgs {
     unsigned int* block_profile; // block indexes: 2 counters per block of the index (docs / freqs decodes) or null
     const void* skip;            // block indexes: interleaved {block_max, block end offset} per block (uint2) or null
     const float* bmw;            // per block / chunk of the index: max doc_term_weight of its postings, or null
+    // Doc-id-range max-weight tables (one per list, QTerm::rmw_*), or null: byte e of list t's table covers the doc-ids
+    // [e << shift_t, (e + 1) << shift_t); 0 = no posting of the list in that range (=> no document of it can be in an
+    // intersection with the list), otherwise an upward-rounded 8-bit quantisation of the largest doc_term_weight in
+    // the range relative to the list's maximum. Direct addressing by doc-id: a candidate's bound in every other list
+    // costs one byte gather per list and no search (cf. the doc-id-oriented block-max indexes of Dimopoulos, Nepomnyachiy
+    // & Suel, WSDM'13). shift_t is chosen per list so that the table holds DS2I_RMW_G..2*DS2I_RMW_G entries per posting.
+    const uint8_t* rmw;
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
     uint32_t dyn_lists;          // union kernels: list slots of decoded blocks in dynamic LDS (>= the longest query of the launch)
@@ -105,6 +118,7 @@ struct BmwArgs {
     uint32_t num_docs;
     float* bmw;             // out: one per block
     unsigned int* list_bmw; // out: per list max (float bits; weights are >= 0 so the bit patterns order like the values)
+    uint8_t* rmw;           // second pass (k_range_max_weights): the range tables; lists[].max_weight = the list maximum of pass 1
 };
 
 struct MergeArgs {

@@ -71,6 +71,7 @@ void free_index(ds2i_hip_index* x) {
     if (x->d_bits1) (void)hipFree(x->d_bits1);
     if (x->oneshot) ds2i_batch_destroy(x->oneshot);
     if (x->d_bmw) (void)hipFree(x->d_bmw);
+    if (x->d_rmw) (void)hipFree(x->d_rmw);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
     if (x->s_up) (void)hipStreamDestroy(x->s_up);
@@ -78,10 +79,25 @@ void free_index(ds2i_hip_index* x) {
     delete x;
 }
 
+// device temporaries of one function: freed on every path out of it
+struct DevTemps {
+    std::vector<void*> p;
+    ~DevTemps() { for (void* x : p) if (x) (void)hipFree(x); }
+    template <class T> hipError_t alloc(T** out, size_t bytes) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes ? bytes : 4);
+        if (e == hipSuccess) p.push_back(q);
+        *out = (T*)q;
+        return e;
+    }
+};
+
 // Per-block (per-chunk) maximum of bm25::doc_term_weight over the block's postings -- the block-level analogue of
 // wand_data's max_term_weight (wand_data.hpp:40-52), computed ON THE DEVICE with the kernels' own float32 arithmetic:
 // one pass decodes every block of the index (k_block_max_weights, <=64 blocks of one list per wave). ranked_and uses
 // it as an exact upper bound to skip blocks and windows that cannot enter the heap (kernels.hip, k_conjunctive).
+// A second pass of the same shape fills the doc-id-range tables (BatchArgs::rmw): it needs every list's maximum, which
+// the first pass delivers.
 int build_block_max_weights(ds2i_hip_index* x) {
     const uint64_t V = x->size;
     std::vector<QTerm> lists(V);
@@ -91,16 +107,19 @@ int build_block_max_weights(ds2i_hip_index* x) {
         lists[t] = ds2i_make_qterm(x, (uint32_t)t);
         for (uint32_t b = 0; b < x->list_nb[t]; b += 64) items.push_back(ds2i_dev::BmwItem{(uint32_t)t, b});
     }
+    DevTemps tmp;
     QTerm* d_lists = nullptr;
     ds2i_dev::BmwItem* d_items = nullptr;
     unsigned int* d_lmax = nullptr;
-    HIP_OK(hipMalloc((void**)&x->d_bmw, 4 * x->total_blocks));
-    HIP_OK(hipMalloc((void**)&d_lists, sizeof(QTerm) * V));
-    HIP_OK(hipMalloc((void**)&d_items, sizeof(ds2i_dev::BmwItem) * items.size()));
-    HIP_OK(hipMalloc((void**)&d_lmax, 4 * V));
-    hipError_t e = hipMemcpy(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_items, items.data(), sizeof(ds2i_dev::BmwItem) * items.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_lmax, 0, 4 * V);
+    float* d_top = nullptr;
+    HIP_OK(hipMalloc((void**)&x->d_bmw, 4 * x->total_blocks)); // (owned by the handle: free_index releases it on failure)
+    HIP_OK(tmp.alloc(&d_lists, sizeof(QTerm) * V));
+    HIP_OK(tmp.alloc(&d_items, sizeof(ds2i_dev::BmwItem) * items.size()));
+    HIP_OK(tmp.alloc(&d_lmax, 4 * V));
+    HIP_OK(tmp.alloc(&d_top, 4 * (size_t)DS2I_HIP_MAX_K * V));
+    HIP_OK(hipMemcpy(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_items, items.data(), sizeof(ds2i_dev::BmwItem) * items.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(d_lmax, 0, 4 * V));
     ds2i_dev::BmwArgs a{};
     a.arena = x->d_arena;
     a.bits0 = x->d_bits0;
@@ -113,24 +132,56 @@ int build_block_max_weights(ds2i_hip_index* x) {
     a.num_docs = (uint32_t)x->num_docs;
     a.bmw = x->d_bmw;
     a.list_bmw = d_lmax;
-    if (e == hipSuccess) e = ds2i_launch_block_max_weights(&a, (unsigned)std::min<size_t>(items.size(), (size_t)x->num_cus * 64), x->stream[0]);
-    if (e == hipSuccess) e = hipStreamSynchronize(x->stream[0]);
+    a.rmw = nullptr;
+    const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)x->num_cus * 64);
+    HIP_OK(ds2i_launch_block_max_weights(&a, grid, x->stream[0]));
+    HIP_OK(hipStreamSynchronize(x->stream[0]));
     x->list_bmw.assign(V, 0.f);
-    if (e == hipSuccess) e = hipMemcpy(x->list_bmw.data(), d_lmax, 4 * V, hipMemcpyDeviceToHost);
+    HIP_OK(hipMemcpy(x->list_bmw.data(), d_lmax, 4 * V, hipMemcpyDeviceToHost));
     // the DS2I_HIP_MAX_K largest block weights of every list: a one-term ranked query knows k documents reaching
     // q_weight * (k-th largest) before it decodes anything
-    float* d_top = nullptr;
-    if (e == hipSuccess) e = hipMalloc((void**)&d_top, 4 * (size_t)DS2I_HIP_MAX_K * V);
-    if (e == hipSuccess) e = ds2i_launch_list_top_bmw(x->d_bmw, d_lists, (uint32_t)V, d_top, (unsigned)std::min<uint64_t>(V, (uint64_t)x->num_cus * 64), x->stream[0]);
-    if (e == hipSuccess) e = hipStreamSynchronize(x->stream[0]);
+    HIP_OK(ds2i_launch_list_top_bmw(x->d_bmw, d_lists, (uint32_t)V, d_top, (unsigned)std::min<uint64_t>(V, (uint64_t)x->num_cus * 64), x->stream[0]));
+    HIP_OK(hipStreamSynchronize(x->stream[0]));
     x->list_topbmw.assign((size_t)DS2I_HIP_MAX_K * V, 0.f);
-    if (e == hipSuccess) e = hipMemcpy(x->list_topbmw.data(), d_top, 4 * (size_t)DS2I_HIP_MAX_K * V, hipMemcpyDeviceToHost);
-    (void)hipFree(d_top);
-    (void)hipFree(d_lists);
-    (void)hipFree(d_items);
-    (void)hipFree(d_lmax);
-    if (e != hipSuccess) return ds2i_set_error(DS2I_EDEVICE, hipGetErrorString(e));
+    HIP_OK(hipMemcpy(x->list_topbmw.data(), d_top, 4 * (size_t)DS2I_HIP_MAX_K * V, hipMemcpyDeviceToHost));
     x->extra_bytes += 4 * x->total_blocks;
+
+    // ---- doc-id-range tables. Granularity per list: the largest power of two of doc-ids per entry that still gives
+    // the list at least G entries per posting (G = DS2I_RMW_G, default 2; 0 = no tables): a long list gets fine ranges
+    // (a 6 M-posting list of a 25 M-doc collection: 2 doc-ids per byte), a short one coarse ranges of about the same
+    // number of bytes per posting -- 1..2 G bytes per posting altogether, every table padded to 64 bytes.
+    static const char* gs = std::getenv("DS2I_RMW_G");
+    const double G = gs ? std::atof(gs) : 2.0;
+    if (!(G > 0) || std::getenv("DS2I_NO_RMW")) return DS2I_OK;
+    x->list_rmw_off64.assign(V, 0);
+    x->list_rmw_shift.assign(V, 0);
+    uint64_t cursor = 0; // in units of 64 bytes
+    for (uint64_t t = 0; t < V; ++t) {
+        uint32_t sh = 0;
+        while (sh < 31 && (double)(x->num_docs >> (sh + 1)) >= G * (double)x->list_n[t]) ++sh;
+        const uint64_t entries = (x->num_docs >> sh) + 1;
+        x->list_rmw_shift[t] = sh;
+        x->list_rmw_off64[t] = (uint32_t)cursor;
+        cursor += (entries + 63) / 64;
+        if (cursor >= (1ull << 32)) return DS2I_OK; // > 256 GB of tables: not on this device; run without them
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t bytes = cursor * 64 + 64;
+    if (bytes > free_b / 2) return DS2I_OK; // the tables are an accelerator, never a reason to fail an upload
+    HIP_OK(hipMalloc((void**)&x->d_rmw, bytes));
+    x->rmw_bytes = bytes;
+    HIP_OK(hipMemsetAsync(x->d_rmw, 0, bytes, x->stream[0]));
+    for (uint64_t t = 0; t < V; ++t) {
+        lists[t].rmw_off64 = x->list_rmw_off64[t];
+        lists[t].rmw_shift = x->list_rmw_shift[t];
+        lists[t].max_weight = x->list_bmw[t];
+    }
+    HIP_OK(hipMemcpyAsync(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice, x->stream[0]));
+    a.rmw = x->d_rmw;
+    HIP_OK(ds2i_launch_block_max_weights(&a, grid, x->stream[0]));
+    HIP_OK(hipStreamSynchronize(x->stream[0]));
+    x->extra_bytes += bytes;
     return DS2I_OK;
 }
 
@@ -355,8 +406,6 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
         QTerm qt = ds2i_make_qterm(x.get(), (uint32_t)t);
         qt.q_weight = x->has_wand ? x->max_term_weight[t] : 0.f;
         qt.max_weight = x->d_bmw ? x->list_bmw[t] : 0.f;
-        const uint32_t nb = x->list_nb[t];
-        std::memcpy(&qt.floor1, &nb, 4);
         x->term_proto[t] = qt;
     }
     *out = x.release();

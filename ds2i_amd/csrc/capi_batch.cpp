@@ -167,13 +167,13 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         for (auto const& p : tf) {
             QTerm qt = idx->term_proto[p.first]; // one cache line: see capi_internal.hpp
             const float mtw = qt.q_weight, lbmw = qt.max_weight;
-            uint32_t nb;
-            std::memcpy(&nb, &qt.floor1, 4);
-            qt.q_weight = qt.max_weight = qt.floor1 = 0.f;
+            const uint32_t nb = qt.nblocks;
+            qt.q_weight = qt.max_weight = 0.f;
             if (ranked) {
                 qt.q_weight = ds2i_host::bm25::query_term_weight(p.second, qt.n, idx->num_docs);
                 qt.max_weight = qt.q_weight * mtw;
                 qt.max_bmw = idx->d_bmw ? qt.q_weight * lbmw : std::numeric_limits<float>::infinity();
+                qt.rmw_scale = qt.q_weight * (lbmw * (1.0f / 255.0f)); // range-table byte -> bound of the term score
             }
             qterms.push_back(qt);
             qnbs.push_back(nb);
@@ -549,6 +549,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
         a.skip = (no_skiptab && conj_op) ? nullptr : idx->d_skip; // (the union kernels are compiled for the table: they position before they decode)
         a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;
+        static const bool no_rmw_use = std::getenv("DS2I_NO_RMW_USE") != nullptr; // A/B: tables built but not consulted
+        a.rmw = (no_rmw_use || (base_op == DS2I_OP_RANKED_AND && !a.bmw)) ? nullptr : idx->d_rmw;
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;

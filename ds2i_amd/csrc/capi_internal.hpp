@@ -96,6 +96,9 @@ struct ds2i_hip_index {
     uint8_t* d_bits0 = nullptr;     // opt index: docs bit vector
     uint8_t* d_bits1 = nullptr;     // opt index: freqs bit vector
     float* d_bmw = nullptr;         // per block / chunk: max doc_term_weight of its postings (ranked_and pruning), or null
+    uint8_t* d_rmw = nullptr;       // doc-id-range max-weight tables (abi_structs.hpp, BatchArgs::rmw), or null
+    uint64_t rmw_bytes = 0;
+    std::vector<uint32_t> list_rmw_off64, list_rmw_shift;
     std::vector<float> list_bmw;    // per list: max over its blocks of d_bmw (device-computed)
     std::vector<float> list_topbmw; // per list: its DS2I_HIP_MAX_K largest block weights, descending, padded with 0
     uint64_t extra_bytes = 0;
@@ -106,10 +109,10 @@ struct ds2i_hip_index {
     hipStream_t s_up = nullptr, s_merge = nullptr;
     unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
     ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)
-    // Planning reads one 64-byte record per query term instead of eight parallel arrays (a 4096-query batch has ~12 k
+    // Planning reads one 80-byte record per query term instead of eight parallel arrays (a 4096-query batch has ~12 k
     // terms; at configs[1] scale planning, not the kernels, bounds the end-to-end rate): the QTerm as the kernels want
     // it, with the query-independent factors parked in the fields planning overwrites -- q_weight = max_term_weight,
-    // max_weight = list max block weight, floor1 = number of blocks (bit pattern).
+    // max_weight = list max block weight.
     std::vector<ds2i_dev::QTerm> term_proto;
 };
 
@@ -131,5 +134,9 @@ static inline ds2i_dev::QTerm ds2i_make_qterm(const ds2i_hip_index* idx, uint32_
     qt.max_bmw = 0.f;
     qt.suf_bmw = 0.f;
     qt.floor1 = 0.f;
+    qt.rmw_off64 = idx->d_rmw ? idx->list_rmw_off64[term] : 0;
+    qt.rmw_shift = idx->d_rmw ? idx->list_rmw_shift[term] : 0;
+    qt.rmw_scale = 0.f;
+    qt.nblocks = idx->list_nb[term];
     return qt;
 }

@@ -25,7 +25,8 @@ enum { M_MAXS_LO = 0, M_MAXS_HI, M_N, M_NB, M_CUR, M_SIZE, M_BMAX, M_POS, M_DOCI
        M_SUF /* sum of the later lists' q_weight * list max bmw (float bits) */,
        M_DDEC /* docs of block M_CUR are decoded (the disjunctive kernel positions a list on a block first and decodes it only if the block can matter) */,
        M_EP, M_BASE /* table words of a positioned, not yet decoded block: start offset, first doc-id it can hold */,
-       M_WORDS }; // 29 dwords per list slot
+       M_RBASE, M_RSHIFT, M_RSCALE /* the list's doc-id-range table (QTerm::rmw_*): offset / 64, doc-ids per entry (log2), byte -> score bound (float bits) */,
+       M_WORDS }; // 32 dwords per list slot
 
 #ifdef DS2I_PHASE_TIMING
 #define PT_BEGIN(cx) const unsigned long long pt_t0_ = __builtin_readcyclecounter()
@@ -375,6 +376,9 @@ struct CtxT {
             setm(s, M_CBW, 0);
             setm(s, M_DDEC, 0);
             setm(s, M_SUF, __float_as_uint(t.suf_bmw));
+            setm(s, M_RBASE, t.rmw_off64);
+            setm(s, M_RSHIFT, t.rmw_shift);
+            setm(s, M_RSCALE, __float_as_uint(t.rmw_scale));
             wave_sync();
             s_bytes += 16 + 8; // two collection offsets + gamma(occurrences), n
             return;
@@ -397,6 +401,9 @@ struct CtxT {
         setm(s, M_CBW, 0);
         setm(s, M_DDEC, 0);
         setm(s, M_SUF, __float_as_uint(t.suf_bmw));
+        setm(s, M_RBASE, t.rmw_off64);
+        setm(s, M_RSHIFT, t.rmw_shift);
+        setm(s, M_RSCALE, __float_as_uint(t.rmw_scale));
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset

@@ -109,6 +109,14 @@ DS2I_DEV bool static_list_loop(uint32_t nt, F& f) {
     }
     return true;
 }
+// body(integral_constant i) for i = HI-1 down to LO, compile-time expanded
+template <int HI, int LO, class F>
+DS2I_DEV void static_loop_down(F& f) {
+    if constexpr (HI > LO) {
+        f(std::integral_constant<uint32_t, (uint32_t)(HI - 1)>{});
+        static_loop_down<HI - 1, LO>(f);
+    }
+}
 #define DS2I_LIST_LOOP(FROM, body)                                   \
     if constexpr (REG) {                                             \
         static_list_loop<(FROM), TMAX>(nt, body);                    \
@@ -194,6 +202,10 @@ template <int TMAX, bool META_IN_LDS, bool RANKED, bool WITH_S16 = true>
 struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED, WITH_S16, (RANKED && TMAX > 2) ? 2 : TMAX> {
     float nl[RANKED ? 128 : 1];
     float part0[RANKED ? 128 : 1]; // list-0 term score of each posting of the block (-inf = dropped): read every round
+    // range-table bytes of each posting of list 0's block in the other lists, packed: byte i-1 of qb = list i (1..4),
+    // byte i-5 of qb2 = list i (5..7)
+    uint32_t qb[RANKED ? 128 : 1];
+    uint32_t qb2[RANKED && (TMAX > 4) ? 128 : 1];
 };
 
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
@@ -215,6 +227,11 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
     //     still enter the heap, so the long lists are probed -- and their blocks decoded -- for few candidates;
     //   * before list i's next block is decoded, the best alive partial score + that block's max weight is tested.
     const float* const bmw = RANKED ? a.bmw : nullptr;
+    // Doc-id-range tables (BatchArgs::rmw): one byte gather per candidate and other list, no search. A zero byte proves
+    // the candidate is in no intersection with that list; otherwise the bytes bound its score in the other lists far
+    // tighter than the list maxima (M_SUF) do. Lists 1..7 of a query are covered (the 9-16-term class keeps M_SUF).
+    constexpr int RL = TMAX < 8 ? TMAX : 8; // lists 1 .. RL-1 have their bytes packed per candidate
+    const uint8_t* const rmw = TMAX <= 8 ? a.rmw : nullptr;
     // one work unit per (single-wave) workgroup, costliest units first: the hardware dispatcher
     // interleaves the workgroups of the concurrently running LDS classes as resources free up
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
@@ -274,9 +291,50 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             }
             return u.blk_end;
         };
+        const bool use_rmw = rmw && nt > 1 && (!RANKED || bmw); // wave-uniform
+        // the range-table bytes of candidate c in lists 1..nt-1 (all gathers are issued before the first is consumed);
+        // false = some list has no posting in c's range, so c cannot be a match
+        auto rmw_gather = [&](uint32_t c, bool valid, uint32_t& qlo, uint32_t& qhi) __attribute__((always_inline)) -> bool {
+            uint32_t e[RL] = {};
+            auto load_one = [&](auto ic) __attribute__((always_inline)) {
+                constexpr uint32_t i = decltype(ic)::value;
+                const uint8_t* tab = rmw + 64ull * cx.m(i, M_RBASE);
+                e[i] = valid ? (uint32_t)tab[c >> cx.m(i, M_RSHIFT)] : 0u;
+                return true;
+            };
+            static_list_loop<1, RL>(nt, load_one);
+            bool ok = valid;
+            qlo = qhi = 0;
+            auto pack_one = [&](auto ic) __attribute__((always_inline)) {
+                constexpr uint32_t i = decltype(ic)::value;
+                ok = ok && e[i] != 0;
+                if constexpr (i <= 4) qlo |= e[i] << (8 * (i - 1)); else qhi |= e[i] << (8 * (i - 5));
+                return true;
+            };
+            static_list_loop<1, RL>(nt, pack_one);
+            return ok;
+        };
+        // bound of the candidate's term score in list i, from its packed byte
+        auto rmw_term = [&](uint32_t qlo, uint32_t qhi, auto ic) __attribute__((always_inline)) -> float {
+            constexpr uint32_t i = decltype(ic)::value;
+            const uint32_t b = i <= 4 ? (qlo >> (8 * (i - 1))) & 255u : (qhi >> (8 * ((i - 5) & 3))) & 255u;
+            return __uint_as_float(cx.m(i, M_RSCALE)) * (float)b;
+        };
+        // sum of those bounds over the lists j > after (added from the last list down, so that the value for `after` is a
+        // prefix of the same chain whatever `after` is)
+        auto rmw_rest = [&](uint32_t qlo, uint32_t qhi, uint32_t after) __attribute__((always_inline)) -> float {
+            float r = 0.f;
+            auto add_one = [&](auto jc) __attribute__((always_inline)) {
+                constexpr uint32_t j = decltype(jc)::value;
+                if (j < nt && j > after) r = r + rmw_term(qlo, qhi, jc);
+            };
+            static_loop_down<RL, 1>(add_one);
+            return r;
+        };
         cx.s_bytes += 4;
         ++cx.s_bm_examined;
         uint32_t lo = 0;
+        uint64_t okm0 = ~0ull, okm1 = ~0ull; // and / and_freq: candidates of list 0's block the range tables have not ruled out
         uint32_t part_blk = 0xFFFFFFFFu; // block of list 0 whose norm_lens / list-0 scores are in L.nl
         // list 0 moves on: `want` = first block with block_max >= lo (or the unit's first block)
         uint32_t want = u.blk_begin;
@@ -301,16 +359,29 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (blk2 >= u.blk_end) break;
                 cx.decode_docs(0, blk2, (have_bi && blk2 == want) ? &bi0 : nullptr);
                 need0 = false;
+                if constexpr (!RANKED) {
+                    if (use_rmw) { // once per block of list 0: who can be a member of every other list at all
+                        const uint32_t n0c = L.docs[0][lane], n1c = L.docs[0][lane + 64];
+                        uint32_t ql, qh;
+                        okm0 = ballot(rmw_gather(n0c, n0c != 0xFFFFFFFFu, ql, qh));
+                        okm1 = ballot(rmw_gather(n1c, n1c != 0xFFFFFFFFu, ql, qh));
+                    }
+                }
             }
             uint32_t hi = cx.m(0, M_BMAX);
             const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
             bool al0 = c0 >= lo && c0 != 0xFFFFFFFFu, al1 = c1 >= lo && c1 != 0xFFFFFFFFu;
+            if constexpr (!RANKED) {
+                al0 = al0 && ((okm0 >> lane) & 1);
+                al1 = al1 && ((okm1 >> lane) & 1);
+            }
             // ranked_and scores PROGRESSIVELY: pa0 / pa1 are the running float32 sums of this lane's two candidates in
             // list order (queries.hpp:372-380). `sf` (wave-uniform) = the heap is full or a floor is known, so bounds
             // can prune: then the list-0 term scores of the whole block are computed up front (once per block, kept in
             // LDS); otherwise they are computed for the candidates that survive list 1, when they are first needed.
-            const bool sf = RANKED && bmw && can_prune();
+            const bool sf = RANKED && bmw && (use_rmw || can_prune());
             float pa0 = 0.f, pa1 = 0.f;
+            uint32_t ql0 = 0, qh0 = 0, ql1 = 0, qh1 = 0; // this lane's two candidates: packed range-table bytes
             bool have_p = false;
             if constexpr (RANKED) {
                 if (sf || nt == 1) {
@@ -327,9 +398,20 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             // score: a posting whose bound (shortest document of the collection) cannot reach the heap
                             // is dropped before its norm_len is fetched. The heap only tightens, so the verdict holds
                             // for every later round of this block (-inf marks the dropped postings).
-                            const float suf0 = __uint_as_float(cx.m(0, M_SUF));
-                            v0 = v0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + suf0) * BOUND_SLACK);
-                            v1 = v1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + suf0) * BOUND_SLACK);
+                            // With range tables the other lists' part of the bound is per candidate (and a candidate
+                            // outside some list's ranges is dropped whatever the heap says).
+                            float r0 = __uint_as_float(cx.m(0, M_SUF)), r1 = r0;
+                            if (use_rmw) {
+                                v0 = rmw_gather(c0, v0, ql0, qh0);
+                                v1 = rmw_gather(c1, v1, ql1, qh1);
+                                r0 = rmw_rest(ql0, qh0, 0);
+                                r1 = rmw_rest(ql1, qh1, 0);
+                                L.qb[lane] = ql0;
+                                L.qb[lane + 64] = ql1;
+                                if constexpr (TMAX > 4) { L.qb2[lane] = qh0; L.qb2[lane + 64] = qh1; }
+                            }
+                            v0 = v0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + r0) * BOUND_SLACK);
+                            v1 = v1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + r1) * BOUND_SLACK);
                         }
                         const float n0 = v0 ? a.norm_lens[c0] : -1.f, n1 = v1 ? a.norm_lens[c1] : -1.f;
                         L.nl[lane] = n0;
@@ -347,9 +429,17 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     pa1 = L.part0[lane + 64];
                     have_p = true;
                     if (sf) {
-                        const float suf0 = __uint_as_float(cx.m(0, M_SUF));
-                        al0 = al0 && tk.would_enter((pa0 + suf0) * BOUND_SLACK);
-                        al1 = al1 && tk.would_enter((pa1 + suf0) * BOUND_SLACK);
+                        float r0 = __uint_as_float(cx.m(0, M_SUF)), r1 = r0;
+                        if (use_rmw) {
+                            ql0 = L.qb[lane];
+                            ql1 = L.qb[lane + 64];
+                            if constexpr (TMAX > 4) { qh0 = L.qb2[lane]; qh1 = L.qb2[lane + 64]; }
+                            r0 = rmw_rest(ql0, qh0, 0);
+                            r1 = rmw_rest(ql1, qh1, 0);
+                        }
+                        // (pa >= 0 excludes the dropped postings explicitly: while the heap is not full would_enter(-inf) holds)
+                        al0 = al0 && pa0 >= 0.f && tk.would_enter((pa0 + r0) * BOUND_SLACK);
+                        al1 = al1 && pa1 >= 0.f && tk.would_enter((pa1 + r1) * BOUND_SLACK);
                     }
                 }
             }
@@ -388,12 +478,27 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             // best alive partial score inside [lo, min(hi, block_max)] + this block's max weight + the
                             // later lists' maxima: if that cannot enter the heap the block is not even decoded
                             const uint32_t wh = nbmax < hi ? nbmax : hi;
-                            float pm = (al0 && c0 <= wh) ? pa0 : 0.f;
-                            const float p1 = (al1 && c1 <= wh) ? pa1 : 0.f;
+                            const float cbw = __uint_as_float(cx.m(i, M_QW)) * wnew;
+                            float pm, p1, tail = __uint_as_float(cx.m(i, M_SUF));
+                            if (use_rmw) { // per candidate: its partial + min(block weight, its own byte bound in list i) + its later lists
+                                float t0 = cbw, t1 = cbw;
+                                if constexpr (std::is_same<decltype(ic), uint32_t>::value) {
+                                    // (run-time list slot: the 5-8-list class; keep the block weight for list i)
+                                } else {
+                                    const float b0 = rmw_term(ql0, qh0, ic), b1 = rmw_term(ql1, qh1, ic);
+                                    t0 = b0 < cbw ? b0 : cbw;
+                                    t1 = b1 < cbw ? b1 : cbw;
+                                }
+                                pm = (al0 && c0 <= wh) ? (pa0 + t0) + rmw_rest(ql0, qh0, i) : 0.f;
+                                p1 = (al1 && c1 <= wh) ? (pa1 + t1) + rmw_rest(ql1, qh1, i) : 0.f;
+                                tail = 0.f;
+                            } else {
+                                pm = (al0 && c0 <= wh) ? pa0 + cbw : cbw;
+                                p1 = (al1 && c1 <= wh) ? pa1 + cbw : cbw;
+                            }
                             pm = p1 > pm ? p1 : pm; // scores are >= 0: their bit patterns order like the values
                             pm = __uint_as_float(bcast(wave_incl_max_scan(__float_as_uint(pm)), 63));
-                            const float cbw = __uint_as_float(cx.m(i, M_QW)) * wnew;
-                            if (!tk.would_enter(((pm + cbw) + __uint_as_float(cx.m(i, M_SUF))) * BOUND_SLACK)) {
+                            if (!tk.would_enter((pm + tail) * BOUND_SLACK)) {
                                 hi = wh;
                                 skip_decode = true;
                             }
@@ -460,9 +565,10 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                         if (al0) pa0 = pa0 + qw * doc_term_weight(f[p0], L.nl[lane]);
                         if (al1) pa1 = pa1 + qw * doc_term_weight(f[p1], L.nl[lane + 64]);
                         if (sf) { // who cannot reach the heap any more drops out before the next list is touched
-                            const float sufi = __uint_as_float(cx.m(i, M_SUF));
-                            al0 = al0 && tk.would_enter((pa0 + sufi) * BOUND_SLACK);
-                            al1 = al1 && tk.would_enter((pa1 + sufi) * BOUND_SLACK);
+                            float r0 = __uint_as_float(cx.m(i, M_SUF)), r1 = r0;
+                            if (use_rmw) { r0 = rmw_rest(ql0, qh0, i); r1 = rmw_rest(ql1, qh1, i); }
+                            al0 = al0 && tk.would_enter((pa0 + r0) * BOUND_SLACK);
+                            al1 = al1 && tk.would_enter((pa1 + r1) * BOUND_SLACK);
                         }
                     }
                     return true;
@@ -1392,6 +1498,24 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
 // bmw[block] = max over the block's postings of bm25::doc_term_weight(freq, norm_len[doc]) -- the block-level analogue
 // of wand_data's max_term_weight (wand_data.hpp:40-52), with the scoring code's own float32 arithmetic. One wave per
 // item = <=64 consecutive blocks of one list: lane j keeps the weight of block blk_begin + j, one coalesced store.
+// Range-table entries (BatchArgs::rmw): 0 = no posting in the doc-id range; otherwise 1 + floor(255 * w / list max) capped
+// at 255, so that entry * (list max / 255) >= w for every posting of the range (the cap meets w <= list max; the float
+// rounding of the two products is far inside the pruning bound's BOUND_SLACK).
+DS2I_DEV uint32_t rmw_quantise(float w, float inv) {
+    const uint32_t q = (uint32_t)(w * inv) + 1u;
+    return q > 255u ? 255u : q;
+}
+// entry = max(entry, q): bytes have no atomic max, so the containing dword is replaced by compare-and-swap
+DS2I_DEV void rmw_raise(uint8_t* tab, uint32_t entry, uint32_t q) {
+    unsigned int* word = (unsigned int*)(tab + (entry & ~3u));
+    const uint32_t sh = 8u * (entry & 3u);
+    unsigned int old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (((old >> sh) & 255u) < q) {
+        const unsigned int want = (old & ~(255u << sh)) | (q << sh);
+        if (__hip_atomic_compare_exchange_strong(word, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
     __shared__ Lds<1> L;
     BatchArgs ba{};
@@ -1409,16 +1533,21 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
         const uint32_t nb = cx.m(0, M_NB);
         const uint32_t end = it.blk_begin + 64u < nb ? it.blk_begin + 64u : nb;
         float mine = 0.f;
+        uint8_t* const rtab = a.rmw ? a.rmw + 64ull * t.rmw_off64 : nullptr;
+        const float rinv = t.max_weight > 0.f ? 255.0f / t.max_weight : 0.f; // second pass: max_weight = the list's largest weight
         for (uint32_t b = it.blk_begin; b < end; ++b) {
             cx.decode_docs(0, b);
             cx.decode_freqs(0);
             const uint32_t sz = cx.m(0, M_SIZE);
             float w = 0.f;
             if (lane < sz) w = doc_term_weight(L.freqs[0][lane], a.norm_lens[L.docs[0][lane]]);
+            if (a.rmw && lane < sz) rmw_raise(rtab, L.docs[0][lane] >> t.rmw_shift, rmw_quantise(w, rinv));
             if (lane + 64 < sz) {
                 const float w1 = doc_term_weight(L.freqs[0][lane + 64], a.norm_lens[L.docs[0][lane + 64]]);
+                if (a.rmw) rmw_raise(rtab, L.docs[0][lane + 64] >> t.rmw_shift, rmw_quantise(w1, rinv));
                 w = w1 > w ? w1 : w;
             }
+            if (a.rmw) { wave_sync(); continue; } // second pass: bmw[] and the list maxima are final already
             for (int o = 32; o; o >>= 1) {
                 const float x = __shfl_xor(w, o);
                 w = x > w ? x : w;
@@ -1426,6 +1555,7 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
             if (lane == b - it.blk_begin) mine = w;
             wave_sync();
         }
+        if (a.rmw) continue;
         if (it.blk_begin + lane < end) a.bmw[t.blk_base + it.blk_begin + lane] = mine;
         float lm = mine;
         for (int o = 32; o; o >>= 1) {
@@ -1441,7 +1571,7 @@ __global__ void __launch_bounds__(64) k_list_top_bmw(const float* bmw, const QTe
     const uint32_t lane = lane_id();
     for (uint32_t l = blockIdx.x; l < nlists; l += gridDim.x) {
         const QTerm t = lists[l];
-        const uint32_t nb = t.aux1 ? t.term : (t.n + 127u) >> 7; // freq_index layouts carry their chunk count in `term`
+        const uint32_t nb = t.nblocks;
         const float* w = bmw + t.blk_base;
         TopK tk;
         tk.init(64);
