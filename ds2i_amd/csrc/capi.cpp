@@ -459,6 +459,34 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     return DS2I_OK;
 }
 
+int ds2i_hip_list_block_weights(ds2i_hip_index* idx, uint32_t term, float* out, uint64_t capacity, uint64_t* nblocks) {
+    if (!idx || !nblocks) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_block_weights: null argument");
+    if (term >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+    *nblocks = idx->d_bmw ? idx->list_nb[term] : 0;
+    if (!*nblocks) return DS2I_OK;
+    if (!out || capacity < *nblocks) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_block_weights: capacity too small");
+    HIP_OK(hipSetDevice(idx->device));
+    HIP_OK(hipMemcpy(out, idx->d_bmw + idx->list_blk_base[term], 4 * *nblocks, hipMemcpyDeviceToHost));
+    return DS2I_OK;
+}
+
+int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint8_t* out, uint64_t capacity, uint64_t* entries,
+                              uint32_t* shift, float* list_max) {
+    if (!idx || !entries || !shift || !list_max) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: null argument");
+    if (term >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+    *entries = 0;
+    *shift = 0;
+    *list_max = 0.f;
+    if (!idx->d_rmw) return DS2I_OK;
+    *shift = idx->list_rmw_shift[term];
+    *entries = (idx->num_docs >> *shift) + 1;
+    *list_max = idx->list_bmw[term];
+    if (!out || capacity < *entries) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: capacity too small");
+    HIP_OK(hipSetDevice(idx->device));
+    HIP_OK(hipMemcpy(out, idx->d_rmw + 64ull * idx->list_rmw_off64[term], *entries, hipMemcpyDeviceToHost));
+    return DS2I_OK;
+}
+
 // profiling aid: one pass over the whole index arena with the decoders' load shape (4 B per lane); the
 // bytes read are returned so that rocprofv3's FETCH_SIZE can be calibrated against a known count
 int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read) {

@@ -197,6 +197,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 qnb0[q] = qnbs[begin];
                 cost = qnb0[q] * (ranked ? 2.0 : 1.0);
                 for (size_t i = begin + 1; i < qterms.size(); ++i) cost += std::min<double>(qnbs[i], n0);
+                // With range tables (BatchArgs::rmw) a ranked conjunction is a walk over the blocks of its shortest list --
+                // most of them are left after one decode and one gather per other list -- so a unit's time goes with its
+                // number of list-0 blocks, a little more per block the more lists there are (measured wave time per round:
+                // 6 / 10 / 15 us for the <=2- / <=4- / <=8-list classes)
+                if (ranked && idx->d_rmw && tf.size() > 1) cost = qnb0[q] * (3.0 + (double)tf.size());
                 // a one-term ranked query scans its block weights (64 per probe) and decodes about k blocks
                 if (ranked && idx->d_bmw && tf.size() == 1) cost = qnb0[q] / 16.0 + 4.0 * k;
                 b->match_off[q + 1] = 128ull * qnb0[q];
@@ -264,7 +269,8 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
         static const char* ud = std::getenv("DS2I_UNIT_DIV");
         static const double unit_div = ud && std::atof(ud) > 0 ? std::atof(ud) : 4.0;
-        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : unit_div));
+        const bool rmw_cost = ranked && conj && idx->d_rmw; // (cost already counts the class's time per block)
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 || rmw_cost ? 1.0 : unit_div));
         ++b->nqcls[c];
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);

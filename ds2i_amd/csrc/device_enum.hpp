@@ -55,7 +55,7 @@ struct MetaReg {
     // since ranked_and prunes, list 1 is probed for few candidates and rarely sequentially -- its prefetch only cost
     // three VGPRs and wasted loads (same throughput without it, and the kernel no longer needs scratch). None with 3-4
     // lists, where the extra VGPRs cost more occupancy than the prefetch wins (measured).
-    static constexpr int NPF = TMAX <= 2 ? 1 : 0;
+    static constexpr int NPF = 0; // (superseded by the list-0 stream of k_conjunctive, kernels.hip)
     // the interleaved skip table saves the table round trip of a non-sequential decode; the <=2-list kernel decodes
     // sequentially through its prefetch and cannot afford the extra state (72 SGPRs)
     static constexpr bool SKIPTAB = TMAX > 2;
@@ -194,7 +194,8 @@ struct CtxT {
     // its block_max and the first doc-id it can hold
     struct BlockInfo { uint32_t ep, next_ep, bmax, base; };
 
-    DS2I_DEV void decode_docs(uint32_t s, uint32_t b, const BlockInfo* pre = nullptr) {
+    // `pre`: the block's table words, already known to the caller; `staged`: its bytes are in the staging window too
+    DS2I_DEV void decode_docs(uint32_t s, uint32_t b, const BlockInfo* pre = nullptr, bool staged = false) {
         PT_BEGIN(*this);
         if (is_pef()) {
             decode_docs_pef(s, b);
@@ -236,7 +237,7 @@ struct CtxT {
             uint32_t hint = next_ep - ep;
             if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
             p = data + ep;
-            win.load(p, hint);
+            if (!staged) win.load(p, hint);
         }
         if (!have) {
         // Table words come from ONE unconditional load with a per-lane address (lane 0: endpoint[b-1], 1: block_max[b],
@@ -650,10 +651,16 @@ struct TopK {
     uint32_t n;   // uniform
     uint32_t k;
     float floor;  // scores below it can never be in the final top-k (seeded lower bound); -inf = none
-    DS2I_DEV void init(uint32_t k_) { v = -__builtin_inff(); n = 0; k = k_; floor = -__builtin_inff(); }
-    DS2I_DEV float threshold() const { return __uint_as_float(bcast(__float_as_uint(v), k - 1)); }
-    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > threshold()); }
-    DS2I_DEV bool insert(float s) { // s wave-uniform
+    // The k-th best score (-inf until k scores are held), kept as a wave-uniform copy that insert() refreshes.
+    // would_enter() is called on per-lane values, often behind a short-circuit (`alive && would_enter(..)`), i.e. in
+    // DIVERGENT code: reading lane k-1 of `v` there is undefined when that lane is inactive (after a spill the register is
+    // reloaded for the active lanes only -- the runtime-codec kernels lost results to exactly that), so no cross-lane
+    // operation may sit on that path. It also saves a v_readlane per test.
+    float thr;
+    DS2I_DEV void init(uint32_t k_) { v = -__builtin_inff(); n = 0; k = k_; floor = -__builtin_inff(); thr = -__builtin_inff(); }
+    DS2I_DEV float threshold() const { return thr; }
+    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > thr); }
+    DS2I_DEV bool insert(float s) { // s wave-uniform; wave-uniform control flow only
         if (!would_enter(s)) return false;
         const uint32_t lane = lane_id();
         uint64_t ge = ballot(lane < n && v >= s);
@@ -662,6 +669,7 @@ struct TopK {
         v = (lane < p) ? v : (lane == p) ? s : up;
         if (n < k) ++n;
         if (lane >= k) v = -__builtin_inff();
+        thr = __uint_as_float(bcast(__float_as_uint(v), k - 1));
         return true;
     }
 };
@@ -680,15 +688,18 @@ struct TopKBig {
         n = 0;
         k = k_;
         floor = -__builtin_inff();
+        thr = -__builtin_inff();
     }
-    DS2I_DEV float threshold() const {
+    float thr; // wave-uniform copy of the k-th best score, refreshed by insert() (see TopK::thr)
+    DS2I_DEV float kth() const {
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < NK; ++r)
             if ((uint32_t)r == ((k - 1) >> 6)) t = __uint_as_float(bcast(__float_as_uint(v[r]), (k - 1) & 63u));
         return t;
     }
-    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > threshold()); }
+    DS2I_DEV float threshold() const { return thr; }
+    DS2I_DEV bool would_enter(float s) const { return s >= floor && (n < k || s > thr); }
     DS2I_DEV bool insert(float s) { // s wave-uniform
         if (!would_enter(s)) return false;
         const uint32_t lane = lane_id();
@@ -706,6 +717,7 @@ struct TopKBig {
             v[r] = nv;
         }
         if (n < k) ++n;
+        thr = kth();
         return true;
     }
 };

@@ -187,6 +187,9 @@ static constexpr float BOUND_SLACK = 1.0f + 1.0f / 131072.0f;
 // extra waves hide); beyond that LDS caps the residency anyway (8 / 13 / 23 KiB per wave of the 160 KiB per CU), and
 // without a bound the register allocator lets the unrolled list loops balloon (237 VGPRs, 2 waves/SIMD for the 4-list
 // kernel when left alone).
+#ifndef DS2I_FLOOR_EVERY
+#define DS2I_FLOOR_EVERY 4 // power of two
+#endif
 #ifndef DS2I_OCC2
 #define DS2I_OCC2 6
 #endif
@@ -333,9 +336,61 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         };
         cx.s_bytes += 4;
         ++cx.s_bm_examined;
-        uint32_t lo = 0;
+        uint32_t lo = 0, floor_tick = 1;
         uint64_t okm0 = ~0ull, okm1 = ~0ull; // and / and_freq: candidates of list 0's block the range tables have not ruled out
         uint32_t part_blk = 0xFFFFFFFFu; // block of list 0 whose norm_lens / list-0 scores are in L.nl
+        // ---- list 0 as a STREAM (block indexes with the interleaved skip table). The driving list is walked front to
+        // back, most of its blocks only to find that none of their documents can be a result, so what a step costs is its
+        // dependent memory round trips. The stream keeps a 64-entry window of the list's table rows in registers (lane j:
+        // {block_max, end offset} and the block weight of entry s_first + j; lane 0 is the row BEFORE the first block the
+        // window can serve, whose block_max / end offset give that block's base / start): "which block is next" is a ballot
+        // over registers, a block's table words cost no load, and the bytes of the block that will be taken after the
+        // current one are requested while the current one is still being worked on (pf_d0 / pf_d1: 512 B, two dwords per lane).
+        const bool stream0 = !cx.is_pef() && cx.skip;
+        const uint2* const tab0 = stream0 ? cx.skip + cx.m(0, M_PBASE) : nullptr;
+        const uint8_t* data0 = nullptr;
+        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
+        uint2 s_e = make_uint2(0xFFFFFFFFu, 0u);
+        float s_w = 0.f;
+        auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
+            s_first = first;
+            const uint32_t idx = first + lane;
+            s_e = make_uint2(0xFFFFFFFFu, 0u);
+            s_w = 0.f;
+            if (idx < u.blk_end) {
+                s_e = tab0[idx];
+                if (RANKED && w0tab) s_w = w0tab[idx];
+            }
+        };
+        // blocks >= from of the window that are worth a visit: inside the unit and (ranked, once bounds can prune) able to
+        // hold a document that enters the heap going by the block's weight + the other lists' list maxima
+        auto s_live = [&](uint32_t from) __attribute__((always_inline)) -> uint64_t {
+            const uint32_t idx = s_first + lane;
+            bool ok = idx >= from && idx < u.blk_end && (lane > 0 || idx == 0);
+            if constexpr (RANKED) {
+                if (bmw && can_prune()) {
+                    const float qw0 = __uint_as_float(cx.m(0, M_QW)), suf0 = __uint_as_float(cx.m(0, M_SUF));
+                    ok = ok && tk.would_enter((qw0 * s_w + suf0) * BOUND_SLACK);
+                }
+            }
+            return ballot(ok);
+        };
+        auto s_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t { // first block >= from worth a visit, or blk_end
+            for (;;) {
+                if (from >= u.blk_end) return u.blk_end;
+                const uint64_t hit = s_live(from);
+                if (hit) return s_first + (uint32_t)__builtin_ctzll(hit);
+                if (s_first + 64 >= u.blk_end) return u.blk_end;
+                s_fill(s_first + 63);
+                from = from > s_first + 1 ? from : s_first + 1;
+            }
+        };
+        if (stream0) {
+            const uint8_t* maxs0 = cx.ptr(0, M_MAXS_LO);
+            const uint32_t nb0 = cx.m(0, M_NB);
+            data0 = maxs0 + 4ull * nb0 + 4ull * (nb0 - 1);
+            s_fill(u.blk_begin ? u.blk_begin - 1 : 0);
+        }
         // list 0 moves on: `want` = first block with block_max >= lo (or the unit's first block)
         uint32_t want = u.blk_begin;
         bool have_bi = false;
@@ -344,7 +399,52 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         bool need0 = true;
         while (!finished) {
             ++cx.s_rounds;
-            if (need0 || lo > cx.m(0, M_BMAX)) { // list 0 supplies the candidates of this round
+            if (stream0 && (need0 || lo > cx.m(0, M_BMAX))) { // list 0 supplies the candidates of this round
+                // (lo never exceeds block_max + 1 of list 0's block -- the window is cut at it -- so the next block with
+                // block_max >= lo is simply the next one)
+                const uint32_t from = need0 ? u.blk_begin : cx.m(0, M_CUR) + 1;
+                if (from >= u.blk_end) break;
+                cx.s_bm_examined += 1;
+                cx.s_bytes += 4;
+                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) adopt_floor();
+                const uint32_t blk2 = s_next(from);
+                if (blk2 >= u.blk_end) break;
+                const uint32_t f = blk2 - s_first, fp = f ? f - 1 : 0;
+                bi0.bmax = bcast(s_e.x, f);
+                bi0.next_ep = bcast(s_e.y, f);
+                bi0.base = blk2 ? bcast(s_e.x, fp) + 1u : 0u;
+                bi0.ep = blk2 ? bcast(s_e.y, fp) : 0u;
+                const bool staged = pf_blk == blk2;
+                if (staged) { // the block's bytes were requested a block ago: from registers into the staging window
+                    const uint8_t* p = data0 + bi0.ep;
+                    cx.win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
+                    cx.win.nbytes = 512;
+                    cx.win.st[lane] = pf_d0;
+                    cx.win.st[lane + 64] = pf_d1;
+                    wave_sync();
+                }
+                cx.decode_docs(0, blk2, &bi0, staged);
+                need0 = false;
+                { // request the bytes of the block that is next as things stand (the heap may still rule it out later)
+                    const uint64_t nx = s_live(blk2 + 1);
+                    pf_blk = 0xFFFFFFFFu;
+                    if (nx) {
+                        const uint32_t fn = (uint32_t)__builtin_ctzll(nx);
+                        const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e.y, fn - 1)) & ~(uintptr_t)3);
+                        pf_d0 = g[lane];
+                        pf_d1 = g[lane + 64];
+                        pf_blk = s_first + fn;
+                    }
+                }
+                if constexpr (!RANKED) {
+                    if (use_rmw) { // once per block of list 0: who can be a member of every other list at all
+                        const uint32_t n0c = L.docs[0][lane], n1c = L.docs[0][lane + 64];
+                        uint32_t ql, qh;
+                        okm0 = ballot(rmw_gather(n0c, n0c != 0xFFFFFFFFu, ql, qh));
+                        okm1 = ballot(rmw_gather(n1c, n1c != 0xFFFFFFFFu, ql, qh));
+                    }
+                }
+            } else if (need0 || lo > cx.m(0, M_BMAX)) { // (freq_index layouts, or no skip table: the search-based form)
                 const bool tabbed = META::SKIPTAB && !cx.is_pef() && cx.skip;
                 if (!need0) {
                     const uint32_t cur = cx.m(0, M_CUR);
@@ -354,7 +454,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     cx.s_bytes += 4ull * (want - cur);
                 }
                 if (want >= u.blk_end) break;
-                if (shared_floor) adopt_floor();
+                // (the shared histogram costs an L2 round trip: consulted every DS2I_FLOOR_EVERY-th block of list 0)
+                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) adopt_floor();
                 const uint32_t blk2 = skip_list0(want);
                 if (blk2 >= u.blk_end) break;
                 cx.decode_docs(0, blk2, (have_bi && blk2 == want) ? &bi0 : nullptr);
@@ -387,10 +488,32 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (sf || nt == 1) {
                     const uint32_t cur0 = cx.m(0, M_CUR);
                     if (part_blk != cur0) { // once per block of list 0: its freqs, the norm_lens and the list-0 term scores
-                        if (!cx.freqs_ready(0)) cx.decode_freqs(0);
-                        PT_BEGIN(cx);
                         const float qw0 = __uint_as_float(cx.m(0, M_QW));
                         bool v0 = c0 != 0xFFFFFFFFu, v1 = c1 != 0xFFFFFFFFu;
+                        float r0 = __uint_as_float(cx.m(0, M_SUF)), r1 = r0;
+                        if (sf && use_rmw) {
+                            // Range tables first, with the BLOCK's weight standing in for the candidates' list-0 scores: most
+                            // blocks of the driving list hold no document that is both inside every other list's ranges and
+                            // able to enter the heap -- those are left without decoding their freqs or touching a norm_len.
+                            const float wblk = qw0 * (stream0 ? __uint_as_float(bcast(__float_as_uint(s_w), cur0 - s_first))
+                                                              : w0tab[cur0]); // (uniform load, in flight with the gathers)
+                            v0 = rmw_gather(c0, v0, ql0, qh0);
+                            v1 = rmw_gather(c1, v1, ql1, qh1);
+                            r0 = rmw_rest(ql0, qh0, 0);
+                            r1 = rmw_rest(ql1, qh1, 0);
+                            v0 = v0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
+                            v1 = v1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+                            if (!(ballot(v0) | ballot(v1))) {
+                                if (hi == 0xFFFFFFFFu) break;
+                                lo = hi + 1;
+                                continue;
+                            }
+                            L.qb[lane] = ql0;
+                            L.qb[lane + 64] = ql1;
+                            if constexpr (TMAX > 4) { L.qb2[lane] = qh0; L.qb2[lane + 64] = qh1; }
+                        }
+                        if (!cx.freqs_ready(0)) cx.decode_freqs(0);
+                        PT_BEGIN(cx);
                         const uint32_t f0 = L.freqs[0][lane], f1 = L.freqs[0][lane + 64];
                         if (sf) {
                             // The 4-byte norm_len gather is the path's largest source of memory traffic (a 64-byte
@@ -398,18 +521,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             // score: a posting whose bound (shortest document of the collection) cannot reach the heap
                             // is dropped before its norm_len is fetched. The heap only tightens, so the verdict holds
                             // for every later round of this block (-inf marks the dropped postings).
-                            // With range tables the other lists' part of the bound is per candidate (and a candidate
-                            // outside some list's ranges is dropped whatever the heap says).
-                            float r0 = __uint_as_float(cx.m(0, M_SUF)), r1 = r0;
-                            if (use_rmw) {
-                                v0 = rmw_gather(c0, v0, ql0, qh0);
-                                v1 = rmw_gather(c1, v1, ql1, qh1);
-                                r0 = rmw_rest(ql0, qh0, 0);
-                                r1 = rmw_rest(ql1, qh1, 0);
-                                L.qb[lane] = ql0;
-                                L.qb[lane + 64] = ql1;
-                                if constexpr (TMAX > 4) { L.qb2[lane] = qh0; L.qb2[lane + 64] = qh1; }
-                            }
+                            // With range tables the other lists' part of the bound is per candidate (r0 / r1 above).
                             v0 = v0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + r0) * BOUND_SLACK);
                             v1 = v1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + r1) * BOUND_SLACK);
                         }

@@ -173,6 +173,38 @@ def _union_topk_equals_oracle(gidx, oidx, queries, nsample=32, k=10, ops=("wand"
         np.testing.assert_allclose(gt[f], ot[f], rtol=RTOL, err_msg=op)
 
 
+@pytest.mark.parametrize("codec", CODECS)
+def test_pruning_tables_are_exact_maxima(coll, images, codec):
+    """The upload-time tables ranked_and prunes with, against numpy on the raw lists, for every index kind: bmw[b] is
+    exactly the largest bm25::doc_term_weight of block b (bit for bit: it is computed with the scoring arithmetic), and
+    every byte of the doc-id-range table is 0 iff its range holds no posting of the list, else an upper bound (<= 1/255
+    of the list maximum above) of the largest weight in the range."""
+    from helpers import doc_term_weight
+    gidx = d.Index(codec, images[0][codec], images[1])
+    for t in list(range(0, 40)) + list(range(40, len(coll.lists), 7)):
+        docs, freqs = coll.lists[t]
+        w = doc_term_weight(freqs, coll.norm_lens[docs])
+        bw = gidx.block_weights(t)
+        if codec in d.BLOCK_CODECS:
+            nb = (len(docs) + 127) // 128
+            assert len(bw) == nb
+            exp = np.array([w[b * 128:(b + 1) * 128].max() for b in range(nb)], dtype=np.float32)
+            assert np.array_equal(bw, exp), (codec, t)
+        else:  # chunks of <= 128 postings cut at partition boundaries: the maxima of consecutive runs, in order
+            assert len(bw) >= (len(docs) + 127) // 128 and np.float32(bw.max()) == np.float32(w.max()), (codec, t)
+        tab, sh, mx = gidx.range_table(t)
+        assert len(tab) == (coll.num_docs >> sh) + 1 and np.float32(mx) == np.float32(w.max())
+        rmax = np.zeros(len(tab), dtype=np.float32)
+        np.maximum.at(rmax, docs >> sh, w)
+        occupied = np.zeros(len(tab), dtype=bool)
+        occupied[docs >> sh] = True
+        assert np.array_equal(tab != 0, occupied), (codec, t)
+        bound = tab.astype(np.float32) * np.float32(mx / 255.0)
+        assert np.all(bound[occupied] * np.float32(1 + 2 ** -17) >= rmax[occupied]), (codec, t)
+        assert np.all(bound[occupied] <= rmax[occupied] + np.float32(mx) * np.float32(1.01 / 255.0)), (codec, t)
+        assert 2 * len(docs) <= len(tab) or sh == 0   # DS2I_RMW_G = 2 entries per posting at least (or one per doc-id)
+
+
 def test_block_mixed_image_holds_all_three_block_types(images):
     """The block_mixed index every test of this module runs on dispatches to all three decoders: > 5 % of its full
     blocks are OptPFor, > 5 % VarInt-G8IU, > 5 % interpolative (docs parts; the freqs parts mix too)."""
