@@ -98,7 +98,7 @@ def lib():
         L.ds2i_hybrid_free.restype = None
         L.ds2i_hip_calibration_read.argtypes = [vp, u64p]
         L.ds2i_hip_list_block_weights.argtypes = [vp, C.c_uint32, vp, C.c_uint64, u64p]
-        L.ds2i_hip_list_range_table.argtypes = [vp, C.c_uint32, vp, C.c_uint64, u64p, u32p, fp]
+        L.ds2i_hip_list_range_table.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p, u32p, fp]
         L.ds2i_hip_selftest_scan.argtypes = [C.c_int, vp, vp, C.c_uint32]
         L.ds2i_hip_selftest_bm25.argtypes = [C.c_int, vp, vp, vp, C.c_uint32]
         L.ds2i_hip_synth_encode.argtypes = [C.c_int, C.POINTER(SynthParams), C.c_int, C.POINTER(vp), C.POINTER(vp), u64p,
@@ -422,7 +422,7 @@ class Batch:
         return st, n.value
 
     def phase_cycles(self, cls):
-        names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert")
+        names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert", "stream", "prefetch", "floor", "unit")
         out = np.zeros(len(names), dtype=np.uint64)
         _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), len(names)))
         return dict(zip(names, out.tolist()))
@@ -556,11 +556,11 @@ class Index:
         _check(lib().ds2i_hip_list_block_weights(self._h, term, _ptr(out), len(out), C.byref(n)))
         return out[:n.value].copy()
 
-    def range_table(self, term):
-        """(bytes, shift, list_max) of one list's doc-id-range table (ds2i_hip_list_range_table)"""
+    def range_table(self, term, level=1):
+        """(bytes, shift, list_max) of one level of one list's doc-id-range table (ds2i_hip_list_range_table)"""
         n, sh, mx = C.c_uint64(), C.c_uint32(), C.c_float()
         out = np.zeros(int(self.num_docs()) + 64, dtype=np.uint8)
-        _check(lib().ds2i_hip_list_range_table(self._h, term, _ptr(out), len(out), C.byref(n), C.byref(sh), C.byref(mx)))
+        _check(lib().ds2i_hip_list_range_table(self._h, term, level, _ptr(out), len(out), C.byref(n), C.byref(sh), C.byref(mx)))
         return out[:n.value].copy(), int(sh.value), float(mx.value)
 
     def query_batch(self, op, queries, k=10):

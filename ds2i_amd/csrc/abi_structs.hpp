@@ -30,7 +30,7 @@ struct QTerm {
 };
 static_assert(sizeof(QTerm) == 80, "QTerm is an 80-byte device record");
 
-enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_PROLOG, PH_PROBE, PH_INSERT, PH_COUNT };
+enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_PROLOG, PH_PROBE, PH_INSERT, PH_STREAM, PH_PREFETCH, PH_FLOOR, PH_UNIT, PH_COUNT };
 struct Stats {
     unsigned long long docs_blocks, freqs_blocks, block_max_examined, algorithmic_bytes, postings_scored, rounds;
     unsigned long long phase_cycles[PH_COUNT]; // summed over waves; only filled with -DDS2I_PHASE_TIMING
@@ -95,6 +95,9 @@ struct BatchArgs {
     // the range relative to the list's maximum. Direct addressing by doc-id: a candidate's bound in every other list
     // costs one byte gather per list and no search (cf. the doc-id-oriented block-max indexes of Dimopoulos, Nepomnyachiy
     // & Suel, WSDM'13). shift_t is chosen per list so that the table holds DS2I_RMW_G..2*DS2I_RMW_G entries per posting.
+    // Each table is followed by two coarser levels of itself (level l + 1 entry e = max of level l entries 64 e .. 64 e + 63;
+    // every level padded to 64 bytes): the largest entry over the doc-id span of a whole BLOCK of the driving list is found
+    // in <= 16 bytes of the level whose entries are wide enough, and bounds every candidate of that block at once.
     const uint8_t* rmw;
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
@@ -105,6 +108,20 @@ struct BatchArgs {
 // upload-time pass computing bmw[] (k_block_max_weights): one wave per item = <=64 consecutive blocks of one list
 struct BmwItem {
     uint32_t list, blk_begin;
+};
+// geometry of one list's range-table levels, derived from the collection size and the list's shift alone
+struct RmwLevels {
+    uint32_t e[3];   // entries of level 1, 2, 3
+    uint64_t off[3]; // byte offset of each level from the start of the list's table
+    __host__ __device__ RmwLevels(uint32_t num_docs, uint32_t shift) {
+        e[0] = (num_docs >> shift) + 1u;
+        e[1] = (e[0] + 63u) >> 6;
+        e[2] = (e[1] + 63u) >> 6;
+        off[0] = 0;
+        off[1] = ((uint64_t)e[0] + 63u) & ~63ull;
+        off[2] = off[1] + (((uint64_t)e[1] + 63u) & ~63ull);
+    }
+    __host__ __device__ uint64_t bytes() const { return off[2] + (((uint64_t)e[2] + 63u) & ~63ull); }
 };
 struct BmwArgs {
     const uint8_t* arena;
@@ -119,6 +136,8 @@ struct BmwArgs {
     float* bmw;             // out: one per block
     unsigned int* list_bmw; // out: per list max (float bits; weights are >= 0 so the bit patterns order like the values)
     uint8_t* rmw;           // second pass (k_range_max_weights): the range tables; lists[].max_weight = the list maximum of pass 1
+    uint32_t rmw_level;     // 0: fill level 1 from the postings; 1 / 2: items = {list, first entry of a 4096-entry run of level
+                            // rmw_level + 1}, each entry the maximum of 64 entries of the level below
 };
 
 struct MergeArgs {

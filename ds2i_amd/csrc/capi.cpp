@@ -159,10 +159,9 @@ int build_block_max_weights(ds2i_hip_index* x) {
     for (uint64_t t = 0; t < V; ++t) {
         uint32_t sh = 0;
         while (sh < 31 && (double)(x->num_docs >> (sh + 1)) >= G * (double)x->list_n[t]) ++sh;
-        const uint64_t entries = (x->num_docs >> sh) + 1;
         x->list_rmw_shift[t] = sh;
         x->list_rmw_off64[t] = (uint32_t)cursor;
-        cursor += (entries + 63) / 64;
+        cursor += ds2i_dev::RmwLevels((uint32_t)x->num_docs, sh).bytes() / 64; // level 1 + its two coarser levels
         if (cursor >= (1ull << 32)) return DS2I_OK; // > 256 GB of tables: not on this device; run without them
     }
     size_t free_b = 0, total_b = 0;
@@ -179,7 +178,23 @@ int build_block_max_weights(ds2i_hip_index* x) {
     }
     HIP_OK(hipMemcpyAsync(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice, x->stream[0]));
     a.rmw = x->d_rmw;
+    a.rmw_level = 0;
     HIP_OK(ds2i_launch_block_max_weights(&a, grid, x->stream[0]));
+    for (uint32_t lvl = 1; lvl <= 2; ++lvl) { // level lvl + 1 = maxima of 64 entries of level lvl, 4096 entries per item
+        items.clear();
+        for (uint64_t t = 0; t < V; ++t) {
+            const ds2i_dev::RmwLevels g((uint32_t)x->num_docs, x->list_rmw_shift[t]);
+            for (uint32_t e = 0; e < g.e[lvl]; e += 4096) items.push_back(ds2i_dev::BmwItem{(uint32_t)t, e});
+        }
+        ds2i_dev::BmwItem* d_it = nullptr;
+        HIP_OK(tmp.alloc(&d_it, sizeof(ds2i_dev::BmwItem) * items.size()));
+        HIP_OK(hipMemcpyAsync(d_it, items.data(), sizeof(ds2i_dev::BmwItem) * items.size(), hipMemcpyHostToDevice, x->stream[0]));
+        HIP_OK(hipStreamSynchronize(x->stream[0])); // (`items` is reused by the next level)
+        a.items = d_it;
+        a.nitems = (uint32_t)items.size();
+        a.rmw_level = lvl;
+        HIP_OK(ds2i_launch_block_max_weights(&a, (unsigned)std::min<size_t>(items.size(), (size_t)x->num_cus * 64), x->stream[0]));
+    }
     HIP_OK(hipStreamSynchronize(x->stream[0]));
     x->extra_bytes += bytes;
     return DS2I_OK;
@@ -470,20 +485,22 @@ int ds2i_hip_list_block_weights(ds2i_hip_index* idx, uint32_t term, float* out, 
     return DS2I_OK;
 }
 
-int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint8_t* out, uint64_t capacity, uint64_t* entries,
-                              uint32_t* shift, float* list_max) {
+int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint32_t level, uint8_t* out, uint64_t capacity,
+                              uint64_t* entries, uint32_t* shift, float* list_max) {
     if (!idx || !entries || !shift || !list_max) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: null argument");
     if (term >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
     *entries = 0;
     *shift = 0;
     *list_max = 0.f;
     if (!idx->d_rmw) return DS2I_OK;
-    *shift = idx->list_rmw_shift[term];
-    *entries = (idx->num_docs >> *shift) + 1;
+    if (level < 1 || level > 3) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: level must be 1, 2 or 3");
+    const ds2i_dev::RmwLevels g((uint32_t)idx->num_docs, idx->list_rmw_shift[term]);
+    *shift = idx->list_rmw_shift[term] + 6 * (level - 1);
+    *entries = g.e[level - 1];
     *list_max = idx->list_bmw[term];
     if (!out || capacity < *entries) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: capacity too small");
     HIP_OK(hipSetDevice(idx->device));
-    HIP_OK(hipMemcpy(out, idx->d_rmw + 64ull * idx->list_rmw_off64[term], *entries, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out, idx->d_rmw + 64ull * idx->list_rmw_off64[term] + g.off[level - 1], *entries, hipMemcpyDeviceToHost));
     return DS2I_OK;
 }
 

@@ -252,7 +252,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
     // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
     static const char* uf = std::getenv("DS2I_UNIT_FACTOR");
-    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : 16.0;
+    // With range tables a ranked conjunction is cheap per block and the parts of a split query each pay for warming up
+    // their own heap: coarser units win (measured on the GOV2-scale batch, queries/s: factor 16: 355 k, 8: 344 k,
+    // 4 with the many-list classes cut 4x finer: 430-457 k, 2: 251 k)
+    const bool rmw_units = ranked && conj && idx->d_rmw;
+    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? 4.0 : 16.0;
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
         u.q = q;
@@ -270,7 +274,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         static const char* ud = std::getenv("DS2I_UNIT_DIV");
         static const double unit_div = ud && std::atof(ud) > 0 ? std::atof(ud) : 4.0;
         const bool rmw_cost = ranked && conj && idx->d_rmw; // (cost already counts the class's time per block)
-        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 || rmw_cost ? 1.0 : unit_div));
+        static const char* udr = std::getenv("DS2I_UNIT_DIV_RMW");
+        static const double unit_div_rmw = udr && std::atof(udr) > 0 ? std::atof(udr) : 4.0;
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div));
         ++b->nqcls[c];
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);

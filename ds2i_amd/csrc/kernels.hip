@@ -351,7 +351,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         const uint8_t* data0 = nullptr;
         uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
         uint2 s_e = make_uint2(0xFFFFFFFFu, 0u);
-        float s_w = 0.f;
+        float s_w = 0.f, s_rb = 0.f;
+        bool s_none = false; // some other list has no posting at all inside the block's doc-id span: nothing to intersect
         auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
             s_first = first;
             const uint32_t idx = first + lane;
@@ -361,16 +362,57 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 s_e = tab0[idx];
                 if (RANKED && w0tab) s_w = w0tab[idx];
             }
+            s_none = false;
+            {
+                s_rb = RANKED ? __uint_as_float(cx.m(0, M_SUF)) : 0.f; // what the other lists can add to a document of the block: their list maxima, or
+                if (use_rmw) {
+                    // ... with range tables the largest entry each of them has over the block's own doc-id span [base, block_max],
+                    // read from the level of the table whose entries are wide enough for <= 16 of them to cover the span
+                    // (a lane serves the block of its table row; 16 independent byte loads per list, once per 63 blocks)
+                    const uint32_t prev_max = (uint32_t)__shfl_up((int)s_e.x, 1);
+                    const uint32_t base = (lane == 0) ? 0u : prev_max + 1u, top = s_e.x;
+                    const bool row = idx < u.blk_end && (lane > 0 || idx == 0) && top != 0xFFFFFFFFu && base <= top;
+                    float acc = 0.f;
+                    auto one_list = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr uint32_t j = decltype(jc)::value;
+                        if (j >= nt) return;
+                        const uint32_t sh = cx.m(j, M_RSHIFT);
+                        const RmwLevels g(a.num_docs, sh);
+                        const uint8_t* tb = rmw + 64ull * cx.m(j, M_RBASE);
+                        uint32_t best = 255u; // (the list maximum)
+                        if (row) {
+                            uint32_t lsh = sh, lvl = 0;
+                            while (lvl < 2 && (top >> lsh) - (base >> lsh) >= 16u) { lsh += 6; ++lvl; }
+                            const uint32_t lo = base >> lsh, hi = top >> lsh;
+                            if (hi - lo < 16u) {
+                                const uint8_t* lp = tb + g.off[lvl] + lo;
+                                const uint32_t cnt = hi - lo + 1u;
+                                uint32_t m = 0;
+#pragma unroll
+                                for (uint32_t k = 0; k < 16; ++k) {
+                                    const uint32_t v = k < cnt ? (uint32_t)lp[k] : 0u;
+                                    m = m > v ? m : v;
+                                }
+                                best = m;
+                            }
+                        }
+                        s_none = s_none || best == 0u;
+                        if constexpr (RANKED) acc = acc + __uint_as_float(cx.m(j, M_RSCALE)) * (float)best;
+                    };
+                    static_loop_down<RL, 1>(one_list);
+                    s_rb = acc;
+                }
+            }
         };
         // blocks >= from of the window that are worth a visit: inside the unit and (ranked, once bounds can prune) able to
         // hold a document that enters the heap going by the block's weight + the other lists' list maxima
         auto s_live = [&](uint32_t from) __attribute__((always_inline)) -> uint64_t {
             const uint32_t idx = s_first + lane;
-            bool ok = idx >= from && idx < u.blk_end && (lane > 0 || idx == 0);
+            bool ok = idx >= from && idx < u.blk_end && (lane > 0 || idx == 0) && !s_none;
             if constexpr (RANKED) {
                 if (bmw && can_prune()) {
-                    const float qw0 = __uint_as_float(cx.m(0, M_QW)), suf0 = __uint_as_float(cx.m(0, M_SUF));
-                    ok = ok && tk.would_enter((qw0 * s_w + suf0) * BOUND_SLACK);
+                    const float qw0 = __uint_as_float(cx.m(0, M_QW));
+                    ok = ok && tk.would_enter((qw0 * s_w + s_rb) * BOUND_SLACK);
                 }
             }
             return ballot(ok);
@@ -397,8 +439,14 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         typename decltype(cx)::BlockInfo bi0;
         bool finished = false;
         bool need0 = true;
+#ifdef DS2I_PHASE_TIMING
+        cx.s_phase[PH_UNIT] += __builtin_readcyclecounter() - unit_t0;
+#endif
         while (!finished) {
             ++cx.s_rounds;
+#ifdef DS2I_PHASE_TIMING
+            const unsigned long long round_t0 = __builtin_readcyclecounter(); // PH_PROLOG = rounds that end at the range-table test
+#endif
             if (stream0 && (need0 || lo > cx.m(0, M_BMAX))) { // list 0 supplies the candidates of this round
                 // (lo never exceeds block_max + 1 of list 0's block -- the window is cut at it -- so the next block with
                 // block_max >= lo is simply the next one)
@@ -406,7 +454,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (from >= u.blk_end) break;
                 cx.s_bm_examined += 1;
                 cx.s_bytes += 4;
-                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) adopt_floor();
+                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
+                PT_BEGIN(cx);
                 const uint32_t blk2 = s_next(from);
                 if (blk2 >= u.blk_end) break;
                 const uint32_t f = blk2 - s_first, fp = f ? f - 1 : 0;
@@ -423,9 +472,11 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     cx.win.st[lane + 64] = pf_d1;
                     wave_sync();
                 }
+                PT_END(cx, PH_STREAM);
                 cx.decode_docs(0, blk2, &bi0, staged);
                 need0 = false;
                 { // request the bytes of the block that is next as things stand (the heap may still rule it out later)
+                    PT_BEGIN(cx);
                     const uint64_t nx = s_live(blk2 + 1);
                     pf_blk = 0xFFFFFFFFu;
                     if (nx) {
@@ -435,6 +486,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                         pf_d1 = g[lane + 64];
                         pf_blk = s_first + fn;
                     }
+                    PT_END(cx, PH_PREFETCH);
                 }
                 if constexpr (!RANKED) {
                     if (use_rmw) { // once per block of list 0: who can be a member of every other list at all
@@ -495,6 +547,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             // Range tables first, with the BLOCK's weight standing in for the candidates' list-0 scores: most
                             // blocks of the driving list hold no document that is both inside every other list's ranges and
                             // able to enter the heap -- those are left without decoding their freqs or touching a norm_len.
+                            PT_BEGIN(cx);
                             const float wblk = qw0 * (stream0 ? __uint_as_float(bcast(__float_as_uint(s_w), cur0 - s_first))
                                                               : w0tab[cur0]); // (uniform load, in flight with the gathers)
                             v0 = rmw_gather(c0, v0, ql0, qh0);
@@ -503,7 +556,12 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             r1 = rmw_rest(ql1, qh1, 0);
                             v0 = v0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
                             v1 = v1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+                            PT_END(cx, PH_PROBE);
                             if (!(ballot(v0) | ballot(v1))) {
+#ifdef DS2I_PHASE_TIMING
+                                cx.s_phase[PH_PROLOG] += __builtin_readcyclecounter() - round_t0;
+                                cx.s_phase[PH_INSERT] += 1; // (count of such rounds)
+#endif
                                 if (hi == 0xFFFFFFFFu) break;
                                 lo = hi + 1;
                                 continue;
@@ -1641,6 +1699,32 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
     for (uint32_t item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const BmwItem it = a.items[item];
         const QTerm t = a.lists[it.list];
+        if (a.rmw && a.rmw_level) { // coarser levels of the range table: entry e = max of the 64 entries below it
+            const RmwLevels g(a.num_docs, t.rmw_shift);
+            const uint8_t* src = a.rmw + 64ull * t.rmw_off64 + g.off[a.rmw_level - 1];
+            uint8_t* dst = a.rmw + 64ull * t.rmw_off64 + g.off[a.rmw_level];
+            const uint32_t end = it.blk_begin + 4096u < g.e[a.rmw_level] ? it.blk_begin + 4096u : g.e[a.rmw_level];
+            for (uint32_t e = it.blk_begin + lane; e < end; e += 64) { // (every level is zero-padded to 64 bytes: no tail case)
+                const uint4* p = (const uint4*)(src + 64ull * e);
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 v = p[k];
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t x = w[j];
+                        uint32_t b = x & 255u, c = (x >> 8) & 255u, d = (x >> 16) & 255u, f = x >> 24;
+                        b = b > c ? b : c;
+                        d = d > f ? d : f;
+                        b = b > d ? b : d;
+                        m = m > b ? m : b;
+                    }
+                }
+                dst[e] = (uint8_t)m;
+            }
+            continue;
+        }
         cx.bind(0, t);
         const uint32_t nb = cx.m(0, M_NB);
         const uint32_t end = it.blk_begin + 64u < nb ? it.blk_begin + 64u : nb;

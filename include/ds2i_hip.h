@@ -194,12 +194,13 @@ int ds2i_hip_synth_encode(int device, const struct ds2i_synth_params* p, int thr
 /* Inspection of the upload-time pruning tables of one list (test hooks; both tables exist only with wand data).
  * block weights: bmw[b] = max over block b's postings of bm25::doc_term_weight(freq, norm_len[doc]) (the block-level
  * analogue of wand_data's max_term_weight, wand_data.hpp:40-52); out gets *nblocks floats (capacity in floats).
- * range table: byte e covers the doc-ids [e << *shift, (e + 1) << *shift): 0 = no posting of the list there, else
- * entry * (*list_max / 255) >= the largest doc_term_weight of the range; out gets *entries bytes. A table that was
- * not built (no wand data, DS2I_NO_BMW / DS2I_NO_RMW) reports 0 entries. */
+ * range table, level 1..3: byte e covers the doc-ids [e << *shift, (e + 1) << *shift): 0 = no posting of the list there,
+ * else entry * (*list_max / 255) >= the largest doc_term_weight of the range; level l + 1 halves the resolution six
+ * times (its entry e is the maximum of entries 64 e .. 64 e + 63 of level l). out gets *entries bytes. A table that
+ * was not built (no wand data, DS2I_NO_BMW / DS2I_NO_RMW) reports 0 entries. */
 int ds2i_hip_list_block_weights(ds2i_hip_index* idx, uint32_t term, float* out, uint64_t capacity, uint64_t* nblocks);
-int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint8_t* out, uint64_t capacity, uint64_t* entries,
-                              uint32_t* shift, float* list_max);
+int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint32_t level, uint8_t* out, uint64_t capacity,
+                              uint64_t* entries, uint32_t* shift, float* list_max);
 
 /* profiling aid: streams the whole index arena once with the decoders' load shape (calibrates FETCH_SIZE) */
 int ds2i_hip_calibration_read(ds2i_hip_index* idx, uint64_t* bytes_read);

@@ -203,6 +203,14 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
         assert np.all(bound[occupied] * np.float32(1 + 2 ** -17) >= rmax[occupied]), (codec, t)
         assert np.all(bound[occupied] <= rmax[occupied] + np.float32(mx) * np.float32(1.01 / 255.0)), (codec, t)
         assert 2 * len(docs) <= len(tab) or sh == 0   # DS2I_RMW_G = 2 entries per posting at least (or one per doc-id)
+        prev = tab
+        for level in (2, 3):  # the coarser levels: maxima of 64 entries of the level below
+            up, shl, _ = gidx.range_table(t, level)
+            assert shl == sh + 6 * (level - 1) and len(up) == (len(prev) + 63) // 64
+            padded = np.zeros(len(up) * 64, dtype=np.uint8)
+            padded[:len(prev)] = prev
+            assert np.array_equal(up, padded.reshape(-1, 64).max(axis=1)), (codec, t, level)
+            prev = up
 
 
 def test_block_mixed_image_holds_all_three_block_types(images):
