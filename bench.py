@@ -49,8 +49,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mixed-policy", default="optimised", choices=["optimised", "fixed"],
                     help="block_mixed only: ds2i_hybrid optimiser (default) or the fixed per-block size policy")
     ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2", "cw09"])
@@ -159,6 +159,7 @@ def main():
         tickets, results, cls_ms = [], [], [[0.0, 0] for _ in range(NCLS)]
         def reap():
             r = pipe.wait(tickets.pop(0))
+            done_at.append(time.perf_counter())
             if collect:
                 results.append(r)
                 for c in range(NCLS):
@@ -174,14 +175,22 @@ def main():
             reap()
         return results, cls_ms
 
+    done_at = []
     _, warm_ms = run_stream(0, args.warmup, True)
     barrier()
     t0 = time.perf_counter()
+    done_at = []
     results, cls_ms = run_stream(args.warmup, args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sh.max_over_ranks(dist, elapsed)
     count, topk, tlen = results[0]
+    # spread of the step time: intervals between consecutive batch completions in the pipelined region (the first `depth`
+    # completions include the ramp-up of the pipeline and are left out when there are enough steps)
+    gaps = np.diff(np.array([t0] + done_at))
+    steady = gaps[args.depth:] if len(gaps) > 2 * args.depth else gaps
+    step_spread = {"min": 1e3 * float(steady.min()), "median": 1e3 * float(np.median(steady)), "max": 1e3 * float(steady.max()),
+                   "n": int(len(steady))}
 
     # ---- untimed extras: kernel-resident rate (one prepared batch re-run, round-1's figure) and the instrumented pass
     batch = d.Batch(idx, args.op, my_queries[args.warmup], k=10)
@@ -241,7 +250,7 @@ def main():
     out = {
         "metric": "queries/sec (%s, %s)" % (args.op, args.codec), "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "mean_us_per_query": 1e6 / qps,
+        "mean_us_per_query": 1e6 / qps, "step_ms_spread": step_spread,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
         "timing": "end-to-end over %d distinct batches through ds2i_hip_pipeline_submit/wait (host planning + H2D + kernels + D2H), "
                   "%d in flight" % (args.steps, args.depth),
@@ -362,7 +371,10 @@ def main():
         per_class.append({"kernel": kernel_name(c), "queries": nqc, "ms_per_launch": mean_ms[c], "ms_alone": res_ms[c] / args.steps,
                           "algorithmic_bytes": int(bytes_c) if bytes_c is not None else None,
                           "achieved_gbs": (bytes_c / (mean_ms[c] * 1e-3) / 1e9) if bytes_c is not None else None,
-                          "device_counted_bytes": int(cls_stats[c][0].algorithmic_bytes)})
+                          "device_counted_bytes": int(cls_stats[c][0].algorithmic_bytes),
+                          "postings_scored": int(cls_stats[c][0].postings_scored),
+                          "docs_blocks_decoded": int(cls_stats[c][0].docs_blocks_decoded),
+                          "freqs_blocks_decoded": int(cls_stats[c][0].freqs_blocks_decoded)})
     # dominant kernel = the class kernel that moves the most algorithmic bytes per launch. (Launch durations are not a
     # good criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched
     # to the length of the step by the big ones.)

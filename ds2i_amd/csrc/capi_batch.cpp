@@ -309,6 +309,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             static const bool scale_from_env = [] { // DS2I_DISJ_SCALE="a,b,c,d": A/B knob
                 const char* e = std::getenv("DS2I_DISJ_SCALE");
                 if (e) std::sscanf(e, "%lf,%lf,%lf,%lf", &disj_scale[0], &disj_scale[1], &disj_scale[2], &disj_scale[3]);
+                for (double& v : disj_scale) if (!(v > 0)) v = 1.0; // (a zero scale would divide by zero below)
                 return e != nullptr;
             }();
             (void)scale_from_env;
@@ -337,7 +338,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // stream, so finer is not better: DS2I_DYN_GROUP = granularity in lists, measured on the GOV2-scale wand batch
         // 0 (off) 60.6 k, 1: 60.0 k, 2: 62.4 k, 4: 61.0 k queries/s.
         static const char* dg = std::getenv("DS2I_DYN_GROUP");
-        static const uint32_t dyn_group = dg ? (uint32_t)std::atoi(dg) : 2u;
+        static const uint32_t dyn_group = dg ? (uint32_t)std::min(16, std::max(0, std::atoi(dg))) : 2u; // (a negative value would wrap)
         const uint32_t cls_lists = c == 0 ? 2u : c == 1 ? 4u : c == 2 ? 8u : 16u;
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
         static const char* dm = std::getenv("DS2I_DYN_MINCLS");
@@ -356,6 +357,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             uint32_t j = i;
             const uint32_t l = lists_of(b->order[c][i]);
             while (j < b->ncls[c] && lists_of(b->order[c][j]) == l) ++j;
+            // a group narrower than one of its queries would make the kernel answer that query with an empty result
+            for (uint32_t t = i; t < j; ++t) {
+                const uint32_t q = b->units[b->order[c][t]].q;
+                if (qoff[q + 1] - qoff[q] > l) return ds2i_set_error(DS2I_EINVAL, "internal: launch group has fewer list slots than a query of it");
+            }
             b->sub[c].push_back({i, j, l});
             i = j;
         }
@@ -726,12 +732,22 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     return DS2I_OK;
 }
 
+// A launch that failed part-way may have kernels of this slot in flight (the seed pass, some class kernels) with no
+// completion event recorded: wait for the device before the caller can reuse or free the slot's buffers. The error
+// being reported is kept (the drain's own status is secondary).
+static int drain_after_failure(ds2i_hip_batch* b, int rc) {
+    const std::string keep = ds2i_get_error();
+    (void)hipSetDevice(b->idx->device);
+    (void)hipDeviceSynchronize();
+    return ds2i_set_error(rc, keep.c_str());
+}
+
 int ds2i_hip_batch_run(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     if (!b) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_run: null batch");
     HIP_OK(hipSetDevice(b->idx->device));
     int rc = launch_batch(b);
-    if (!rc) rc = finish_batch(b, stats);
-    return rc;
+    if (rc) return drain_after_failure(b, rc);
+    return finish_batch(b, stats);
 }
 
 // GPU-side counterpart of profile_queries.cpp: per-block decode counts of the batch (input of the block_mixed
@@ -886,9 +902,10 @@ int ds2i_hip_pipeline_submit(ds2i_hip_pipeline* p, int op, uint32_t k, const uin
     HIP_OK(hipSetDevice(p->idx->device));
     ds2i_hip_batch* b = p->slots[slot];
     int rc = plan_batch(b, op, k, terms, query_offsets, nq, 0);
-    if (!rc) rc = upload_batch(b);
+    if (rc) return rc; // (nothing enqueued yet)
+    rc = upload_batch(b);
     if (!rc) rc = launch_batch(b);
-    if (rc) return rc;
+    if (rc) return drain_after_failure(b, rc); // the slot stays free, and nothing of it is still running
     p->busy[slot] = 1;
     p->slot_ticket[slot] = p->next_ticket;
     *ticket = p->next_ticket++;

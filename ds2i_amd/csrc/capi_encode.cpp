@@ -96,11 +96,12 @@ extern "C" int ds2i_hip_encode_index(int device, int index_kind, uint64_t num_do
     HIP_OK(hipMemcpy(d_list_in, list_offsets, 8 * (nlists + 1), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_blk_list, blk_list.data(), 4 * nblocks, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_list_blk0, list_blk0.data(), 4 * nlists, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1, e2, e3;
-    HIP_OK(hipEventCreate(&e0));
-    HIP_OK(hipEventCreate(&e1));
-    HIP_OK(hipEventCreate(&e2));
-    HIP_OK(hipEventCreate(&e3));
+    struct Events { // destroyed on every path out of the function
+        hipEvent_t e[4] = {};
+        ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    for (auto& x : evs.e) HIP_OK(hipEventCreate(&x));
+    const hipEvent_t e0 = evs.e[0], e1 = evs.e[1], e2 = evs.e[2], e3 = evs.e[3];
     EncArgsHost a{};
     a.docs = d_docs;
     a.freqs = d_freqs;
@@ -148,10 +149,6 @@ extern "C" int ds2i_hip_encode_index(int device, int index_kind, uint64_t num_do
     HIP_OK(hipEventElapsedTime(&ms_plan, e0, e1));
     HIP_OK(hipEventElapsedTime(&ms_write, e2, e3));
     if (device_ms) *device_ms = (double)ms_plan + ms_write;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
-    (void)hipEventDestroy(e3);
     try {
         ds2i_host::bytes_t lists(cursor);
         HIP_OK(hipMemcpy(lists.data(), d_out, cursor, hipMemcpyDeviceToHost));

@@ -13,10 +13,13 @@
 // Errors: the C ABI's negative codes become std::runtime_error (builders in the reference throw
 // std::invalid_argument / std::runtime_error too; its query path only asserts).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -181,6 +184,108 @@ private:
     std::vector<std::pair<uint32_t, uint32_t>> m_meta;
 };
 
+// ---- several devices of one node. The path shards by QUERY: every device holds a full replica of the
+// index (a GOV2-scale index is ~1 % of one MI355X's 288 GB), a batch is cut into contiguous slices, one per replica,
+// each slice runs on its device under its own host thread, and the answers are concatenated in order -- no exchange
+// between devices, no collective. The host-side analogue in the reference is profile_queries.cpp:21-39 (one thread
+// per core over disjoint query ranges). The same device may be listed more than once (two replicas on one GPU): the
+// answers are the same, which is what the single-GPU test of this class relies on.
+class gpu_index_set {
+public:
+    gpu_index_set(int index_kind, const void* image, size_t bytes, const void* wand, size_t wand_bytes,
+                  std::vector<int> const& devices) {
+        if (devices.empty()) throw std::invalid_argument("gpu_index_set: no devices");
+        m_replicas.resize(devices.size());
+        std::vector<std::string> errors(devices.size());
+        std::vector<std::thread> pool; // replicas are uploaded in parallel (PCIe links are per device)
+        for (size_t i = 0; i < devices.size(); ++i)
+            pool.emplace_back([&, i] {
+                try { m_replicas[i].reset(new gpu_index(index_kind, image, bytes, wand, wand_bytes, devices[i])); }
+                catch (std::exception const& e) { errors[i] = e.what(); }
+            });
+        for (auto& t : pool) t.join();
+        for (auto const& e : errors) if (!e.empty()) throw std::runtime_error(e);
+    }
+    size_t replicas() const { return m_replicas.size(); }
+    gpu_index const& replica(size_t i) const { return *m_replicas[i]; }
+    size_t size() const { return m_replicas[0]->size(); }
+    uint64_t num_docs() const { return m_replicas[0]->num_docs(); }
+    void warmup(size_t) const {}
+    gpu_index::document_enumerator operator[](size_t term) const { return (*m_replicas[0])[term]; }
+    // contiguous slice of a batch of n queries owned by replica r (ds2i_amd/sharding.py: query_slice)
+    static std::pair<size_t, size_t> slice(size_t n, size_t r, size_t parts) {
+        const size_t base = n / parts, extra = n % parts;
+        const size_t lo = r * base + std::min(r, extra);
+        return {lo, lo + base + (r < extra ? 1 : 0)};
+    }
+
+private:
+    std::vector<std::unique_ptr<gpu_index>> m_replicas;
+};
+
+// the query-operator concept over a replica set: same calls, same answers as gpu_query_op over one index
+template <int OP>
+class gpu_set_query_op {
+public:
+    explicit gpu_set_query_op(uint64_t k = 10) : m_k(k) {}
+    template <class WandData> gpu_set_query_op(WandData const&, uint64_t k) : m_k(k) {}
+    uint64_t operator()(gpu_index_set const& set, term_id_vec const& terms) {
+        std::vector<term_id_vec> one(1, terms);
+        return (*this)(set, one)[0];
+    }
+    std::vector<uint64_t> const& operator()(gpu_index_set const& set, std::vector<term_id_vec> const& queries) {
+        const size_t parts = set.replicas();
+        if (m_ops.size() != parts) m_ops.assign(parts, gpu_query_op<OP>(m_k));
+        std::vector<std::vector<term_id_vec>> slices(parts);
+        std::vector<std::vector<uint64_t>> counts(parts);
+        std::vector<std::string> errors(parts);
+        std::vector<std::thread> pool;
+        for (size_t r = 0; r < parts; ++r) {
+            const auto range = gpu_index_set::slice(queries.size(), r, parts);
+            slices[r].assign(queries.begin() + range.first, queries.begin() + range.second);
+            m_ops[r].collect_counters(m_counters);
+            if (slices[r].empty()) continue;
+            pool.emplace_back([&, r] { // one host thread per replica: its slice crosses the C ABI on that device's streams
+                try { counts[r] = m_ops[r](set.replica(r), slices[r]); }
+                catch (std::exception const& e) { errors[r] = e.what(); }
+            });
+        }
+        for (auto& t : pool) t.join();
+        for (auto const& e : errors) if (!e.empty()) throw std::runtime_error(e);
+        m_counts.clear();
+        m_topk.clear();
+        m_stats = ds2i_hip_stats{};
+        for (size_t r = 0; r < parts; ++r) { // the host concatenates the slices in order: that is the whole "merge"
+            if (slices[r].empty()) continue;
+            m_counts.insert(m_counts.end(), counts[r].begin(), counts[r].end());
+            auto const& tk = m_ops[r].topk_batch();
+            m_topk.insert(m_topk.end(), tk.begin(), tk.end());
+            ds2i_hip_stats const& st = m_ops[r].stats();
+            m_stats.kernel_ms = std::max(m_stats.kernel_ms, st.kernel_ms);
+            m_stats.docs_blocks_decoded += st.docs_blocks_decoded;
+            m_stats.freqs_blocks_decoded += st.freqs_blocks_decoded;
+            m_stats.block_max_examined += st.block_max_examined;
+            m_stats.algorithmic_bytes += st.algorithmic_bytes;
+            m_stats.postings_scored += st.postings_scored;
+            m_stats.rounds += st.rounds;
+        }
+        return m_counts;
+    }
+    std::vector<float> const& topk() const { return m_topk.back(); }
+    std::vector<std::vector<float>> const& topk_batch() const { return m_topk; }
+    ds2i_hip_stats const& stats() const { return m_stats; } // kernel_ms = slowest replica, counters summed
+    void collect_counters(bool on) { m_counters = on; }
+    static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
+
+private:
+    uint64_t m_k;
+    bool m_counters = false;
+    std::vector<gpu_query_op<OP>> m_ops;
+    std::vector<uint64_t> m_counts;
+    std::vector<std::vector<float>> m_topk;
+    ds2i_hip_stats m_stats{};
+};
+
 typedef gpu_query_op<DS2I_OP_AND> and_query;
 typedef gpu_query_op<DS2I_OP_AND_FREQ> and_freq_query;
 typedef gpu_query_op<DS2I_OP_OR> or_query;
@@ -189,5 +294,7 @@ typedef gpu_query_op<DS2I_OP_RANKED_AND> ranked_and_query;
 typedef gpu_query_op<DS2I_OP_WAND> wand_query;
 typedef gpu_query_op<DS2I_OP_MAXSCORE> maxscore_query;
 typedef gpu_query_op<DS2I_OP_RANKED_OR> ranked_or_query;
+// the same operators over a replica set (one index per device)
+template <int OP> using set_query = gpu_set_query_op<OP>;
 
 } // namespace ds2i_hip

@@ -79,7 +79,11 @@ typedef struct ds2i_hip_batch ds2i_hip_batch;
 
 /* Device-side counters of one batch run; the byte pricing is SURVEY.md §8(d)'s A_skip. */
 typedef struct ds2i_hip_stats {
-    double kernel_ms;             /* hipEvent time of the kernels of the last run */
+    double kernel_ms;             /* device-side WINDOW of the last run (hipEvents): from the batch's first clear to the
+                                     completion of its last kernel. In a pipeline the window also holds whatever other
+                                     batches ran on the GPU meanwhile; for wand / maxscore / ranked_or the ranked_and seed
+                                     pass is enqueued ahead of the window and may start before it. rocprofv3's per-kernel
+                                     durations are the exact figures. */
     uint64_t docs_blocks_decoded; /* block_profiler counter [2b]   (block_posting_list.hpp:316-318) */
     uint64_t freqs_blocks_decoded;/* block_profiler counter [2b+1] (block_posting_list.hpp:328-330) */
     uint64_t block_max_examined;

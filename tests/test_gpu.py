@@ -202,7 +202,7 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
         bound = tab.astype(np.float32) * np.float32(mx / 255.0)
         assert np.all(bound[occupied] * np.float32(1 + 2 ** -17) >= rmax[occupied]), (codec, t)
         assert np.all(bound[occupied] <= rmax[occupied] + np.float32(mx) * np.float32(1.01 / 255.0)), (codec, t)
-        assert 2 * len(docs) <= len(tab) or sh == 0   # DS2I_RMW_G = 2 entries per posting at least (or one per doc-id)
+        assert 4 * len(docs) <= len(tab) or sh == 0   # DS2I_RMW_G = 4 entries per posting at least (or one per doc-id)
         prev = tab
         for level in (2, 3):  # the coarser levels: maxima of 64 entries of the level below
             up, shl, _ = gidx.range_table(t, level)
@@ -282,12 +282,11 @@ def test_reference_order_kernel_and_algorithmic_bytes(coll, queries, images, op)
     assert st.freqs_blocks_decoded == prof["freqs_blocks"]
     assert st.block_max_examined == prof["block_max_examined"]
     assert st.algorithmic_bytes == prof["algorithmic_bytes"]
-    # block-synchronous kernel: a superset of those blocks, never fewer docs blocks
+    # block-synchronous kernel: never many more docs blocks than the reference decodes, and -- with the doc-id-range tables
+    # ruling candidates out before another list is touched (and ranked_and's score bounds on top) -- usually fewer
     b = d.Batch(gidx, op, queries)
     st2 = b.run()
-    if op != "ranked_and":  # ranked_and additionally skips blocks whose score bound cannot enter the heap
-        assert st2.docs_blocks_decoded >= prof["docs_blocks"] * 0.85  # lazy binding skips unneeded block-0 decodes
-    assert st2.docs_blocks_decoded <= prof["docs_blocks"] * 1.5 + 16
+    assert 0 < st2.docs_blocks_decoded <= prof["docs_blocks"] * 1.5 + 16
 
 
 def test_topk_other_k(coll, queries, images):
@@ -669,6 +668,30 @@ def test_queries_cli_and_cpp_adaptor(coll, queries, images, tmp_path):
     assert "Unsupported query type: bogus" in r.stderr
     r = subprocess.run([tool, "no_such_index", "and", str(idx_path)], input=log, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "ERROR: Unknown type" in r.stderr  # queries.cpp:149-151
+    for l in lines:
+        assert l["gpus"] == 1 and l["hbm_gbps"] > 0 and l["kernel_ms"] > 0
+    # in-process multi-device path behind the C++ boundary: ds2i_hip::gpu_index_set + one host thread per
+    # replica. Three replicas (on however many devices the box has -- one here, so they share it) cut every batch into three
+    # contiguous slices; the concatenated answers are the one-replica answers, bit for bit, and the Python ABI's.
+    dumps = []
+    for g in (1, 3):
+        dump = tmp_path / ("dump%d" % g)
+        r = subprocess.run([tool, "block_optpfor", "and:ranked_and:maxscore", str(idx_path), str(wand_path), "--gpus", str(g),
+                            "--dump", str(dump)], input=log, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        assert [l["gpus"] for l in out] == [g] * 3 and ("on %d replica(s)" % g) in r.stderr
+        dumps.append(dump.read_text().splitlines())
+    assert dumps[0] == dumps[1] and len(dumps[0]) == 3 * sum(1 for q in queries if q)
+    gidx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    qs = [q for q in queries if q]
+    acount, _, _, _ = gidx.query_batch("and", qs)
+    _, rtopk, rlen, _ = gidx.query_batch("ranked_and", qs, k=10)
+    for i in range(len(qs)):
+        assert dumps[1][i].split() == ["and", str(int(acount[i]))]
+        got = dumps[1][len(qs) + i].split()
+        assert got[0] == "ranked_and" and int(got[1]) == int(rlen[i])
+        assert [int(x, 16) for x in got[2:]] == rtopk[i, :rlen[i]].view(np.uint32).tolist()
 
 
 def test_gpu_encode_is_byte_identical(coll, images):
