@@ -255,7 +255,8 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     // With range tables a ranked conjunction is cheap per block and the parts of a split query each pay for warming up
     // their own heap: coarser units win (measured on the GOV2-scale batch, queries/s: factor 16: 355 k, 8: 344 k,
     // 4 with the many-list classes cut 4x finer: 430-457 k, 2: 251 k)
-    const bool rmw_units = ranked && conj && idx->d_rmw;
+    const bool rmw_units = ranked && conj && idx->d_rmw; // (and / and_freq verify every candidate the tables let through: their cost
+                                                         // stays with the blocks of all lists, and they are throughput-, not tail-bound: measured)
     const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? 4.0 : 16.0;
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
@@ -273,7 +274,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
         static const char* ud = std::getenv("DS2I_UNIT_DIV");
         static const double unit_div = ud && std::atof(ud) > 0 ? std::atof(ud) : 4.0;
-        const bool rmw_cost = ranked && conj && idx->d_rmw; // (cost already counts the class's time per block)
+        const bool rmw_cost = rmw_units; // (cost already counts the class's time per block)
         static const char* udr = std::getenv("DS2I_UNIT_DIV_RMW");
         static const double unit_div_rmw = udr && std::atof(udr) > 0 ? std::atof(udr) : 4.0;
         const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div));
@@ -313,7 +314,10 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 return e != nullptr;
             }();
             (void)scale_from_env;
-            const double dtarget = std::max(48.0, all_cost / (unit_factor * disj_scale[c] * resident));
+            // or / or_freq run as a stream (k_union): a part costs a positioning of every list plus its blocks, once each
+            static const bool no_union_stream = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
+            const bool stream_or = !ranked && !(op & DS2I_OP_REFERENCE_ORDER) && !no_union_stream;
+            const double dtarget = std::max(48.0, all_cost / (unit_factor * (stream_or ? 1.0 : disj_scale[c]) * resident));
             if (nt && N > 1)
                 parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));
             const uint32_t width = (N + parts - 1) / parts;
@@ -343,6 +347,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
         static const char* dm = std::getenv("DS2I_DYN_MINCLS");
         static const int dyn_mincls = dm ? std::atoi(dm) : 2;
+        static const bool no_union_stream2 = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
+        if (union_kernel && !ranked && !no_union_stream2) { // or / or_freq: the streaming kernel serves every list count (lists = ~0 says so)
+            b->sub[c].push_back({0u, b->ncls[c], 0xFFFFFFFFu});
+            continue;
+        }
         if (!union_kernel || c < dyn_mincls || dyn_group == 0) {
             b->sub[c].push_back({0u, b->ncls[c], cls_lists});
             continue;

@@ -460,7 +460,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (from >= u.blk_end) break;
                 cx.s_bm_examined += 1;
                 cx.s_bytes += 4;
-                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
+                // (measured: consulting it every 4th window instead saves the trips and loses as much to the staler floor)
+            if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
                 PT_BEGIN(cx);
                 const uint32_t blk2 = s_next(from);
                 if (blk2 >= u.blk_end) break;
@@ -1395,7 +1396,8 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
         float skip_rest = 0.f;
         while (non_ess < nt && lo < N) {
             ++cx.s_rounds;
-            if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_TOPK); }
+            // (measured: consulting the histogram every 4th window instead saves the trips and loses as much to the staler floor)
+            if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
             if (non_ess >= nt) break;
             // ---- window: every essential list is positioned on its block at lo; [lo, hi] ends with the first of them
 #ifdef DS2I_PHASE_TIMING
@@ -1501,12 +1503,17 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                 const float ub_low = fo ? ubw(fo - 1) : 0.f;
                 // Range tables (BatchArgs::rmw): what the lower lists can add to THIS candidate, one byte gather per lower
                 // list and candidate instead of their list maxima -- and a zero byte says the candidate is not in that list
-                // at all, so it is never looked up there. lb*[j] = byte of the list at position j of the max-score order
-                // (the <= 7 lower lists of the <= 8-list classes), packed four to a dword.
-                constexpr int NL = TMAX <= 8 ? TMAX - 1 : 0;
-                const bool use_rmw = MODE == 0 && NL > 0 && a.rmw && fo > 0;
-                uint32_t lb0[2] = {0u, 0u}, lb1[2] = {0u, 0u};
-                auto low_byte = [&](const uint32_t* lb, uint32_t j) __attribute__((always_inline)) { return (lb[(j >> 2) & 1u] >> (8u * (j & 3u))) & 255u; };
+                // at all, so it is never looked up there. lb*[j] = byte of the list at position j of the max-score order,
+                // packed four to a dword.
+                constexpr int NL = TMAX - 1, NLW = (NL + 3) / 4;
+                const bool use_rmw = MODE == 0 && a.rmw && fo > 0;
+                uint32_t lb0[NLW] = {}, lb1[NLW] = {};
+                auto low_byte = [&](const uint32_t* lb, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t w = lb[0];
+#pragma unroll
+                    for (int k = 1; k < NLW; ++k) w = (j >> 2) == (uint32_t)k ? lb[k] : w; // (selects, not a dynamic index: the words stay in registers)
+                    return (w >> (8u * (j & 3u))) & 255u;
+                };
                 // sum of the candidate's bounds in the lower lists at positions <= upto (added from position 0 up)
                 auto low_rest = [&](const uint32_t* lb, uint32_t upto) __attribute__((always_inline)) -> float {
                     float r = 0.f;
@@ -1516,7 +1523,7 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
                     return r;
                 };
                 if (use_rmw) {
-                    uint32_t e0[NL > 0 ? NL : 1] = {}, e1[NL > 0 ? NL : 1] = {};
+                    uint32_t e0[NL] = {}, e1[NL] = {};
 #pragma unroll
                     for (int j = 0; j < NL; ++j) { // (all gathers are issued before the first is consumed)
                         if ((uint32_t)j < fo) {
@@ -1687,6 +1694,155 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
 #ifdef DS2I_PHASE_TIMING
         cx.s_phase[PH_TOTAL] += __builtin_readcyclecounter() - pt_unit0;
 #endif
+    }
+    cx.flush_stats(a.stats);
+}
+
+// ------------------------------------------------------------------ or_query as a stream
+// or_query<with_freqs> (queries.hpp:88-131) returns the size of the union of the query's lists (and touches every freq).
+// There is nothing to prune and nothing to rank, so the lists need not be walked in lock step at all: a unit owns a doc-id
+// range; it takes the range 32 Ki doc-ids at a time, and for every list decodes the blocks that reach into the current
+// piece -- each block once, front to back, whatever the other lists do -- setting one bit per posting in a 4 KiB bitmap
+// in LDS (ds_or, no global atomics). The piece's popcount is its part of the union. No list is ever searched for another
+// list's documents, no window is cut at a block boundary, and the number of lists is not a template parameter (<= 64
+// per query; longer queries keep the one-document-per-step kernel). A block that straddles the end of a piece is decoded
+// again for the next piece (one extra decode per list and piece); pieces without any block are never visited, because the
+// next piece starts at the first doc-id any list can still hold.
+constexpr uint32_t UNION_PIECE = 32768u;   // doc-ids per bitmap (4 KiB)
+constexpr uint32_t UNION_MAX_LISTS = 64u;
+struct LdsUnion : Lds<1, false> { // (one list slot at a time, its enumerator state in registers: MetaReg<1>)
+    uint32_t bits[UNION_PIECE / 32];
+    uint32_t nextblk[UNION_MAX_LISTS];  // first block of list i not yet fully behind the stream
+    uint32_t nextbase[UNION_MAX_LISTS]; // smallest doc-id that block can still contribute
+};
+template <bool WITH_FREQS, int CODEC_T, bool STATS = true>
+__global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
+    __shared__ LdsUnion L;
+    const uint32_t lane = lane_id();
+    CtxT<CODEC_T, MetaReg<1>, STATS> cx = make_ctx<CODEC_T, MetaReg<1>, STATS>(L, a);
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
+        const uint32_t uid = a.order[tkt];
+        const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
+        const Unit u = a.units[uid];
+        const uint32_t q = u.q;
+        const bool whole = u.nparts == 1;
+        const uint32_t unit_lo = whole ? 0u : u.blk_begin, unit_hi = whole ? a.num_docs : u.blk_end;
+        const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
+        unsigned long long count = 0, fsum = 0;
+        if (nt && nt <= UNION_MAX_LISTS && unit_lo < unit_hi) {
+            // position every list on its first block that reaches into the unit
+            for (uint32_t i = 0; i < nt; ++i) {
+                cx.bind(0, a.qterms[t0 + i]);
+                uint32_t bmax = 0;
+                float w;
+                const uint32_t nb = cx.m(0, M_NB);
+                const uint32_t blk = unit_lo ? cx.find_block(0, 0, unit_lo, bmax, nullptr, w) : 0u;
+                cx.s_bm_examined += 1;
+                cx.s_bytes += 4;
+                if (lane == 0) {
+                    L.nextblk[i] = blk < nb ? blk : 0xFFFFFFFFu;
+                    L.nextbase[i] = blk < nb ? unit_lo : 0xFFFFFFFFu;
+                }
+            }
+            wave_sync();
+            for (;;) {
+                // the piece starts at the first doc-id some list can still hold
+                uint32_t mine = 0xFFFFFFFFu;
+                for (uint32_t i = lane; i < nt; i += 64) mine = L.nextbase[i] < mine ? L.nextbase[i] : mine;
+                const uint32_t lo = bcast(wave_incl_min_scan(mine), 63);
+                if (lo >= unit_hi) break;
+                const uint32_t hi = unit_hi - lo > UNION_PIECE ? lo + UNION_PIECE : unit_hi; // [lo, hi)
+                ++cx.s_rounds;
+#pragma unroll
+                for (uint32_t k = 0; k < UNION_PIECE / 32 / 64; ++k) L.bits[k * 64 + lane] = 0u;
+                wave_sync();
+                for (uint32_t i = 0; i < nt; ++i) {
+                    if (uniform(L.nextbase[i]) >= hi) continue;
+                    cx.bind(0, a.qterms[t0 + i]);
+                    const uint32_t nb = cx.m(0, M_NB);
+                    uint32_t b = uniform(L.nextblk[i]), base = hi;
+                    // block indexes with the skip table: the list's table rows for the next 63 blocks sit in registers (lane j =
+                    // row wfirst + j, lane 0 the row before the first block served), and the bytes of block b + 1 are requested
+                    // while block b is decoded -- the stream costs no dependent round trip per block
+                    const bool tabbed = !cx.is_pef() && cx.skip;
+                    const uint2* const tab = tabbed ? cx.skip + cx.m(0, M_PBASE) : nullptr;
+                    const uint8_t* const data = tabbed ? cx.ptr(0, M_MAXS_LO) + 4ull * nb + 4ull * (nb - 1) : nullptr;
+                    uint32_t wfirst = 0, pf_blk = 0xFFFFFFFFu, pf0 = 0, pf1 = 0;
+                    uint2 we = make_uint2(0xFFFFFFFFu, 0u);
+                    auto wfill = [&](uint32_t first) __attribute__((always_inline)) {
+                        wfirst = first;
+                        we = make_uint2(0xFFFFFFFFu, 0u);
+                        if (first + lane < nb) we = tab[first + lane];
+                    };
+                    if (tabbed && b < nb) wfill(b ? b - 1 : 0);
+                    while (b < nb) {
+                        if (tabbed) {
+                            if (b - wfirst > 63u) wfill(b - 1);
+                            const uint32_t f = b - wfirst, fp = f ? f - 1 : 0;
+                            typename decltype(cx)::BlockInfo bi;
+                            bi.bmax = bcast(we.x, f);
+                            bi.next_ep = bcast(we.y, f);
+                            bi.base = b ? bcast(we.x, fp) + 1u : 0u;
+                            bi.ep = b ? bcast(we.y, fp) : 0u;
+                            if (bi.base >= hi) { base = bi.base; break; } // the block starts behind the piece: not decoded yet
+                            const bool staged = pf_blk == b;
+                            if (staged) {
+                                const uint8_t* p = data + bi.ep;
+                                cx.win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
+                                cx.win.nbytes = 512;
+                                cx.win.st[lane] = pf0;
+                                cx.win.st[lane + 64] = pf1;
+                                wave_sync();
+                            }
+                            cx.decode_docs(0, b, &bi, staged);
+                            pf_blk = 0xFFFFFFFFu;
+                            if (b + 1 < nb && bi.bmax + 1u < hi) { // the next block reaches into this piece too: request its bytes now
+                                const uint32_t* g = (const uint32_t*)((uintptr_t)(data + bi.next_ep) & ~(uintptr_t)3);
+                                pf0 = g[lane];
+                                pf1 = g[lane + 64];
+                                pf_blk = b + 1;
+                            }
+                        } else {
+                            cx.decode_docs(0, b);
+                        }
+                        const uint32_t d0 = L.docs[0][lane], d1 = L.docs[0][lane + 64];
+                        const bool in0 = d0 >= lo && d0 < hi, in1 = d1 >= lo && d1 < hi; // (the padding doc-id 0xFFFFFFFF is never inside)
+                        if (in0) atomicOr(&L.bits[(d0 - lo) >> 5], 1u << ((d0 - lo) & 31u));
+                        if (in1) atomicOr(&L.bits[(d1 - lo) >> 5], 1u << ((d1 - lo) & 31u));
+                        if constexpr (WITH_FREQS) { // or_query<true> reads the freq of every posting it passes (queries.hpp:118-120)
+                            if (ballot(in0) | ballot(in1)) {
+                                cx.decode_freqs(0);
+                                unsigned long long fs = (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
+                                for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                                fsum += fs;
+                            }
+                        }
+                        const uint32_t bmax = cx.m(0, M_BMAX);
+                        if (bmax >= hi) { base = hi; break; }       // reaches past the piece: taken up again by the next one
+                        ++b;
+                        base = bmax + 1u;
+                        if (base >= hi) break;
+                    }
+                    if (lane == 0) {
+                        L.nextblk[i] = b;
+                        L.nextbase[i] = b < nb ? base : 0xFFFFFFFFu;
+                    }
+                    wave_sync();
+                }
+                uint32_t pc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < UNION_PIECE / 32 / 64; ++k) pc += (uint32_t)__builtin_popcount(L.bits[k * 64 + lane]);
+                pc = bcast(wave_incl_scan(pc), 63);
+                count += pc;
+                wave_sync();
+            }
+        }
+        if (whole) {
+            if (lane == 0) { a.out_count[q] = count; if (a.out_freq_sum) a.out_freq_sum[q] = fsum; }
+        } else {
+            if (lane == 0) { a.unit_count[uid] = count; a.unit_freq_sum[uid] = fsum; }
+        }
+        if (STATS && a.unit_clock && lane == 0) { a.unit_clock[2ull * uid] = t_unit; a.unit_clock[2ull * uid + 1] = wall_clock64(); }
     }
     cx.flush_stats(a.stats);
 }
@@ -2007,6 +2163,21 @@ extern "C" {
 // 4 -> more than 16 terms (state in global scratch)
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
+    if ((op == OP_OR || op == OP_OR_FREQ) && a.dyn_lists == 0xFFFFFFFFu) { // or_query as a stream: one kernel for every list count
+        const dim3 g(grid), b(64);
+        const bool f = op == OP_OR_FREQ;
+        if (a.codec == CODEC_OPTPFOR && !a.stats) {
+            if (f) hipLaunchKernelGGL((k_union<true, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_union<false, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        } else if (a.codec == CODEC_OPTPFOR) {
+            if (f) hipLaunchKernelGGL((k_union<true, CODEC_OPTPFOR>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_union<false, CODEC_OPTPFOR>), g, b, 0, s, a);
+        } else {
+            if (f) hipLaunchKernelGGL((k_union<true, -1>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_union<false, -1>), g, b, 0, s, a);
+        }
+        return hipGetLastError();
+    }
     switch (tmax_class) {
     case 0: return ds2i_launch::launch_t<2>(op, a, grid, s);
     case 1: return ds2i_launch::launch_t<4>(op, a, grid, s);
