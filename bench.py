@@ -393,7 +393,7 @@ def main():
     # labelled as such; otherwise null.
     traffic = None
     traffic_src = None
-    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r02_traffic_%s_%s.json" % (wl, args.op))
+    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r03_traffic_%s_%s.json" % (wl, args.op))
     if os.path.exists(tj) and args.codec == "block_optpfor":
         tjson = json.load(open(tj))
         if tjson.get("kernel_class") == dom:

@@ -99,6 +99,7 @@ struct BatchArgs {
     // every level padded to 64 bytes): the largest entry over the doc-id span of a whole BLOCK of the driving list is found
     // in <= 16 bytes of the level whose entries are wide enough, and bounds every candidate of that block at once.
     const uint8_t* rmw;
+    uint32_t rmw_bitmaps;        // the dense lists' exact bitmaps exist behind their tables (RmwLevels::has_bitmap)
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
     uint32_t dyn_lists;          // union kernels: list slots of decoded blocks in dynamic LDS (>= the longest query of the launch)
@@ -122,6 +123,12 @@ struct RmwLevels {
         off[2] = off[1] + (((uint64_t)e[1] + 63u) & ~63ull);
     }
     __host__ __device__ uint64_t bytes() const { return off[2] + (((uint64_t)e[2] + 63u) & ~63ull); }
+    // Lists holding at least one document in 64 additionally get an exact BITMAP of their doc-ids behind the levels (at
+    // byte offset bytes(); num_docs bits, padded to 64 bytes + one spare line so that a pair of adjacent words can always
+    // be read): <= 64 bits per posting. and_query tests membership in such a list with one bit gather and never decodes
+    // it; or_query ORs its words into the union instead of decoding its blocks.
+    static __host__ __device__ bool has_bitmap(uint32_t n, uint32_t num_docs) { return (uint64_t)n * 64u >= num_docs; }
+    static __host__ __device__ uint64_t bitmap_bytes(uint32_t num_docs) { return ((((uint64_t)num_docs + 31u) / 32u * 4u + 63u) & ~63ull) + 64u; }
 };
 struct BmwArgs {
     const uint8_t* arena;
@@ -136,6 +143,7 @@ struct BmwArgs {
     float* bmw;             // out: one per block
     unsigned int* list_bmw; // out: per list max (float bits; weights are >= 0 so the bit patterns order like the values)
     uint8_t* rmw;           // second pass (k_range_max_weights): the range tables; lists[].max_weight = the list maximum of pass 1
+    uint32_t bitmaps;       // level-1 pass: also set the bits of the dense lists' bitmaps
     uint32_t rmw_level;     // 0: fill level 1 from the postings; 1 / 2: items = {list, first entry of a 4096-entry run of level
                             // rmw_level + 1}, each entry the maximum of 64 entries of the level below
 };

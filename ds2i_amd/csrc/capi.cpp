@@ -163,6 +163,8 @@ int build_block_max_weights(ds2i_hip_index* x) {
         x->list_rmw_shift[t] = sh;
         x->list_rmw_off64[t] = (uint32_t)cursor;
         cursor += ds2i_dev::RmwLevels((uint32_t)x->num_docs, sh).bytes() / 64; // level 1 + its two coarser levels
+        if (ds2i_dev::RmwLevels::has_bitmap(x->list_n[t], (uint32_t)x->num_docs) && !std::getenv("DS2I_NO_BITMAPS"))
+            cursor += ds2i_dev::RmwLevels::bitmap_bytes((uint32_t)x->num_docs) / 64; // dense list: + its exact bitmap
         if (cursor >= (1ull << 32)) return DS2I_OK; // > 256 GB of tables: not on this device; run without them
     }
     size_t free_b = 0, total_b = 0;
@@ -180,6 +182,8 @@ int build_block_max_weights(ds2i_hip_index* x) {
     HIP_OK(hipMemcpyAsync(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice, x->stream[0]));
     a.rmw = x->d_rmw;
     a.rmw_level = 0;
+    a.bitmaps = std::getenv("DS2I_NO_BITMAPS") ? 0u : 1u;
+    x->has_bitmaps = a.bitmaps != 0;
     HIP_OK(ds2i_launch_block_max_weights(&a, grid, x->stream[0]));
     for (uint32_t lvl = 1; lvl <= 2; ++lvl) { // level lvl + 1 = maxima of 64 entries of level lvl, 4096 entries per item
         items.clear();
@@ -494,8 +498,17 @@ int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint32_t level
     *shift = 0;
     *list_max = 0.f;
     if (!idx->d_rmw) return DS2I_OK;
-    if (level < 1 || level > 3) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: level must be 1, 2 or 3");
+    if (level > 3) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: level must be 0 (the bitmap), 1, 2 or 3");
     const ds2i_dev::RmwLevels g((uint32_t)idx->num_docs, idx->list_rmw_shift[term]);
+    if (level == 0) { // the exact bitmap of a dense list: (num_docs + 7) / 8 bytes, bit d = doc-id d; 0 entries = the list has none
+        *list_max = idx->list_bmw[term];
+        if (!idx->has_bitmaps || !ds2i_dev::RmwLevels::has_bitmap(idx->list_n[term], (uint32_t)idx->num_docs)) return DS2I_OK;
+        *entries = (idx->num_docs + 7) / 8;
+        if (!out || capacity < *entries) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: capacity too small");
+        HIP_OK(hipSetDevice(idx->device));
+        HIP_OK(hipMemcpy(out, idx->d_rmw + 64ull * idx->list_rmw_off64[term] + g.bytes(), *entries, hipMemcpyDeviceToHost));
+        return DS2I_OK;
+    }
     *shift = idx->list_rmw_shift[term] + 6 * (level - 1);
     *entries = g.e[level - 1];
     *list_max = idx->list_bmw[term];

@@ -578,6 +578,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;
         static const bool no_rmw_use = std::getenv("DS2I_NO_RMW_USE") != nullptr; // A/B: tables built but not consulted
         a.rmw = (no_rmw_use || (base_op == DS2I_OP_RANKED_AND && !a.bmw)) ? nullptr : idx->d_rmw;
+        static const bool no_bm_use = std::getenv("DS2I_NO_BITMAP_USE") != nullptr; // A/B: bitmaps built but not consulted
+        a.rmw_bitmaps = (a.rmw && idx->has_bitmaps && !no_bm_use) ? 1u : 0u;
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;

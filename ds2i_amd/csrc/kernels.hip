@@ -340,6 +340,39 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             static_loop_down<RL, 1>(add_one);
             return r;
         };
+        // and_query only: lists dense enough to carry an exact bitmap (bit i of bm_lists) are tested by a bit gather and then
+        // never probed or decoded -- membership is all and_query wants from them; the others go by their range-table byte
+        // (zero = not a member for sure) and are verified by the usual probe
+        uint32_t bm_lists = 0;
+        if constexpr (!RANKED && !WITH_FREQS) {
+            if (use_rmw && a.rmw_bitmaps) {
+                auto mark = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    if (RmwLevels::has_bitmap(cx.m(i, M_N), a.num_docs)) bm_lists |= 1u << i;
+                    return true;
+                };
+                static_list_loop<1, RL>(nt, mark);
+            }
+        }
+        auto and_filter = [&](uint32_t c, bool valid) __attribute__((always_inline)) -> bool {
+            uint32_t e[RL] = {};
+            auto load_one = [&](auto ic) __attribute__((always_inline)) {
+                constexpr uint32_t i = decltype(ic)::value;
+                const uint8_t* tab = rmw + 64ull * cx.m(i, M_RBASE);
+                if ((bm_lists >> i) & 1u) {
+                    const uint32_t* bm = (const uint32_t*)(tab + RmwLevels(a.num_docs, cx.m(i, M_RSHIFT)).bytes());
+                    e[i] = valid ? (bm[c >> 5] >> (c & 31u)) & 1u : 0u;
+                } else {
+                    e[i] = valid ? (uint32_t)tab[c >> cx.m(i, M_RSHIFT)] : 0u;
+                }
+                return true;
+            };
+            static_list_loop<1, RL>(nt, load_one);
+            bool ok = valid;
+            auto test_one = [&](auto ic) __attribute__((always_inline)) { ok = ok && e[decltype(ic)::value] != 0; return true; };
+            static_list_loop<1, RL>(nt, test_one);
+            return ok;
+        };
         cx.s_bytes += 4;
         ++cx.s_bm_examined;
         uint32_t lo = 0, floor_tick = 1;
@@ -498,9 +531,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if constexpr (!RANKED) {
                     if (use_rmw) { // once per block of list 0: who can be a member of every other list at all
                         const uint32_t n0c = L.docs[0][lane], n1c = L.docs[0][lane + 64];
-                        uint32_t ql, qh;
-                        okm0 = ballot(rmw_gather(n0c, n0c != 0xFFFFFFFFu, ql, qh));
-                        okm1 = ballot(rmw_gather(n1c, n1c != 0xFFFFFFFFu, ql, qh));
+                        okm0 = ballot(and_filter(n0c, n0c != 0xFFFFFFFFu));
+                        okm1 = ballot(and_filter(n1c, n1c != 0xFFFFFFFFu));
                     }
                 }
             } else if (need0 || lo > cx.m(0, M_BMAX)) { // (freq_index layouts, or no skip table: the search-based form)
@@ -522,9 +554,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if constexpr (!RANKED) {
                     if (use_rmw) { // once per block of list 0: who can be a member of every other list at all
                         const uint32_t n0c = L.docs[0][lane], n1c = L.docs[0][lane + 64];
-                        uint32_t ql, qh;
-                        okm0 = ballot(rmw_gather(n0c, n0c != 0xFFFFFFFFu, ql, qh));
-                        okm1 = ballot(rmw_gather(n1c, n1c != 0xFFFFFFFFu, ql, qh));
+                        okm0 = ballot(and_filter(n0c, n0c != 0xFFFFFFFFu));
+                        okm1 = ballot(and_filter(n1c, n1c != 0xFFFFFFFFu));
                     }
                 }
             }
@@ -623,6 +654,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             bool pruned = false;
             auto probe_list = [&](auto ic) __attribute__((always_inline)) -> bool {
                 const uint32_t i = ic;
+                if constexpr (!RANKED && !WITH_FREQS) { if ((bm_lists >> i) & 1u) return true; } // settled by its bitmap
                 uint64_t b0 = ballot(al0), b1 = ballot(al1);
                 if (!(b0 | b1)) return false;
                 uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
@@ -1732,6 +1764,10 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
         if (nt && nt <= UNION_MAX_LISTS && unit_lo < unit_hi) {
             // position every list on its first block that reaches into the unit
             for (uint32_t i = 0; i < nt; ++i) {
+                if (!WITH_FREQS && a.rmw_bitmaps && RmwLevels::has_bitmap(a.qterms[t0 + i].n, a.num_docs)) { // (served from its bitmap: no block to find)
+                    if (lane == 0) { L.nextblk[i] = 0u; L.nextbase[i] = unit_lo; }
+                    continue;
+                }
                 cx.bind(0, a.qterms[t0 + i]);
                 uint32_t bmax = 0;
                 float w;
@@ -1758,6 +1794,28 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                 wave_sync();
                 for (uint32_t i = 0; i < nt; ++i) {
                     if (uniform(L.nextbase[i]) >= hi) continue;
+                    if constexpr (!WITH_FREQS) {
+                        // a dense list (>= one document in 64) has its exact bitmap behind its range table: its part of the
+                        // piece is 1024 words to OR in, not a hundred blocks to decode
+                        const QTerm& qt = a.qterms[t0 + i];
+                        if (a.rmw_bitmaps && RmwLevels::has_bitmap(qt.n, a.num_docs)) {
+                            const uint32_t* bm = (const uint32_t*)(a.rmw + 64ull * qt.rmw_off64 + RmwLevels(a.num_docs, qt.rmw_shift).bytes());
+                            const uint32_t w0 = lo >> 5, shft = lo & 31u, nbits = hi - lo;
+#pragma unroll
+                            for (uint32_t k = 0; k < UNION_PIECE / 32 / 64; ++k) {
+                                const uint32_t idx = k * 64 + lane;
+                                if (32u * idx < nbits) {
+                                    uint32_t v = __builtin_amdgcn_alignbit(bm[w0 + idx + 1], bm[w0 + idx], shft); // bit j = doc-id lo + 32 idx + j
+                                    const uint32_t left = nbits - 32u * idx;
+                                    if (left < 32u) v &= (1u << left) - 1u;
+                                    L.bits[idx] |= v;
+                                }
+                            }
+                            if (lane == 0) L.nextbase[i] = hi < unit_hi ? hi : 0xFFFFFFFFu;
+                            wave_sync();
+                            continue;
+                        }
+                    }
                     cx.bind(0, a.qterms[t0 + i]);
                     const uint32_t nb = cx.m(0, M_NB);
                     uint32_t b = uniform(L.nextblk[i]), base = hi;
@@ -1942,6 +2000,8 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
         float mine = 0.f;
         uint8_t* const rtab = a.rmw ? a.rmw + 64ull * t.rmw_off64 : nullptr;
         const float rinv = t.max_weight > 0.f ? 255.0f / t.max_weight : 0.f; // second pass: max_weight = the list's largest weight
+        unsigned int* const bm = (a.rmw && a.bitmaps && RmwLevels::has_bitmap(t.n, a.num_docs))
+                                     ? (unsigned int*)(a.rmw + 64ull * t.rmw_off64 + RmwLevels(a.num_docs, t.rmw_shift).bytes()) : nullptr;
         for (uint32_t b = it.blk_begin; b < end; ++b) {
             cx.decode_docs(0, b);
             cx.decode_freqs(0);
@@ -1949,6 +2009,10 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
             float w = 0.f;
             if (lane < sz) w = doc_term_weight(L.freqs[0][lane], a.norm_lens[L.docs[0][lane]]);
             if (a.rmw && lane < sz) rmw_raise(rtab, L.docs[0][lane] >> t.rmw_shift, rmw_quantise(w, rinv));
+            if (bm) { // dense list: its exact bitmap
+                if (lane < sz) atomicOr(bm + (L.docs[0][lane] >> 5), 1u << (L.docs[0][lane] & 31u));
+                if (lane + 64 < sz) atomicOr(bm + (L.docs[0][lane + 64] >> 5), 1u << (L.docs[0][lane + 64] & 31u));
+            }
             if (lane + 64 < sz) {
                 const float w1 = doc_term_weight(L.freqs[0][lane + 64], a.norm_lens[L.docs[0][lane + 64]]);
                 if (a.rmw) rmw_raise(rtab, L.docs[0][lane + 64] >> t.rmw_shift, rmw_quantise(w1, rinv));

@@ -203,6 +203,12 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
         assert np.all(bound[occupied] * np.float32(1 + 2 ** -17) >= rmax[occupied]), (codec, t)
         assert np.all(bound[occupied] <= rmax[occupied] + np.float32(mx) * np.float32(1.01 / 255.0)), (codec, t)
         assert 4 * len(docs) <= len(tab) or sh == 0   # DS2I_RMW_G = 4 entries per posting at least (or one per doc-id)
+        bm, _, _ = gidx.range_table(t, 0)  # dense lists (>= one document in 64) carry their exact bitmap
+        if 64 * len(docs) >= coll.num_docs:
+            bits = np.unpackbits(bm, bitorder="little")[:coll.num_docs]
+            assert np.array_equal(np.flatnonzero(bits).astype(np.uint32), docs), (codec, t)
+        else:
+            assert len(bm) == 0
         prev = tab
         for level in (2, 3):  # the coarser levels: maxima of 64 entries of the level below
             up, shl, _ = gidx.range_table(t, level)
