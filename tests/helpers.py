@@ -118,16 +118,24 @@ def mixed_block_type_counts(image, oracle_mod, max_blocks=20000):
     oidx = oracle_mod.Index("block_mixed", image)
     counts = {"docs": [0, 0, 0], "freqs": [0, 0, 0]}
     visited = 0
-    per_list = max(1, max_blocks // max(size, 1))
+    # a uniform sample over the BLOCKS of the index (every step-th full block in index order), so that long lists weigh
+    # what they weigh in the index
+    nfull = [int(oidx.list_size(t)) // 128 for t in range(size)]
+    step = max(1, sum(nfull) // max(max_blocks, 1))
+    cum = 0
     for t in range(size):
+        full = nfull[t]
+        first = (-cum) % step
+        cum += full
+        if first >= full:
+            continue
         off = int(oidx.list_offset(t))
         n, vl = oracle_mod.decode_vbyte(lists[off:off + 5].tobytes())
         nb = (n + 127) // 128
         maxs = np.frombuffer(lists[off + vl:off + vl + 4 * nb].tobytes(), dtype=np.uint32)
         eps = np.frombuffer(lists[off + vl + 4 * nb:off + vl + 4 * nb + 4 * (nb - 1)].tobytes(), dtype=np.uint32)
         data = off + vl + 4 * nb + 4 * (nb - 1)
-        full = n // 128
-        for b in list(range(0, full, max(1, full // per_list)))[:per_list]:
+        for b in range(first, full, step):
             start = data + (int(eps[b - 1]) if b else 0)
             base = int(maxs[b - 1]) + 1 if b else 0
             blk = lists[start:start + 2048].tobytes()
