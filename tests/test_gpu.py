@@ -392,10 +392,26 @@ def test_ranked_and_pruning_fuzz_bit_identical(built_lib, seed):
     qs = d.synth_queries(0xABC0 + seed, nt, 300)
     qs += [[int(t)] for t in rng.integers(0, nt, 20)] + [[0, 1], [0, 1, 2], [nt - 1, 0], list(range(min(nt, 6)))]
     qs += [[int(x) for x in rng.integers(0, min(nt, 12), int(rng.integers(2, 5)))] for _ in range(80)]  # dense lists: big intersections
-    for codec in ("block_optpfor", "opt", "block_mixed"):
+    # (the runtime-codec kernel instantiation -- block_varint / block_interpolative / block_qmx -- spills the most registers:
+    # round 3's divergent-readlane bug only showed there)
+    for codec in ("block_optpfor", "opt", "block_mixed", ("block_varint", "block_qmx", "block_interpolative")[seed % 3]):
         img = d.build_index(codec, nd, lists)
         gidx = d.Index(codec, img, wand)
         oidx = o.Index(codec, img, wand)
+        # and / or: counts (and the doc-id lists of a sample) -- range tables, dense-list bitmaps, the streaming union
+        for op in ("and", "and_freq", "or", "or_freq"):
+            oc, _, _, ofs, _ = oidx.query_batch(op, qs)
+            b = d.Batch(gidx, op, qs, want_matches=op == "and")
+            b.run()
+            gc, _, _, gfs = b.fetch()
+            assert np.array_equal(gc, oc), (codec, op, np.argwhere(gc != oc)[:3])
+            if op.endswith("freq"):
+                assert np.array_equal(gfs, ofs), (codec, op)
+            if op == "and":
+                got = b.fetch_matches(gc)
+                for i in range(0, len(qs), 7):
+                    assert np.array_equal(got[i], oidx.query("and", qs[i], want_matches=True)["matches"]), (codec, qs[i])
+            b.close()
         pipe = d.Pipeline(gidx, depth=2)
         for k in (1, 2, 10, 64):
             oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", qs, k=k)
@@ -928,11 +944,15 @@ def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_BMW_PRUNE=1", "DS2I_NO_SKIPTAB=1", "DS2I_DYN_GROUP=0", "DS2I_DYN_GROUP=1"])
+@pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_BMW_PRUNE=1", "DS2I_NO_SKIPTAB=1", "DS2I_DYN_GROUP=0", "DS2I_DYN_GROUP=1",
+                                  "DS2I_NO_RMW=1", "DS2I_NO_RMW_USE=1", "DS2I_RMW_G=1", "DS2I_NO_BITMAPS=1", "DS2I_NO_BITMAP_USE=1",
+                                  "DS2I_NO_UNION_STREAM=1", "DS2I_UNIT_FACTOR=64"])
 def test_alternative_paths_give_the_same_results(built_lib, knob):
     """The library reads its A/B knobs once per process, so each alternative path -- no block-max table, table present but
-    unused, no interleaved skip table, union kernels without / with exact dynamic-LDS groups -- is driven through one
-    fuzz collection (every codec, k, operator; oracle-checked) in a process of its own."""
+    unused, no interleaved skip table (= no list-0 stream), union kernels without / with exact dynamic-LDS groups, no
+    range tables / tables unused / coarse tables, no dense-list bitmaps / bitmaps unused, or_query through the windowed
+    kernel, very fine work units (many parts per query) -- is driven through one fuzz collection (every codec, k,
+    operator; oracle-checked) in a process of its own."""
     import os, subprocess, sys
     env = dict(os.environ)
     k, v = knob.split("=")
