@@ -134,13 +134,18 @@ struct CtxT {
 
     // ---- decode_docs_block (block_posting_list.hpp:292-319)
     // ---- opt index: chunk b of the list = <=128 elements of one docs partition (device_pef.hpp)
-    DS2I_DEV void decode_docs_pef(uint32_t s, uint32_t b) {
+    // `pre`: the chunk's directory entry (lanes 0 .. PC_WORDS-1) and its cmax (lane PC_WORDS), loaded ahead by the caller
+    DS2I_DEV void decode_docs_pef(uint32_t s, uint32_t b, const uint32_t* pre = nullptr) {
         const uint32_t lane = lane_id();
         const uint8_t* cmaxp = ptr(s, M_MAXS_LO);
         const uint32_t* ent = (const uint32_t*)(ptr(s, M_END_LO) + (uint64_t)b * (4 * PC_WORDS));
         uint32_t ev = 0;
-        if (lane < PC_WORDS) ev = ent[lane];
-        if (lane == PC_WORDS) ev = ((const uint32_t*)cmaxp)[b];
+        if (pre) {
+            ev = *pre;
+        } else {
+            if (lane < PC_WORDS) ev = ent[lane];
+            if (lane == PC_WORDS) ev = ((const uint32_t*)cmaxp)[b];
+        }
         const uint32_t packed = bcast(ev, PC_PACKED), cnt = packed & 0xFFu;
         const uint32_t bmax = bcast(ev, PC_WORDS);
         const uint64_t bit0 = ((uint64_t)m(s, M_DBIT_HI) << 32) | m(s, M_DBIT_LO);

@@ -344,7 +344,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         // never probed or decoded -- membership is all and_query wants from them; the others go by their range-table byte
         // (zero = not a member for sure) and are verified by the usual probe
         uint32_t bm_lists = 0;
-        if constexpr (!RANKED && !WITH_FREQS) {
+        if constexpr (!RANKED) { // (and_freq filters by the bitmap too -- exact, where a byte covering 1..4 doc-ids of a dense list
+                                 // mostly is not zero -- but still probes the list: it needs the matching postings' freqs)
             if (use_rmw && a.rmw_bitmaps) {
                 auto mark = [&](auto ic) __attribute__((always_inline)) {
                     constexpr uint32_t i = decltype(ic)::value;
@@ -385,8 +386,14 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         // window can serve, whose block_max / end offset give that block's base / start): "which block is next" is a ballot
         // over registers, a block's table words cost no load, and the bytes of the block that will be taken after the
         // current one are requested while the current one is still being worked on (pf_d0 / pf_d1: 512 B, two dwords per lane).
-        const bool stream0 = !cx.is_pef() && cx.skip;
-        const uint2* const tab0 = stream0 ? cx.skip + cx.m(0, M_PBASE) : nullptr;
+        // The freq_index layouts stream the same way over their chunk directory: the window holds cmax[] (a chunk's last
+        // doc-id) and the chunk weights, and what is requested ahead is the next chunk's 12-dword directory entry (its bit
+        // positions: the first of the two dependent loads a chunk decode starts with).
+        const bool pstream = cx.is_pef();
+        const bool stream0 = pstream || cx.skip;
+        const uint2* const tab0 = (stream0 && !pstream) ? cx.skip + cx.m(0, M_PBASE) : nullptr;
+        const uint32_t* const cmax0 = pstream ? (const uint32_t*)cx.ptr(0, M_MAXS_LO) : nullptr;
+        const uint32_t* const ent0 = pstream ? (const uint32_t*)cx.ptr(0, M_END_LO) : nullptr;
         const uint8_t* data0 = nullptr;
         uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
         uint2 s_e = make_uint2(0xFFFFFFFFu, 0u);
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             s_e = make_uint2(0xFFFFFFFFu, 0u);
             s_w = 0.f;
             if (idx < u.blk_end) {
-                s_e = tab0[idx];
+                if (pstream) s_e.x = cmax0[idx]; else s_e = tab0[idx];
                 if (RANKED && w0tab) s_w = w0tab[idx];
             }
             s_none = false;
@@ -467,9 +474,11 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             }
         };
         if (stream0) {
-            const uint8_t* maxs0 = cx.ptr(0, M_MAXS_LO);
-            const uint32_t nb0 = cx.m(0, M_NB);
-            data0 = maxs0 + 4ull * nb0 + 4ull * (nb0 - 1);
+            if (!pstream) {
+                const uint8_t* maxs0 = cx.ptr(0, M_MAXS_LO);
+                const uint32_t nb0 = cx.m(0, M_NB);
+                data0 = maxs0 + 4ull * nb0 + 4ull * (nb0 - 1);
+            }
             s_fill(u.blk_begin ? u.blk_begin - 1 : 0);
         }
         // list 0 moves on: `want` = first block with block_max >= lo (or the unit's first block)
@@ -493,8 +502,9 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 if (from >= u.blk_end) break;
                 cx.s_bm_examined += 1;
                 cx.s_bytes += 4;
-                // (measured: consulting it every 4th window instead saves the trips and loses as much to the staler floor)
-            if (shared_floor) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
+                // (the shared histogram costs an L2 round trip: consulted every DS2I_FLOOR_EVERY-th block of list 0; every
+                // block: -3 %, every 16th: -6 % -- the staler floor costs decodes)
+                if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) { PT_BEGIN(cx); adopt_floor(); PT_END(cx, PH_FLOOR); }
                 PT_BEGIN(cx);
                 const uint32_t blk2 = s_next(from);
                 if (blk2 >= u.blk_end) break;
@@ -504,7 +514,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                 bi0.base = blk2 ? bcast(s_e.x, fp) + 1u : 0u;
                 bi0.ep = blk2 ? bcast(s_e.y, fp) : 0u;
                 const bool staged = pf_blk == blk2;
-                if (staged) { // the block's bytes were requested a block ago: from registers into the staging window
+                if (staged && !pstream) { // the block's bytes were requested a block ago: from registers into the staging window
                     const uint8_t* p = data0 + bi0.ep;
                     cx.win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
                     cx.win.nbytes = 512;
@@ -513,7 +523,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     wave_sync();
                 }
                 PT_END(cx, PH_STREAM);
-                cx.decode_docs(0, blk2, &bi0, staged);
+                if (pstream) cx.decode_docs_pef(0, blk2, staged ? &pf_d0 : nullptr);
+                else cx.decode_docs(0, blk2, &bi0, staged);
                 need0 = false;
                 { // request the bytes of the block that is next as things stand (the heap may still rule it out later)
                     PT_BEGIN(cx);
@@ -521,9 +532,15 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     pf_blk = 0xFFFFFFFFu;
                     if (nx) {
                         const uint32_t fn = (uint32_t)__builtin_ctzll(nx);
-                        const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e.y, fn - 1)) & ~(uintptr_t)3);
-                        pf_d0 = g[lane];
-                        pf_d1 = g[lane + 64];
+                        if (pstream) { // the chunk's directory entry (lanes 0..11) and its cmax (lane 12), as decode_docs_pef reads them
+                            const uint32_t nb2 = s_first + fn, cm = bcast(s_e.x, fn);
+                            pf_d0 = lane == PC_WORDS ? cm : 0u;
+                            if (lane < PC_WORDS) pf_d0 = ent0[(size_t)nb2 * PC_WORDS + lane];
+                        } else {
+                            const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e.y, fn - 1)) & ~(uintptr_t)3);
+                            pf_d0 = g[lane];
+                            pf_d1 = g[lane + 64];
+                        }
                         pf_blk = s_first + fn;
                     }
                     PT_END(cx, PH_PREFETCH);
