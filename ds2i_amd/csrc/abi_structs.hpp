@@ -100,6 +100,11 @@ struct BatchArgs {
     // in <= 16 bytes of the level whose entries are wide enough, and bounds every candidate of that block at once.
     const uint8_t* rmw;
     uint32_t rmw_bitmaps;        // the dense lists' exact bitmaps exist behind their tables (RmwLevels::has_bitmap)
+    // k_union_topk (wand / maxscore / ranked_or as streams): units belong to VIRTUAL queries = (query, driving list); qterms /
+    // q_off then describe the virtual queries, and vq_info holds 3 words per virtual query: the real query, the number
+    // of exclusion lists (slots 1 .. nexcl: lists of higher max score -- a document found there is theirs), and the float
+    // bits of the real query's score bound (the scale of its shared score histogram). Null for every other kernel.
+    const uint32_t* vq_info;
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
     uint32_t dyn_lists;          // union kernels: list slots of decoded blocks in dynamic LDS (>= the longest query of the launch)

@@ -51,10 +51,15 @@ struct ds2i_hip_batch {
     std::vector<float> unit_cost;
     std::vector<unsigned long long> match_off;
     std::vector<uint32_t> seed_terms, seed_offs;
+    // wand / maxscore / ranked_or as streams (k_union_topk): the virtual queries (query, driving list) their units belong to
+    std::vector<QTerm> vterms;
+    std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
+    bool union_stream = false;
     uint32_t ncls[NCLS] = {};  // units per kernel class
     uint32_t nqcls[NCLS] = {}; // queries per kernel class
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
+    size_t o_vinfo = 0;
     size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {},
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
@@ -258,6 +263,19 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     const bool rmw_units = ranked && conj && idx->d_rmw; // (and / and_freq verify every candidate the tables let through: their cost
                                                          // stays with the blocks of all lists, and they are throughput-, not tail-bound: measured)
     const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? 4.0 : 16.0;
+    // wand / maxscore / ranked_or: the streaming form (kernels.hip, k_union_topk) needs the range tables and the block weights;
+    // queries beyond 16 terms and k > 64 keep the one-document-per-step kernel, and the whole batch keeps the windowed
+    // kernel when any query does (one operator = one kernel family per batch)
+    static const bool no_topk_stream = std::getenv("DS2I_NO_TOPK_STREAM") != nullptr;
+    const bool disj_topk_op = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
+    static const bool tables_off = std::getenv("DS2I_NO_BMW_PRUNE") || std::getenv("DS2I_NO_RMW_USE"); // (A/B knobs of launch_batch)
+    b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
+                      !b->long_terms && !no_topk_stream && !tables_off;
+    b->vterms.clear();
+    b->voff.assign(1, 0);
+    b->vinfo.clear();
+    static const char* utb = std::getenv("DS2I_UT_BLOCKS");
+    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 96u; // blocks of the driving list per unit
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
         u.q = q;
@@ -297,6 +315,56 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             parts = (nb0 + per - 1) / per;
             if (parts > 1) b->split_queries.push_back(q);
             for (uint32_t j = 0; j < parts; ++j) add_unit(c, q, j * per, std::min(nb0, (j + 1) * per), parts, qcost[q] / parts);
+        } else if (b->union_stream && nt) {
+            // lists by decreasing max score (device-computed list maxima x query weight); a document belongs to the first
+            // list of that order that holds it, so what list e owns scores at most S_e = the maxima from e down. A list
+            // whose S_e is below the static floor (some term's k-th best block weight) gets no units at all -- MaxScore's
+            // non-essential lists, decided at plan time; the kernel re-checks against the live threshold.
+            const size_t begin = qoff[q];
+            uint32_t ord[DS2I_HIP_MAX_TERMS];
+            for (uint32_t i = 0; i < nt; ++i) ord[i] = i;
+            for (uint32_t i = 1; i < nt; ++i) { // stable insertion sort, descending max score
+                const uint32_t v = ord[i];
+                uint32_t j = i;
+                while (j > 0 && qterms[begin + v].max_bmw > qterms[begin + ord[j - 1]].max_bmw) { ord[j] = ord[j - 1]; --j; }
+                ord[j] = v;
+            }
+            float suffix[DS2I_HIP_MAX_TERMS + 1];
+            suffix[nt] = 0.f;
+            for (uint32_t e = nt; e-- > 0;) suffix[e] = suffix[e + 1] + qterms[begin + ord[e]].max_bmw;
+            const float f1 = qterms[begin].floor1;
+            const size_t first_unit = b->units.size();
+            for (uint32_t e = 0; e < nt; ++e) {
+                if (e && suffix[e] * (1.0f + 1.0f / 65536.0f) < f1 * (1.0f - 1.0e-5f)) break; // this list and all after it: non-essential
+                const uint32_t vq = (uint32_t)b->voff.size() - 1;
+                QTerm drv = qterms[begin + ord[e]];
+                drv.suf_bmw = suffix[e + 1];
+                drv.floor1 = f1;
+                b->vterms.push_back(drv);
+                for (uint32_t j = 0; j < e; ++j) { // exclusion lists
+                    QTerm t = qterms[begin + ord[j]];
+                    t.suf_bmw = suffix[e + 1];
+                    b->vterms.push_back(t);
+                }
+                for (uint32_t j = e + 1; j < nt; ++j) { // optional lists
+                    QTerm t = qterms[begin + ord[j]];
+                    t.suf_bmw = suffix[j + 1];
+                    b->vterms.push_back(t);
+                }
+                b->voff.push_back((uint32_t)b->vterms.size());
+                uint32_t sbits;
+                std::memcpy(&sbits, &suffix[0], 4);
+                b->vinfo.push_back(q);
+                b->vinfo.push_back(e);
+                b->vinfo.push_back(sbits);
+                const uint32_t nbe = std::max(1u, qnbs[begin + ord[e]]);
+                const uint32_t parts_e = (nbe + ut_blocks - 1) / ut_blocks, per = (nbe + parts_e - 1) / parts_e;
+                for (uint32_t lo = 0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
+                    add_unit(c, vq, lo, std::min(nbe, lo + per), 0, (double)(nt - e) * 1.0e7 + (double)(std::min(nbe, lo + per) - lo));
+            }
+            const uint32_t total = (uint32_t)(b->units.size() - first_unit);
+            for (size_t ui = first_unit; ui < b->units.size(); ++ui) b->units[ui].nparts = total;
+            if (total > 1) b->split_queries.push_back(q);
         } else {
             // or / ranked_or / wand / maxscore: units are equal-width doc-id ranges; every part keeps its own
             // top-k (its own pruning threshold), the merge is exact
@@ -347,6 +415,10 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
         static const char* dm = std::getenv("DS2I_DYN_MINCLS");
         static const int dyn_mincls = dm ? std::atoi(dm) : 2;
+        if (b->union_stream) { // k_union_topk: static LDS, one launch per class
+            b->sub[c].push_back({0u, b->ncls[c], cls_lists});
+            continue;
+        }
         static const bool no_union_stream2 = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
         if (union_kernel && !ranked && !no_union_stream2) { // or / or_freq: the streaming kernel serves every list count (lists = ~0 says so)
             b->sub[c].push_back({0u, b->ncls[c], 0xFFFFFFFFu});
@@ -385,8 +457,13 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     // ---- layouts
     size_t o = 0;
     auto place = [&](size_t bytes) { size_t at = o; o = align16(o + bytes); return at; };
+    if (b->union_stream) { // the kernels see the virtual queries; the per-query arrays (units by query, histogram slots) stay real
+        qterms.swap(b->vterms);
+        qoff.swap(b->voff);
+    }
     b->o_qterms = place(qterms.size() * sizeof(QTerm));
     b->o_qoff = place(qoff.size() * 4);
+    b->o_vinfo = place(b->union_stream ? b->vinfo.size() * 4 : 0);
     b->o_units = place(b->units.size() * sizeof(Unit));
     b->o_q_unit_off = place(b->q_unit_off.size() * 4);
     b->o_split = place(b->split_queries.size() * 4);
@@ -478,6 +555,7 @@ int upload_batch(ds2i_hip_batch* b) {
     auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) std::memcpy(h + off, src, bytes); };
     put(b->o_qterms, b->qterms.data(), b->qterms.size() * sizeof(QTerm));
     put(b->o_qoff, b->qoff.data(), b->qoff.size() * 4);
+    if (b->union_stream) put(b->o_vinfo, b->vinfo.data(), b->vinfo.size() * 4);
     put(b->o_units, b->units.data(), b->units.size() * sizeof(Unit));
     put(b->o_q_unit_off, b->q_unit_off.data(), b->q_unit_off.size() * 4);
     put(b->o_split, b->split_queries.data(), b->split_queries.size() * 4);
@@ -548,6 +626,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.min_norm_len = idx->min_norm_len;
         a.qterms = b->d_up.at<QTerm>(b->o_qterms);
         a.q_off = b->d_up.at<uint32_t>(b->o_qoff);
+        a.vq_info = b->union_stream ? b->d_up.at<uint32_t>(b->o_vinfo) : nullptr;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
         a.nslice = b->ncls[c];

@@ -1747,6 +1747,347 @@ __global__ void __launch_bounds__(64, DISJ_WAVES(TMAX, MODE)) k_disjunctive(Batc
     cx.flush_stats(a.stats);
 }
 
+// ------------------------------------------------------------------ top-k of the union as streams (wand / maxscore / ranked_or)
+// The three operators return the k best scores of the union of the query's lists (queries.hpp:200-319, 404-476, 478-591);
+// what differs in the reference is only how they avoid scoring everything. Here: the lists of a query are ordered by
+// decreasing max score, and a document BELONGS to the first list of that order that contains it. A unit streams a block
+// range of one list e (its "driver") exactly like ranked_and streams its shortest list -- table window in registers,
+// next block prefetched -- and for every posting of the block gathers its range-table byte in every other list:
+//   * the lists AFTER e (lower max score) are optional: their bytes bound what they can add, a zero byte says the document
+//     is not in that list, so only the few candidates whose bound can enter the heap are ever looked up there;
+//   * the lists BEFORE e are exclusions: a candidate found in one of them belongs to that list's units and is dropped
+//     (a zero byte settles that without a lookup).
+// A document owned by list e occurs in no list of higher max score, so it scores at most S_e = the sum of the max scores
+// from e down: once the threshold passes S_e the units of list e -- and of every later list -- end at once. That is
+// MaxScore's essential / non-essential split (queries.hpp:529-574), evaluated per unit; no list is walked in lock step
+// with another, no window is cut at block boundaries, and every unit is an independent stream for the dispatcher.
+// Every document's score is computed by exactly one unit, as the float32 sum of its term scores in the fixed order
+// driver, optional lists by decreasing max score: wand == maxscore == ranked_or bit for bit, run after run.
+#ifndef DS2I_UT_WAVES2
+#define DS2I_UT_WAVES2 6
+#endif
+constexpr int UT_WAVES(int tmax) { return tmax <= 2 ? DS2I_UT_WAVES2 : tmax <= 4 ? 5 : tmax <= 8 ? 3 : 1; }
+template <int TMAX, bool META_IN_LDS, bool WITH_S16>
+struct LdsUnionTopk : Lds<TMAX, META_IN_LDS, false, WITH_S16, (TMAX > 2) ? 2 : TMAX> {};
+
+template <int TMAX, int CODEC_T, bool STATS = true>
+__global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) {
+    constexpr bool REG = TMAX <= 4;
+    typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
+    __shared__ LdsUnionTopk<TMAX, !REG, CODEC_T != CODEC_PEF> L;
+    const uint32_t lane = lane_id();
+    constexpr bool SHARE_F = TMAX > 2; // one freqs buffer for the driver, one shared by the lists that are looked up
+    CtxT<CODEC_T, META, STATS, SHARE_F> cx = make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a);
+    const float* const bmw = a.bmw;
+    const uint8_t* const rmw = a.rmw;
+    constexpr int NW = (TMAX + 3) / 4; // a candidate's bytes, four lists to a dword (byte i = list slot i; slot 0 unused)
+    for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
+        const uint32_t uid = a.order[tkt];
+        const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
+        const Unit u = a.units[uid];
+        const uint32_t vq = u.q;
+        const uint32_t q = uniform(a.vq_info[3u * vq]), nexcl = uniform(a.vq_info[3u * vq + 1u]);
+        const float s_all = __uint_as_float(uniform(a.vq_info[3u * vq + 2u]));
+        const bool whole = u.nparts == 1;
+        const uint32_t t0 = a.q_off[vq], nt = a.q_off[vq + 1] - t0;
+        TopK tk;
+        tk.init(a.k);
+        auto finish_unit = [&]() __attribute__((always_inline)) {
+            if (whole) {
+                if (lane == 0) a.out_count[q] = tk.n;
+                store_topk(a.out_topk, a.out_topk_len, a.k, q, tk);
+            } else {
+                if (lane == 0) { a.unit_count[uid] = tk.n; a.unit_freq_sum[uid] = 0; }
+                store_topk(a.unit_topk, a.unit_topk_len, a.k, uid, tk);
+            }
+            if (STATS && a.unit_clock && lane == 0) { a.unit_clock[2ull * uid] = t_unit; a.unit_clock[2ull * uid + 1] = wall_clock64(); }
+        };
+        if (nt == 0 || nt > (uint32_t)TMAX) { finish_unit(); continue; }
+        auto bind_one = [&](auto ic) __attribute__((always_inline)) { const uint32_t i = ic; cx.bind(i, a.qterms[t0 + i]); return true; };
+        DS2I_LIST_LOOP(0, bind_one)
+        cx.s_bytes += 4ull * nt;
+        // ---- floors: all lower bounds of the final k-th score of the union
+        if (a.seed_topk && a.seed_len[q] >= a.k) { // the ranked_and pass over (a sub-query of) the same query, relaxed for re-association
+            const float kth = a.seed_topk[(size_t)q * a.k + a.k - 1];
+            tk.floor = __uint_as_float(uniform(__float_as_uint(kth * (1.0f - 1.0e-5f))));
+        }
+        {   // some term has k blocks whose best posting alone reaches floor1 (host, from the upload-time block weights)
+            const float f1 = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].floor1))) * (1.0f - 1.0e-5f);
+            if (f1 > tk.floor) tk.floor = f1;
+        }
+        const bool shared_floor = !whole && a.q_hist;
+        ScoreHist sh;
+        sh.init(shared_floor ? a.q_hist : nullptr, shared_floor ? a.q_hist_slot[q] : 0u, shared_floor ? s_all : 0.f, 1.0f - 1.0f / 1048576.0f);
+        auto adopt_floor = [&]() __attribute__((always_inline)) {
+            const float f = sh.floor(tk.k);
+            if (f > tk.floor) tk.floor = f;
+        };
+        if (shared_floor) adopt_floor();
+        const float qw0 = __uint_as_float(cx.m(0, M_QW));
+        // S_e: a document owned by the driver is in no list of higher max score
+        const float s_e = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw)));
+        if (!tk.would_enter(s_e * BOUND_SLACK)) { finish_unit(); continue; }
+        const float* const w0tab = bmw + cx.m(0, M_PBASE);
+        // a candidate's bytes: byte (i & 3) of word (i >> 2) = its range-table entry in list slot i
+        auto byte_of = [&](const uint32_t* pk, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+            uint32_t w = pk[0];
+#pragma unroll
+            for (int k2 = 1; k2 < NW; ++k2) w = (i >> 2) == (uint32_t)k2 ? pk[k2] : w;
+            return (w >> (8u * (i & 3u))) & 255u;
+        };
+        // what the optional lists after slot `after` can add to the candidate (slots nexcl+1 .. nt-1 are the optional ones)
+        auto rest_of = [&](const uint32_t* pk, uint32_t after) __attribute__((always_inline)) -> float {
+            float r = 0.f;
+            if constexpr (REG) { // (register-resident list state: the slot must be a compile-time constant)
+                auto add_one = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr uint32_t j = decltype(jc)::value;
+                    if (j < nt && j > nexcl && j > after) r = r + __uint_as_float(cx.m(j, M_RSCALE)) * (float)byte_of(pk, j);
+                };
+                static_loop_down<TMAX, 1>(add_one);
+            } else {
+                for (uint32_t j = nt; j-- > 1;) {
+                    if (j <= nexcl || j <= after) break;
+                    r = r + __uint_as_float(cx.m(j, M_RSCALE)) * (float)byte_of(pk, j);
+                }
+            }
+            return r;
+        };
+        // ---- the driver as a stream (see k_conjunctive): table window in registers, next block requested ahead
+        const bool pstream = cx.is_pef();
+        const uint2* const tab0 = pstream ? nullptr : cx.skip + cx.m(0, M_PBASE);
+        const uint32_t* const cmax0 = pstream ? (const uint32_t*)cx.ptr(0, M_MAXS_LO) : nullptr;
+        const uint32_t* const ent0 = pstream ? (const uint32_t*)cx.ptr(0, M_END_LO) : nullptr;
+        const uint8_t* data0 = nullptr;
+        if (!pstream) {
+            const uint32_t nb0 = cx.m(0, M_NB);
+            data0 = cx.ptr(0, M_MAXS_LO) + 4ull * nb0 + 4ull * (nb0 - 1);
+        }
+        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
+        uint2 s_e2 = make_uint2(0xFFFFFFFFu, 0u);
+        float s_w = 0.f, s_rb = 0.f;
+        auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
+            s_first = first;
+            const uint32_t idx = first + lane;
+            s_e2 = make_uint2(0xFFFFFFFFu, 0u);
+            s_w = 0.f;
+            if (idx < u.blk_end) {
+                if (pstream) s_e2.x = cmax0[idx]; else s_e2 = tab0[idx];
+                s_w = w0tab[idx];
+            }
+            // the optional lists' largest entry over the block's own doc-id span (<= 16 bytes of the level that is wide enough)
+            const uint32_t prev_max = (uint32_t)__shfl_up((int)s_e2.x, 1);
+            const uint32_t base = (lane == 0) ? 0u : prev_max + 1u, top = s_e2.x;
+            const bool row = idx < u.blk_end && (lane > 0 || idx == 0) && top != 0xFFFFFFFFu && base <= top;
+            float acc = 0.f;
+            auto span_max = [&](uint32_t sh, uint32_t rbase, float scale) __attribute__((always_inline)) {
+                const RmwLevels g(a.num_docs, sh);
+                const uint8_t* tb = rmw + 64ull * rbase;
+                uint32_t best = 255u;
+                if (row) {
+                    uint32_t lsh = sh, lvl = 0;
+                    while (lvl < 2 && (top >> lsh) - (base >> lsh) >= 16u) { lsh += 6; ++lvl; }
+                    const uint32_t lo2 = base >> lsh, hi2 = top >> lsh;
+                    if (hi2 - lo2 < 16u) {
+                        const uint8_t* lp = tb + g.off[lvl] + lo2;
+                        const uint32_t cnt = hi2 - lo2 + 1u;
+                        uint32_t m = 0;
+#pragma unroll
+                        for (uint32_t k2 = 0; k2 < 16; ++k2) {
+                            const uint32_t v = k2 < cnt ? (uint32_t)lp[k2] : 0u;
+                            m = m > v ? m : v;
+                        }
+                        best = m;
+                    }
+                }
+                acc = acc + scale * (float)best;
+            };
+            if constexpr (REG) {
+                auto one = [&](auto jc) __attribute__((always_inline)) {
+                    constexpr uint32_t j = decltype(jc)::value;
+                    if (j < nt && j > nexcl) span_max(cx.m(j, M_RSHIFT), cx.m(j, M_RBASE), __uint_as_float(cx.m(j, M_RSCALE)));
+                };
+                static_loop_down<TMAX, 1>(one);
+            } else {
+                for (uint32_t j = nt; j-- > 1;) {
+                    if (j <= nexcl) break;
+                    span_max(cx.m(j, M_RSHIFT), cx.m(j, M_RBASE), __uint_as_float(cx.m(j, M_RSCALE)));
+                }
+            }
+            s_rb = acc;
+        };
+        auto s_live = [&](uint32_t from) __attribute__((always_inline)) -> uint64_t {
+            const uint32_t idx = s_first + lane;
+            bool ok = idx >= from && idx < u.blk_end && (lane > 0 || idx == 0);
+            ok = ok && tk.would_enter((qw0 * s_w + s_rb) * BOUND_SLACK);
+            return ballot(ok);
+        };
+        auto s_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {
+            for (;;) {
+                if (from >= u.blk_end) return u.blk_end;
+                const uint64_t hit = s_live(from);
+                if (hit) return s_first + (uint32_t)__builtin_ctzll(hit);
+                if (s_first + 64 >= u.blk_end) return u.blk_end;
+                s_fill(s_first + 63);
+                from = from > s_first + 1 ? from : s_first + 1;
+            }
+        };
+        s_fill(u.blk_begin ? u.blk_begin - 1 : 0);
+        uint32_t from = u.blk_begin, floor_tick = 1;
+        for (;;) {
+            ++cx.s_rounds;
+            if (from >= u.blk_end) break;
+            if (shared_floor && (floor_tick++ & (DS2I_FLOOR_EVERY - 1)) == 0) {
+                adopt_floor();
+                if (!tk.would_enter(s_e * BOUND_SLACK)) break; // the driver became non-essential
+            }
+            const uint32_t blk = s_next(from);
+            if (blk >= u.blk_end) break;
+            from = blk + 1;
+            const uint32_t f = blk - s_first, fp = f ? f - 1 : 0;
+            const float wblk = qw0 * __uint_as_float(bcast(__float_as_uint(s_w), f));
+            const bool staged = pf_blk == blk;
+            if (pstream) {
+                cx.decode_docs_pef(0, blk, staged ? &pf_d0 : nullptr);
+            } else {
+                typename decltype(cx)::BlockInfo bi;
+                bi.bmax = bcast(s_e2.x, f);
+                bi.next_ep = bcast(s_e2.y, f);
+                bi.base = blk ? bcast(s_e2.x, fp) + 1u : 0u;
+                bi.ep = blk ? bcast(s_e2.y, fp) : 0u;
+                if (staged) {
+                    const uint8_t* p = data0 + bi.ep;
+                    cx.win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
+                    cx.win.nbytes = 512;
+                    cx.win.st[lane] = pf_d0;
+                    cx.win.st[lane + 64] = pf_d1;
+                    wave_sync();
+                }
+                cx.decode_docs(0, blk, &bi, staged);
+            }
+            {   // request what the block that is next as things stand will need first
+                const uint64_t nx = s_live(blk + 1);
+                pf_blk = 0xFFFFFFFFu;
+                if (nx) {
+                    const uint32_t fn = (uint32_t)__builtin_ctzll(nx);
+                    if (pstream) {
+                        const uint32_t nb2 = s_first + fn, cm = bcast(s_e2.x, fn);
+                        pf_d0 = lane == PC_WORDS ? cm : 0u;
+                        if (lane < PC_WORDS) pf_d0 = ent0[(size_t)nb2 * PC_WORDS + lane];
+                    } else {
+                        const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e2.y, fn - 1)) & ~(uintptr_t)3);
+                        pf_d0 = g[lane];
+                        pf_d1 = g[lane + 64];
+                    }
+                    pf_blk = s_first + fn;
+                }
+            }
+            const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
+            bool al0 = c0 != 0xFFFFFFFFu, al1 = c1 != 0xFFFFFFFFu;
+            // ---- the candidates' bytes in every other list: one gather per list, all issued before the first is consumed
+            uint32_t pk0[NW] = {}, pk1[NW] = {};
+            {
+                uint32_t e0[TMAX] = {}, e1[TMAX] = {};
+                auto load_one = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    const uint8_t* tab = rmw + 64ull * cx.m(i, M_RBASE);
+                    const uint32_t sh = cx.m(i, M_RSHIFT);
+                    e0[i] = al0 ? (uint32_t)tab[c0 >> sh] : 0u;
+                    e1[i] = al1 ? (uint32_t)tab[c1 >> sh] : 0u;
+                    return true;
+                };
+                static_list_loop<1, TMAX>(nt, load_one);
+                auto pack_one = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    pk0[i >> 2] |= e0[i] << (8u * (i & 3u));
+                    pk1[i >> 2] |= e1[i] << (8u * (i & 3u));
+                    return true;
+                };
+                static_list_loop<1, TMAX>(nt, pack_one);
+            }
+            float r0 = rest_of(pk0, 0), r1 = rest_of(pk1, 0);
+            al0 = al0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
+            al1 = al1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+            if (!(ballot(al0) | ballot(al1))) continue; // nobody of this block can enter: its freqs stay undecoded
+            // ---- the driver's own term score: freq-only bound first, then the norm_len gather
+            cx.decode_freqs(0);
+            const uint32_t f0 = L.freqs[0][lane], f1 = L.freqs[0][lane + 64];
+            al0 = al0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + r0) * BOUND_SLACK);
+            al1 = al1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + r1) * BOUND_SLACK);
+            const float nl0 = al0 ? a.norm_lens[c0] : 0.f, nl1 = al1 ? a.norm_lens[c1] : 0.f;
+            float pa0 = al0 ? qw0 * doc_term_weight(f0, nl0) : 0.f, pa1 = al1 ? qw0 * doc_term_weight(f1, nl1) : 0.f;
+            {
+                const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(al0)) + __builtin_popcountll(ballot(al1)));
+                cx.s_bytes += 4ull * nv;
+                cx.s_scored += nv;
+            }
+            al0 = al0 && tk.would_enter((pa0 + r0) * BOUND_SLACK);
+            al1 = al1 && tk.would_enter((pa1 + r1) * BOUND_SLACK);
+            // ---- the other lists, one after the other: exclusions first (slots 1 .. nexcl), then the optional lists by
+            // decreasing max score; a list is consulted only for the candidates whose byte there is not zero
+            auto resolve_list = [&](auto ic) __attribute__((always_inline)) -> bool {
+                const uint32_t i = ic;
+                if (!(ballot(al0) | ballot(al1))) return false;
+                const bool excl = i <= nexcl;
+                bool n0 = al0 && byte_of(pk0, i) != 0u, n1 = al1 && byte_of(pk1, i) != 0u; // still to be looked up in list i
+                const float qw = __uint_as_float(cx.m(i, M_QW));
+                for (;;) {
+                    const uint64_t b0 = ballot(n0), b1 = ballot(n1);
+                    if (!(b0 | b1)) break;
+                    const uint32_t amin = b0 ? bcast(c0, (uint32_t)__builtin_ctzll(b0)) : bcast(c1, (uint32_t)__builtin_ctzll(b1));
+                    if (cx.m(i, M_CUR) == 0xFFFFFFFFu || amin > cx.m(i, M_BMAX)) {
+                        const uint32_t cur = cx.m(i, M_CUR);
+                        uint32_t blk2, nbmax = 0;
+                        float wdummy = 0.f;
+                        typename decltype(cx)::BlockInfo bi;
+                        const bool tabbed = !cx.is_pef() && cx.skip;
+                        if (tabbed) blk2 = cx.find_block_info(i, cur + 1, amin, bi, nullptr, wdummy);
+                        else blk2 = cx.find_block(i, cur + 1, amin, nbmax, nullptr, wdummy);
+                        cx.s_bm_examined += 1;
+                        cx.s_bytes += 4;
+                        if (blk2 >= cx.m(i, M_NB)) break; // the list has nothing at or after amin: nobody left is in it
+                        cx.decode_docs(i, blk2, tabbed ? &bi : nullptr);
+                    }
+                    const uint32_t bm = cx.m(i, M_BMAX);
+                    const bool w0 = n0 && c0 <= bm, w1 = n1 && c1 <= bm;
+                    uint32_t p0 = 0, p1 = 0;
+                    const bool m0 = member_bsearch(L.docs[i], c0, w0, p0), m1 = member_bsearch(L.docs[i], c1, w1, p1);
+                    if (excl) { // found in a list of higher max score: the document is that list's
+                        al0 = al0 && !m0;
+                        al1 = al1 && !m1;
+                    } else if (ballot(m0) | ballot(m1)) {
+                        if (!cx.freqs_ready(i)) cx.decode_freqs(i);
+                        const uint32_t* fr = cx.F(i);
+                        if (m0) pa0 = pa0 + qw * doc_term_weight(fr[p0], nl0);
+                        if (m1) pa1 = pa1 + qw * doc_term_weight(fr[p1], nl1);
+                    }
+                    n0 = n0 && !w0;
+                    n1 = n1 && !w1;
+                }
+                if (!excl) { // who cannot reach the heap any more is not looked up in the lists still to come
+                    al0 = al0 && tk.would_enter((pa0 + rest_of(pk0, i)) * BOUND_SLACK);
+                    al1 = al1 && tk.would_enter((pa1 + rest_of(pk1, i)) * BOUND_SLACK);
+                }
+                return true;
+            };
+            DS2I_LIST_LOOP(1, resolve_list)
+            // ---- whoever is still alive has its complete score
+            for (int half = 0; half < 2; ++half) {
+                const bool al = half ? al1 : al0;
+                const float sc = half ? pa1 : pa0;
+                uint64_t todo = ballot(al && tk.would_enter(sc));
+                while (todo) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
+                    if (tk.insert(v) && shared_floor && lane == 0) sh.add(v);
+                }
+            }
+        }
+        finish_unit();
+    }
+    cx.flush_stats(a.stats);
+}
+
 // ------------------------------------------------------------------ or_query as a stream
 // or_query<with_freqs> (queries.hpp:88-131) returns the size of the union of the query's lists (and touches every freq).
 // There is nothing to prune and nothing to rank, so the lists need not be walked in lock step at all: a unit owns a doc-id
@@ -2208,6 +2549,13 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
     case OP_WAND:
     case OP_MAXSCORE:
     case OP_RANKED_OR:
+        if (a.vq_info) { // the streaming form (units = (query, driving list, block range)); needs the range tables
+            if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+            else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+            else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_PEF>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((k_union_topk<TMAX, -1>), g, b, 0, s, a);
+            break;
+        }
         if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, dyn, s, a);
         else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, dyn, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, dyn, s, a);
