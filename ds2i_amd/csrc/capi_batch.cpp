@@ -315,7 +315,13 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             parts = (nb0 + per - 1) / per;
             if (parts > 1) b->split_queries.push_back(q);
             for (uint32_t j = 0; j < parts; ++j) add_unit(c, q, j * per, std::min(nb0, (j + 1) * per), parts, qcost[q] / parts);
-        } else if (b->union_stream && nt) {
+        } else if (b->union_stream && !nt) { // empty query: one unit of an empty virtual query writes the empty answer
+            b->voff.push_back((uint32_t)b->vterms.size());
+            b->vinfo.push_back(q);
+            b->vinfo.push_back(0);
+            b->vinfo.push_back(0);
+            add_unit(c, (uint32_t)b->voff.size() - 2, 0, 0, 1, 0.0);
+        } else if (b->union_stream) {
             // lists by decreasing max score (device-computed list maxima x query weight); a document belongs to the first
             // list of that order that holds it, so what list e owns scores at most S_e = the maxima from e down. A list
             // whose S_e is below the static floor (some term's k-th best block weight) gets no units at all -- MaxScore's
