@@ -361,7 +361,12 @@ def main():
             return "k_daat_long<%s>" % args.op
         if args.op in kname:
             return "%s,TMAX=%d>" % (kname[args.op], (2, 4, 8, 16)[c])
-        return "k_disjunctive<TMAX=%d> (%s)" % ((2, 4, 8, 16)[c], args.op)
+        if args.op in ("or", "or_freq"):
+            stream = not os.environ.get("DS2I_NO_UNION_STREAM")
+            return ("k_union<%s> (<=%d lists)" if stream else "k_disjunctive<TMAX=%d> (%s)") % (
+                ("true" if args.op == "or_freq" else "false", (2, 4, 8, 16)[c]) if stream else ((2, 4, 8, 16)[c], args.op))
+        stream = not any(os.environ.get(e) for e in ("DS2I_NO_TOPK_STREAM", "DS2I_NO_BMW_PRUNE", "DS2I_NO_RMW_USE", "DS2I_NO_RMW"))
+        return ("k_union_topk<TMAX=%d> (%s)" if stream else "k_disjunctive<TMAX=%d> (%s)") % ((2, 4, 8, 16)[c], args.op)
     per_class = []
     for c in range(NCLS):
         nqc = cls_stats[c][1]

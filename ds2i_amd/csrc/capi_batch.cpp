@@ -506,6 +506,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // documents, while the rarest pair is cheap to intersect and carries the largest term weights.
         static const char* sv = std::getenv("DS2I_SEED_TERMS");
         const size_t seed_terms = sv && std::atoi(sv) > 0 ? (size_t)std::atoi(sv) : 2;
+        // The streams (k_union_topk) start from the static floor and share a score histogram per query: measured on the
+        // GOV2-scale wand batch the sub-query pass costs 8.3 ms to save 17 % of the block decodes (209 k queries/s with it,
+        // 278 k without), so there only the one-term queries keep it -- it is what answers them. DS2I_SEED_STREAM=1: A/B.
+        static const char* s1 = std::getenv("DS2I_SEED_STREAM");
+        const bool seed_single_only = b->union_stream && !(s1 && std::atoi(s1) > 0);
         auto& sterms = b->seed_terms;
         auto& soffs = b->seed_offs;
         sterms.clear();
@@ -517,7 +522,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             dt.assign(qb, qe);
             std::sort(dt.begin(), dt.end());
             dt.erase(std::unique(dt.begin(), dt.end()), dt.end());
-            if (dt.size() > seed_terms && dt.size() > 2) {
+            if (seed_single_only && dt.size() > 1) {
+                // no sub-query: the stream kernels find their floor themselves (static floor + shared histogram)
+            } else if (dt.size() > seed_terms && dt.size() > 2) {
                 std::stable_sort(dt.begin(), dt.end(), [&](uint32_t x, uint32_t y) { return idx->list_n[x] < idx->list_n[y]; });
                 dt.resize(std::max<size_t>(2, seed_terms));
                 for (const uint32_t* p = qb; p != qe; ++p) // keep multiplicities: the query term weight counts them
