@@ -1,0 +1,29 @@
+#!/bin/bash
+# Usage (GPU box, repo root): bash profiles/probes/pmc_issue.sh <tag> [workload] [op]
+# instruction-cache and issue counters of the class kernels, each group in its own rocprofv3 --pmc run (no trace domains)
+set -u
+TAG=${1:-issue}; WL=${2:-gov2}; OP=${3:-ranked_and}
+OUT=gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for PASS in "icache:SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVES GRBM_GUI_ACTIVE" \
+            "issue:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+            "issue2:SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  NAME=${PASS%%:*}; CTRS=${PASS#*:}
+  timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
+      python bench.py --workload $WL --op $OP --steps 4 --warmup 1 --no-oracle > /dev/null 2> $OUT/pmc_$NAME.err
+  python - "$OUT" "$NAME" <<'PY'
+import csv, glob, collections, sys
+out, name = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(list)
+for f in glob.glob("%s/pmc_%s/**/*counter_collection.csv" % (out, name), recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+with open("%s/counters_%s.txt" % (out, name), "w") as fo:
+    for (k, n), v in sorted(agg.items()):
+        if "rocclr" in k or ", true>(" in k: continue
+        fo.write("%s\t%s\tdispatches=%d\tmean=%.1f\n" % (k[:78], n, len(v), sum(v) / len(v)))
+PY
+  rm -rf $OUT/pmc_$NAME
+done
+grep -E "k_conjunctive|k_union|k_disj" $OUT/counters_*.txt | cut -c1-200
