@@ -211,6 +211,23 @@ struct LdsConj : Lds<TMAX, META_IN_LDS, !RANKED, WITH_S16, (RANKED && TMAX > 2) 
     uint32_t qb2[RANKED && (TMAX > 4) ? 128 : 1];
 };
 
+// largest of the first `cnt` (1..16) bytes at lp. All 16 bytes are read with one unconditional (unaligned) load -- up to 15
+// of them beyond the span, still inside the table area (every table is padded, the area ends with 64 spare bytes) -- so
+// the lanes of a window have their loads in flight together; written as 16 predicated byte loads the compiler emitted
+// 16 dependent round trips.
+DS2I_DEV uint32_t max_of_bytes16(const uint8_t* lp, uint32_t cnt) {
+    uint32_t w[4];
+    __builtin_memcpy(w, lp, 16);
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        uint32_t v = (w[k >> 2] >> (8u * (k & 3u))) & 255u;
+        v = k < cnt ? v : 0u;
+        m = m > v ? m : v;
+    }
+    return m;
+}
+
 template <bool RANKED, bool WITH_FREQS, int TMAX, int CODEC_T, bool STATS = true>
 __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(BatchArgs a) {
     // <=4 lists: every list loop below is fully unrolled, so the enumerator state is addressed with constants
@@ -426,21 +443,14 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                         const RmwLevels g(a.num_docs, sh);
                         const uint8_t* tb = rmw + 64ull * cx.m(j, M_RBASE);
                         uint32_t best = 255u; // (the list maximum)
-                        if (row) {
+                        {   // branch-free: a lane without a row reads entry 0 and discards it
+                            const uint32_t b2 = row ? base : 0u, t2 = row ? top : 0u;
                             uint32_t lsh = sh, lvl = 0;
-                            while (lvl < 2 && (top >> lsh) - (base >> lsh) >= 16u) { lsh += 6; ++lvl; }
-                            const uint32_t lo = base >> lsh, hi = top >> lsh;
-                            if (hi - lo < 16u) {
-                                const uint8_t* lp = tb + g.off[lvl] + lo;
-                                const uint32_t cnt = hi - lo + 1u;
-                                uint32_t m = 0;
-#pragma unroll
-                                for (uint32_t k = 0; k < 16; ++k) {
-                                    const uint32_t v = k < cnt ? (uint32_t)lp[k] : 0u;
-                                    m = m > v ? m : v;
-                                }
-                                best = m;
-                            }
+                            while (lvl < 2 && (t2 >> lsh) - (b2 >> lsh) >= 16u) { lsh += 6; ++lvl; }
+                            const uint32_t lo = b2 >> lsh, hi = t2 >> lsh;
+                            const bool fits = hi - lo < 16u;
+                            const uint32_t m = max_of_bytes16(tb + g.off[lvl] + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
+                            if (row && fits) best = m;
                         }
                         s_none = s_none || best == 0u;
                         if constexpr (RANKED) acc = acc + __uint_as_float(cx.m(j, M_RSCALE)) * (float)best;
@@ -1883,21 +1893,14 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                 const RmwLevels g(a.num_docs, sh);
                 const uint8_t* tb = rmw + 64ull * rbase;
                 uint32_t best = 255u;
-                if (row) {
+                {   // branch-free (see k_conjunctive): a lane without a row reads entry 0 and discards it
+                    const uint32_t b2 = row ? base : 0u, t2 = row ? top : 0u;
                     uint32_t lsh = sh, lvl = 0;
-                    while (lvl < 2 && (top >> lsh) - (base >> lsh) >= 16u) { lsh += 6; ++lvl; }
-                    const uint32_t lo2 = base >> lsh, hi2 = top >> lsh;
-                    if (hi2 - lo2 < 16u) {
-                        const uint8_t* lp = tb + g.off[lvl] + lo2;
-                        const uint32_t cnt = hi2 - lo2 + 1u;
-                        uint32_t m = 0;
-#pragma unroll
-                        for (uint32_t k2 = 0; k2 < 16; ++k2) {
-                            const uint32_t v = k2 < cnt ? (uint32_t)lp[k2] : 0u;
-                            m = m > v ? m : v;
-                        }
-                        best = m;
-                    }
+                    while (lvl < 2 && (t2 >> lsh) - (b2 >> lsh) >= 16u) { lsh += 6; ++lvl; }
+                    const uint32_t lo2 = b2 >> lsh, hi2 = t2 >> lsh;
+                    const bool fits = hi2 - lo2 < 16u;
+                    const uint32_t m = max_of_bytes16(tb + g.off[lvl] + (fits ? lo2 : 0u), fits ? hi2 - lo2 + 1u : 1u);
+                    if (row && fits) best = m;
                 }
                 acc = acc + scale * (float)best;
             };

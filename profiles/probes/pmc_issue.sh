@@ -10,7 +10,7 @@ for PASS in "icache:SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_
             "issue:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
             "issue2:SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   NAME=${PASS%%:*}; CTRS=${PASS#*:}
-  timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
+  timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
       python bench.py --workload $WL --op $OP --steps 4 --warmup 1 --no-oracle > /dev/null 2> $OUT/pmc_$NAME.err
   python - "$OUT" "$NAME" <<'PY'
 import csv, glob, collections, sys
