@@ -6,14 +6,14 @@ TAG=${1:-r03}; WL=${2:-gov2}; OP=${3:-ranked_and}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- \
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- \
     python bench.py --workload $WL --op $OP --steps 60 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 KS=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
 if [ -n "$KS" ]; then cp "$KS" $OUT/kernel_stats.csv; fi
 rm -rf $OUT/kt
 for PASS in "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   NAME=${PASS%%:*}; CTRS=${PASS#*:}
-  timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
+  timeout 420 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
       python bench.py --workload $WL --op $OP --steps 4 --warmup 1 --no-oracle > /dev/null 2> $OUT/pmc_$NAME.err
   python - "$OUT" "$NAME" <<'PY'
 import csv, glob, collections, sys
