@@ -105,6 +105,7 @@ struct BatchArgs {
     // of exclusion lists (slots 1 .. nexcl: lists of higher max score -- a document found there is theirs), and the float
     // bits of the real query's score bound (the scale of its shared score histogram). Null for every other kernel.
     const uint32_t* vq_info;
+    uint32_t ut_first;    // k_union_topk: optional lists gathered in the first trip (0 = every list in one trip; DS2I_UT_FIRST)
     uint32_t* long_scratch;      // "long" class (> 16 terms): per-unit enumerator state in global memory
     uint32_t long_stride;        // dwords of scratch per unit
     uint32_t dyn_lists;          // union kernels: list slots of decoded blocks in dynamic LDS (>= the longest query of the launch)

@@ -640,6 +640,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.qterms = b->d_up.at<QTerm>(b->o_qterms);
         a.q_off = b->d_up.at<uint32_t>(b->o_qoff);
         a.vq_info = b->union_stream ? b->d_up.at<uint32_t>(b->o_vinfo) : nullptr;
+        static const char* utf = std::getenv("DS2I_UT_FIRST");
+        a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
         a.nslice = b->ncls[c];

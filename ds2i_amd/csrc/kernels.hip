@@ -1834,6 +1834,7 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
         };
         if (shared_floor) adopt_floor();
         const float qw0 = __uint_as_float(cx.m(0, M_QW));
+        const bool two_trips = TMAX > 2 && a.ut_first && nexcl + a.ut_first + 1u < nt; // (optional lists are left for a second trip)
         // S_e: a document owned by the driver is in no list of higher max score
         const float s_e = __uint_as_float(uniform(__float_as_uint(a.qterms[t0].max_bmw + a.qterms[t0].suf_bmw)));
         if (!tk.would_enter(s_e * BOUND_SLACK)) { finish_unit(); continue; }
@@ -1989,16 +1990,43 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
             // ---- the candidates' bytes in every other list: one gather per list, all issued before the first is consumed
             uint32_t pk0[NW] = {}, pk1[NW] = {};
             {
+                // Two trips when the driver has two or more optional lists: first the exclusion lists and the optional list
+                // of highest max score (slots 1 .. split), then -- only for the candidates that can still enter the heap with
+                // that list's byte and the LIST maxima of the ones after it -- the rest. The later lists are the long,
+                // low-scoring ones: their tables are the ones in which every candidate hits a line of its own.
                 uint32_t e0[TMAX] = {}, e1[TMAX] = {};
-                auto load_one = [&](auto ic) __attribute__((always_inline)) {
+                const uint32_t split = two_trips ? nexcl + a.ut_first : (uint32_t)TMAX;
+                float f0 = 0.f, f1 = 0.f, suf_split = 0.f;
+                auto load_first = [&](auto ic) __attribute__((always_inline)) {
                     constexpr uint32_t i = decltype(ic)::value;
+                    if (i > split) return true;
                     const uint8_t* tab = rmw + 64ull * cx.m(i, M_RBASE);
                     const uint32_t sh = cx.m(i, M_RSHIFT);
                     e0[i] = al0 ? (uint32_t)tab[c0 >> sh] : 0u;
                     e1[i] = al1 ? (uint32_t)tab[c1 >> sh] : 0u;
+                    if (i > nexcl) { // an optional list of the first trip: what its byte says it can add
+                        const float sc = __uint_as_float(cx.m(i, M_RSCALE));
+                        f0 = f0 + sc * (float)e0[i];
+                        f1 = f1 + sc * (float)e1[i];
+                        if (i == split) suf_split = __uint_as_float(cx.m(i, M_SUF)); // + the list maxima of the ones after it
+                    }
                     return true;
                 };
-                static_list_loop<1, TMAX>(nt, load_one);
+                static_list_loop<1, TMAX>(nt, load_first);
+                if (split + 1u < nt) {
+                    al0 = al0 && tk.would_enter((wblk + f0 + suf_split) * BOUND_SLACK);
+                    al1 = al1 && tk.would_enter((wblk + f1 + suf_split) * BOUND_SLACK);
+                    auto load_rest = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr uint32_t i = decltype(ic)::value;
+                        if (i <= split) return true;
+                        const uint8_t* tab = rmw + 64ull * cx.m(i, M_RBASE);
+                        const uint32_t sh = cx.m(i, M_RSHIFT);
+                        e0[i] = al0 ? (uint32_t)tab[c0 >> sh] : 0u;
+                        e1[i] = al1 ? (uint32_t)tab[c1 >> sh] : 0u;
+                        return true;
+                    };
+                    static_list_loop<1, TMAX>(nt, load_rest);
+                }
                 auto pack_one = [&](auto ic) __attribute__((always_inline)) {
                     constexpr uint32_t i = decltype(ic)::value;
                     pk0[i >> 2] |= e0[i] << (8u * (i & 3u));
