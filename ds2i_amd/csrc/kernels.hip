@@ -2183,27 +2183,32 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                 wave_sync();
                 for (uint32_t i = 0; i < nt; ++i) {
                     if (uniform(L.nextbase[i]) >= hi) continue;
-                    if constexpr (!WITH_FREQS) {
-                        // a dense list (>= one document in 64) has its exact bitmap behind its range table: its part of the
-                        // piece is 1024 words to OR in, not a hundred blocks to decode
-                        const QTerm& qt = a.qterms[t0 + i];
-                        if (a.rmw_bitmaps && RmwLevels::has_bitmap(qt.n, a.num_docs)) {
-                            const uint32_t* bm = (const uint32_t*)(a.rmw + 64ull * qt.rmw_off64 + RmwLevels(a.num_docs, qt.rmw_shift).bytes());
-                            const uint32_t w0 = lo >> 5, shft = lo & 31u, nbits = hi - lo;
+                    // a dense list (>= one document in 64) has its exact bitmap behind its range table: its part of the
+                    // piece is 1024 words to OR in, not a hundred blocks to decode
+                    const QTerm& qt = a.qterms[t0 + i];
+                    const bool from_bitmap = a.rmw_bitmaps && RmwLevels::has_bitmap(qt.n, a.num_docs);
+                    if (from_bitmap) {
+                        const uint32_t* bm = (const uint32_t*)(a.rmw + 64ull * qt.rmw_off64 + RmwLevels(a.num_docs, qt.rmw_shift).bytes());
+                        const uint32_t w0 = lo >> 5, shft = lo & 31u, nbits = hi - lo;
 #pragma unroll
-                            for (uint32_t k = 0; k < UNION_PIECE / 32 / 64; ++k) {
-                                const uint32_t idx = k * 64 + lane;
-                                if (32u * idx < nbits) {
-                                    uint32_t v = __builtin_amdgcn_alignbit(bm[w0 + idx + 1], bm[w0 + idx], shft); // bit j = doc-id lo + 32 idx + j
-                                    const uint32_t left = nbits - 32u * idx;
-                                    if (left < 32u) v &= (1u << left) - 1u;
-                                    L.bits[idx] |= v;
-                                }
+                        for (uint32_t k = 0; k < UNION_PIECE / 32 / 64; ++k) {
+                            const uint32_t idx = k * 64 + lane;
+                            if (32u * idx < nbits) {
+                                uint32_t v = __builtin_amdgcn_alignbit(bm[w0 + idx + 1], bm[w0 + idx], shft); // bit j = doc-id lo + 32 idx + j
+                                const uint32_t left = nbits - 32u * idx;
+                                if (left < 32u) v &= (1u << left) - 1u;
+                                L.bits[idx] |= v;
                             }
+                        }
+                        if constexpr (!WITH_FREQS) {
                             if (lane == 0) L.nextbase[i] = hi < unit_hi ? hi : 0xFFFFFFFFu;
                             wave_sync();
                             continue;
                         }
+                        // or_query<true> still reads every freq (queries.hpp:118-120): the list's blocks are walked below, but a
+                        // block that lies wholly inside the piece has nothing left to say about doc-ids -- its docs part is
+                        // stepped over by its header and only its freqs are decoded (OptPFor full blocks)
+                        wave_sync();
                     }
                     cx.bind(0, a.qterms[t0 + i]);
                     const uint32_t nb = cx.m(0, M_NB);
@@ -2223,6 +2228,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                     };
                     if (tabbed && b < nb) wfill(b ? b - 1 : 0);
                     while (b < nb) {
+                        bool freqs_only = false;
                         if (tabbed) {
                             if (b - wfirst > 63u) wfill(b - 1);
                             const uint32_t f = b - wfirst, fp = f ? f - 1 : 0;
@@ -2233,15 +2239,37 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                             bi.ep = b ? bcast(we.y, fp) : 0u;
                             if (bi.base >= hi) { base = bi.base; break; } // the block starts behind the piece: not decoded yet
                             const bool staged = pf_blk == b;
+                            const uint8_t* const pblk = data + bi.ep;
                             if (staged) {
-                                const uint8_t* p = data + bi.ep;
-                                cx.win.gbase = (const uint8_t*)((uintptr_t)p & ~(uintptr_t)3);
+                                cx.win.gbase = (const uint8_t*)((uintptr_t)pblk & ~(uintptr_t)3);
                                 cx.win.nbytes = 512;
                                 cx.win.st[lane] = pf0;
                                 cx.win.st[lane + 64] = pf1;
                                 wave_sync();
                             }
-                            cx.decode_docs(0, b, &bi, staged);
+                            if constexpr (WITH_FREQS && CODEC_T == CODEC_OPTPFOR)
+                                freqs_only = from_bitmap && bi.base >= lo && bi.bmax < hi && (b + 1u) * 128u <= cx.m(0, M_N);
+                            if (freqs_only) {
+                                if (!staged) {
+                                    uint32_t hint = bi.next_ep - bi.ep;
+                                    if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+                                    cx.win.load(pblk, hint);
+                                }
+                                const uint32_t hdr = uniform(cx.win.rd32(pblk)); // OptPFor header: b | exceptions | Simple16 words
+                                const uint32_t hb = hdr >> 26, hew = hdr & 0xFFFFu;
+                                const uint32_t docs_bytes = hb >= 32 ? 4u * (1u + 128u) : 4u * (1u + hew + 4u * hb);
+                                const uint64_t fo = (uint64_t)(pblk + docs_bytes - cx.arena);
+                                cx.setm(0, M_CUR, b);
+                                cx.setm(0, M_SIZE, 128u);
+                                cx.setm(0, M_BMAX, bi.bmax);
+                                cx.setm(0, M_FREQ_LO, (uint32_t)fo);
+                                cx.setm(0, M_FREQ_HI, (uint32_t)(fo >> 32));
+                                cx.setm(0, M_FDEC, 0);
+                                cx.setm(0, M_DDEC, 0);
+                                cx.s_bytes += 8; // endpoint + header
+                            } else {
+                                cx.decode_docs(0, b, &bi, staged);
+                            }
                             pf_blk = 0xFFFFFFFFu;
                             if (b + 1 < nb && bi.bmax + 1u < hi) { // the next block reaches into this piece too: request its bytes now
                                 const uint32_t* g = (const uint32_t*)((uintptr_t)(data + bi.next_ep) & ~(uintptr_t)3);
@@ -2252,16 +2280,25 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                         } else {
                             cx.decode_docs(0, b);
                         }
-                        const uint32_t d0 = L.docs[0][lane], d1 = L.docs[0][lane + 64];
-                        const bool in0 = d0 >= lo && d0 < hi, in1 = d1 >= lo && d1 < hi; // (the padding doc-id 0xFFFFFFFF is never inside)
-                        if (in0) atomicOr(&L.bits[(d0 - lo) >> 5], 1u << ((d0 - lo) & 31u));
-                        if (in1) atomicOr(&L.bits[(d1 - lo) >> 5], 1u << ((d1 - lo) & 31u));
-                        if constexpr (WITH_FREQS) { // or_query<true> reads the freq of every posting it passes (queries.hpp:118-120)
-                            if (ballot(in0) | ballot(in1)) {
-                                cx.decode_freqs(0);
-                                unsigned long long fs = (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
-                                for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
-                                fsum += fs;
+                        if (freqs_only) { // (every posting of the block is inside the piece, and its bits are set already)
+                            cx.decode_freqs(0);
+                            unsigned long long fs = (unsigned long long)L.freqs[0][lane] + L.freqs[0][lane + 64];
+                            for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                            fsum += fs;
+                        } else {
+                            const uint32_t d0 = L.docs[0][lane], d1 = L.docs[0][lane + 64];
+                            const bool in0 = d0 >= lo && d0 < hi, in1 = d1 >= lo && d1 < hi; // (the padding doc-id 0xFFFFFFFF is never inside)
+                            if (!from_bitmap) {
+                                if (in0) atomicOr(&L.bits[(d0 - lo) >> 5], 1u << ((d0 - lo) & 31u));
+                                if (in1) atomicOr(&L.bits[(d1 - lo) >> 5], 1u << ((d1 - lo) & 31u));
+                            }
+                            if constexpr (WITH_FREQS) { // or_query<true> reads the freq of every posting it passes (queries.hpp:118-120)
+                                if (ballot(in0) | ballot(in1)) {
+                                    cx.decode_freqs(0);
+                                    unsigned long long fs = (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
+                                    for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                                    fsum += fs;
+                                }
                             }
                         }
                         const uint32_t bmax = cx.m(0, M_BMAX);
