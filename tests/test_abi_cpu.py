@@ -76,6 +76,24 @@ def test_device_code_has_no_function_calls(built_lib, tmp_path):
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
         dis = subprocess.run([tools[2], "-d", "--no-show-raw-insn", elf], capture_output=True, text=True, check=True).stdout
         assert dis.count("s_swappc_b64") == 0 and dis.count("s_call_b64") == 0, i
-        seen += "".join(sorted(set(re.findall(r"k_(?:conjunctive|disjunctive|daat|merge|decode_list)", dis))))
-    for k in ("k_conjunctive", "k_disjunctive", "k_daat", "k_merge", "k_decode_list"):
+        seen += "".join(sorted(set(re.findall(r"k_(?:conjunctive|disjunctive|daat|merge|decode_list|union_topk|unionILb)", dis))))
+    for k in ("k_conjunctive", "k_disjunctive", "k_daat", "k_merge", "k_decode_list", "k_union_topk", "k_unionILb"):
         assert k in seen
+
+
+def test_documented_knobs_exist_in_the_source():
+    """DESIGN.md section 7c lists the environment knobs of the library: every name in that table must be read somewhere in
+    the product sources (a renamed or removed knob would otherwise stay documented, and an A/B reported against it would
+    silently have compared a build with itself)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "DESIGN.md")).read()
+    a, b = doc.index("## 7c. Tuning knobs"), doc.index("## 8. Out of scope")
+    names = sorted(set(re.findall(r"`(DS2I_[A-Z0-9_]+|GPU_MAX_HW_QUEUES)", doc[a:b])))
+    assert len(names) >= 20
+    src = ""
+    csrc = os.path.join(root, "ds2i_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            src += open(os.path.join(csrc, f), errors="replace").read()
+    missing = [n for n in names if n not in src]
+    assert not missing, missing
