@@ -44,6 +44,10 @@ class SynthParams(C.Structure):
 
 
 def library_path():
+    # DS2I_LIB_VARIANT=name loads a diagnostic / A-B build of the same library (ds2i_amd/build.py, DS2I_BUILD_VARIANT)
+    variant = os.environ.get("DS2I_LIB_VARIANT", "")
+    if variant:
+        return os.path.join(_HERE, "..", "profiles", "tmp_libs", "lib_%s.so" % variant)
     return os.path.join(_HERE, "libds2i_hip.so")
 
 
@@ -422,7 +426,8 @@ class Batch:
         return st, n.value
 
     def phase_cycles(self, cls):
-        names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert", "stream", "prefetch", "floor", "unit")
+        names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert", "stream", "prefetch", "floor", "unit",
+                 "n_visit", "n_surv1", "n_surv2", "n_bdocs", "n_bfreqs", "n_heap", "n_liverounds")
         out = np.zeros(len(names), dtype=np.uint64)
         _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), len(names)))
         return dict(zip(names, out.tolist()))

@@ -11,9 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libds2i_hip.so")
 ARCH = "gfx950"
 
+# ranked_stream.hip holds the pipelined ranked_and kernels of the benchmark configuration;
 # kernels.hip is compiled six times: once per list-count class (-DDS2I_TU_TMAX=n: the query kernels of that class; 0 = the
 # long class) and once for everything else; encode_kernels.hip holds the index encoder; all units are built in parallel
-DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", []), ("encode_kernels.hip", "encode_kernels.hip", [])]
+DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", []), ("ranked_stream.hip", "ranked_stream.hip", []), ("encode_kernels.hip", "encode_kernels.hip", [])]
 HOST_SRCS = ["capi.cpp", "capi_batch.cpp", "capi_build.cpp", "capi_encode.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
@@ -36,8 +37,18 @@ def _headers():
 def build(verbose=False, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("DS2I_EXTRA_CFLAGS", "").split()  # e.g. -DDS2I_PHASE_TIMING (diagnostic build)
-    force = force or bool(extra)
+    # DS2I_BUILD_VARIANT=name: a diagnostic / A-B build beside the product (own object directory, library written to
+    # profiles/tmp_libs/lib_<name>.so -- git-ignored, travels to the GPU box); the product library is left alone
+    variant = os.environ.get("DS2I_BUILD_VARIANT", "")
+    lib = LIB
     objdir = os.path.join(CSRC, "build")
+    if variant:
+        objdir = os.path.join(CSRC, "build", "variant_" + variant)
+        libdir = os.path.join(HERE, "..", "profiles", "tmp_libs")
+        os.makedirs(libdir, exist_ok=True)
+        lib = os.path.join(libdir, "lib_%s.so" % variant)
+    else:
+        force = force or bool(extra)
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
     objs, jobs = [], []
@@ -60,12 +71,12 @@ def build(verbose=False, force=False):
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
             list(pool.map(run, jobs))
-    if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    if force or _newer(lib, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

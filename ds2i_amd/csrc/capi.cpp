@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -153,7 +154,24 @@ int build_block_max_weights(ds2i_hip_index* x) {
     // the GOV2-scale ranked_and batch (queries/s): G = 1: 335 k, 2: 460 k, 4: 503 k, 8: 474 k.
     static const char* gs = std::getenv("DS2I_RMW_G");
     const double G = gs ? std::atof(gs) : 4.0;
-    if (!(G > 0) || std::getenv("DS2I_NO_RMW")) return DS2I_OK;
+    if (!(G > 0) || std::getenv("DS2I_NO_RMW")) return DS2I_OK; // asked not to build them
+    x->rmw_g = (int)G;
+    // The tables are an accelerator, never a reason to fail an upload -- but running without them changes which kernel
+    // family answers wand / maxscore / ranked_or and costs ranked_and and `and` most of their speed, so the decision is
+    // never silent: it is reported through ds2i_hip_index_get_info(), said once on stderr, and DS2I_RMW_REQUIRE=1 turns
+    // it into DS2I_ENOMEM.
+    auto without_tables = [&](const char* why, uint64_t want) -> int {
+        x->list_rmw_off64.clear();
+        x->list_rmw_shift.clear();
+        if (std::getenv("DS2I_RMW_REQUIRE")) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "doc-id-range tables (%.2f GB) cannot be built: %s (DS2I_RMW_REQUIRE is set)", want / 1e9, why);
+            return ds2i_set_error(DS2I_ENOMEM, msg);
+        }
+        std::fprintf(stderr, "ds2i_hip: index uploaded WITHOUT doc-id-range tables (%.2f GB wanted: %s); ranked_and / and / wand / "
+                             "maxscore / or take their slower table-free kernels\n", want / 1e9, why);
+        return DS2I_OK;
+    };
     x->list_rmw_off64.assign(V, 0);
     x->list_rmw_shift.assign(V, 0);
     uint64_t cursor = 0; // in units of 64 bytes
@@ -165,13 +183,23 @@ int build_block_max_weights(ds2i_hip_index* x) {
         cursor += ds2i_dev::RmwLevels((uint32_t)x->num_docs, sh).bytes() / 64; // level 1 + its two coarser levels
         if (ds2i_dev::RmwLevels::has_bitmap(x->list_n[t], (uint32_t)x->num_docs) && !std::getenv("DS2I_NO_BITMAPS"))
             cursor += ds2i_dev::RmwLevels::bitmap_bytes((uint32_t)x->num_docs) / 64; // dense list: + its exact bitmap
-        if (cursor >= (1ull << 32)) return DS2I_OK; // > 256 GB of tables: not on this device; run without them
+        if (cursor >= (1ull << 32)) return without_tables("more than 256 GB of tables", cursor * 64);
     }
-    size_t free_b = 0, total_b = 0;
-    HIP_OK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t bytes = cursor * 64 + 64;
-    if (bytes > free_b / 2) return DS2I_OK; // the tables are an accelerator, never a reason to fail an upload
-    HIP_OK(hipMalloc((void**)&x->d_rmw, bytes));
+    {
+        // several replicas may be uploaded to one device from parallel host threads (gpu_index_set): the free-memory test
+        // and the allocation it guards are one critical section, and an allocation that fails all the same is not an error
+        static std::mutex table_alloc_mu;
+        std::lock_guard<std::mutex> g(table_alloc_mu);
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        if (bytes > free_b / 2) return without_tables("less than twice their size is free on the device", bytes);
+        if (hipMalloc((void**)&x->d_rmw, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            x->d_rmw = nullptr;
+            return without_tables("hipMalloc failed", bytes);
+        }
+    }
     x->rmw_bytes = bytes;
     HIP_OK(hipMemsetAsync(x->d_rmw, 0, bytes, x->stream[0]));
     for (uint64_t t = 0; t < V; ++t) {
@@ -437,6 +465,24 @@ uint64_t ds2i_hip_index_size(const ds2i_hip_index* idx) { return idx ? idx->size
 uint64_t ds2i_hip_index_num_docs(const ds2i_hip_index* idx) { return idx ? idx->num_docs : 0; }
 uint64_t ds2i_hip_index_device_bytes(const ds2i_hip_index* idx) {
     return idx ? idx->arena_bytes + idx->extra_bytes + (idx->has_wand ? 4 * idx->num_docs : 0) : 0;
+}
+int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out) {
+    if (!idx || !out) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_get_info: null argument");
+    std::memset(out, 0, sizeof *out);
+    const bool freq_layout = idx->kind >= DS2I_OPT;
+    out->block_weight_bytes = idx->d_bmw ? 4 * idx->total_blocks : 0;
+    out->range_table_bytes = idx->d_rmw ? idx->rmw_bytes : 0;
+    out->skip_table_bytes = idx->d_skip ? 8 * idx->total_blocks : 0;
+    out->norm_len_bytes = idx->has_wand ? 4 * idx->num_docs : 0;
+    out->index_bytes = idx->arena_bytes + idx->extra_bytes - out->block_weight_bytes - out->range_table_bytes - out->skip_table_bytes;
+    (void)freq_layout;
+    out->total_blocks = idx->total_blocks;
+    for (uint32_t n : idx->list_n) out->total_postings += n;
+    out->has_block_weights = idx->d_bmw != nullptr;
+    out->has_range_tables = idx->d_rmw != nullptr;
+    out->has_bitmaps = idx->d_rmw != nullptr && idx->has_bitmaps;
+    out->range_table_entries_per_posting = idx->d_rmw ? idx->rmw_g : 0;
+    return DS2I_OK;
 }
 
 int ds2i_hip_list_size(const ds2i_hip_index* idx, uint32_t term, uint64_t* n) {

@@ -25,6 +25,7 @@ using ds2i_dev::Unit;
 
 extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
                                  const unsigned long long* seed_count, float* out_topk, uint32_t* out_len,
@@ -69,7 +70,7 @@ struct ds2i_hip_batch {
     DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long, d_clk;
     // union kernels (k_disjunctive) keep their decoded blocks in dynamic LDS sized per launch: a class's units are grouped
     // by the list count of their query and every group is launched with just that many list slots
-    struct SubLaunch { uint32_t begin, end, lists; };
+    struct SubLaunch { uint32_t begin, end, lists; bool stream = false; /* ranked_and: k_ranked_stream<lists> (ranked_stream.hip) */ };
     std::vector<SubLaunch> sub[NCLS];
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
@@ -425,6 +426,26 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
             b->sub[c].push_back({0u, b->ncls[c], cls_lists});
             continue;
         }
+        // ranked_and on block_optpfor with every upload-time table: the 2-, 3- and 4-term queries run the pipelined stream
+        // kernel compiled for exactly their list count (ranked_stream.hip), one launch group per count, back to back on the
+        // class stream; one-term queries and everything else keep the class kernel
+        static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
+        const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= 1 && !no_rs && !tables_off &&
+                           idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
+        if (rs_ok) {
+            auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
+            std::stable_sort(b->order[c].begin(), b->order[c].end(), [&](uint32_t x, uint32_t y) { return nt_of(x) > nt_of(y); });
+            for (uint32_t i = 0; i < b->ncls[c];) {
+                uint32_t j = i;
+                const uint32_t l = nt_of(b->order[c][i]);
+                while (j < b->ncls[c] && nt_of(b->order[c][j]) == l) ++j;
+                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 ? l : cls_lists};
+                sl.stream = l >= 2 && l <= 4;
+                b->sub[c].push_back(sl);
+                i = j;
+            }
+            continue;
+        }
         static const bool no_union_stream2 = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
         if (union_kernel && !ranked && !no_union_stream2) { // or / or_freq: the streaming kernel serves every list count (lists = ~0 says so)
             b->sub[c].push_back({0u, b->ncls[c], 0xFFFFFFFFu});
@@ -682,6 +703,10 @@ int launch_batch(ds2i_hip_batch* b) {
             a.order = order_base + sl.begin;
             a.nslice = sl.end - sl.begin;
             a.dyn_lists = sl.lists;
+            if (sl.stream && !a.block_profile && !a.unit_clock && a.skip && a.bmw && a.rmw) {
+                HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, s));
+                continue;
+            }
             HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
         }
         HIP_OK(hipEventRecord(b->ev_c1[c], s));

@@ -98,6 +98,7 @@ struct ds2i_hip_index {
     float* d_bmw = nullptr;         // per block / chunk: max doc_term_weight of its postings (ranked_and pruning), or null
     uint8_t* d_rmw = nullptr;       // doc-id-range max-weight tables (abi_structs.hpp, BatchArgs::rmw), or null
     uint64_t rmw_bytes = 0;
+    int rmw_g = 0;                  // entries per posting the tables were built with (DS2I_RMW_G)
     bool d_skip_or_pef() const { return d_skip != nullptr || kind >= DS2I_OPT; } // what the streaming kernels walk the driving list by
     bool has_bitmaps = false;       // dense lists carry an exact bitmap behind their range-table levels
     std::vector<uint32_t> list_rmw_off64, list_rmw_shift;

@@ -469,6 +469,81 @@ DS2I_DEV uint32_t optpfor_decode(const Window& w, const uint8_t* p, uint32_t* ex
     return total;
 }
 
+// ---- OptPFor full block that lies ENTIRELY in LDS (blk = its header dword, avail_dw = dwords staged from there on).
+// Same value layout and result as optpfor_decode; differs in what it never does: touch global memory. A decode whose
+// outputs may come from a global load (the unstaged fallbacks of optpfor_decode) makes the compiler drain vmcnt where
+// its paths join -- and with it every unrelated load the caller has in flight (next block's bytes, range-table gathers).
+// Serves b < 32 with <= 64 exceptions in <= 64 Simple16 words; returns false (nothing decoded) for anything else or
+// when the block is not covered, and the caller takes the general path.
+DS2I_DEV bool optpfor_decode_lds(const uint32_t* blk, uint32_t avail_dw, uint32_t* exc, uint32_t* out, uint32_t& v0, uint32_t& v1,
+                                 uint32_t& consumed) {
+    const uint32_t lane = lane_id();
+    const uint32_t hdr = uniform(blk[0]);
+    const uint32_t b = hdr >> 26, nexc = (hdr >> 16) & 0x3FFu, ew = hdr & 0xFFFFu;
+    const uint32_t total_dw = 1u + ew + 4u * b;
+    if (b >= 32u || nexc > 64u || ew > 64u || total_dw + 1u > avail_dw) return false;
+    consumed = 4u * total_dw;
+    const uint32_t* data = blk + 1 + ew;
+    const uint32_t mask = (1u << b) - 1u; // b == 0: mask 0, every value 0
+    const uint32_t bit0 = lane * b, bit1 = bit0 + 64u * b;
+    const uint32_t i0 = bit0 >> 5, i1 = bit1 >> 5;
+    v0 = __builtin_amdgcn_alignbit(data[i0 + 1], data[i0], bit0 & 31u) & mask;
+    v1 = __builtin_amdgcn_alignbit(data[i1 + 1], data[i1], bit1 & 31u) & mask;
+    if (!nexc) return true;
+    const uint16_t* tab = s16_tab(exc);
+    const uint32_t word = lane < ew ? blk[1 + lane] : 0u;
+    const uint32_t cnt = lane < ew ? (uint32_t)tab[448u + (word >> 28)] : 0u;
+    const uint32_t off = wave_incl_scan(cnt) - cnt; // index of my word's first field
+    uint32_t hi, lpos;
+    if (nexc <= 32u) { // <= 64 fields: one per lane
+        out[lane] = 0; // (LDS operations of one wave are performed in issue order: no fence between the clear and the marks)
+        if (lane < ew && off < 64u) out[off] = 1u; // words hold >= 1 field: starts are distinct
+        wave_sync();
+        const bool starts_here = out[lane] != 0u;
+        const uint64_t starts = ballot(starts_here);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+        const uint32_t widx = below - (starts_here ? 0u : 1u);
+        const uint32_t wword = (uint32_t)__shfl((int)word, (int)(widx & 63u));
+        const uint32_t woff = (uint32_t)__shfl((int)off, (int)(widx & 63u));
+        const uint32_t k = lane - woff;
+        const uint32_t fe = tab[(lane < 2 * nexc && k < 28u) ? (wword >> 28) * 28u + k : 0u];
+        const uint32_t val = __builtin_amdgcn_ubfe(wword, fe & 0xFFu, fe >> 8);
+        hi = (uint32_t)__shfl((int)val, (int)((lane + nexc) & 63u));
+        lpos = wave_incl_scan(lane < nexc ? val + 1u : 0u) - 1u; // positions are delta coded
+    } else { // 33..64 exceptions: two fields per lane (g and g + 64)
+        out[lane] = 0;
+        out[lane + 64] = 0;
+        if (lane < ew && off < 128u) out[off] = 1u;
+        wave_sync();
+        const bool st0 = out[lane] != 0u, st1 = out[lane + 64] != 0u;
+        const uint64_t m0 = ballot(st0), m1 = ballot(st1);
+        const uint32_t below0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        const uint32_t below1 = (uint32_t)__builtin_popcountll(m0) +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        const uint32_t widx0 = below0 - (st0 ? 0u : 1u), widx1 = below1 - (st1 ? 0u : 1u);
+        const uint32_t wword0 = (uint32_t)__shfl((int)word, (int)(widx0 & 63u)), woff0 = (uint32_t)__shfl((int)off, (int)(widx0 & 63u));
+        const uint32_t wword1 = (uint32_t)__shfl((int)word, (int)(widx1 & 63u)), woff1 = (uint32_t)__shfl((int)off, (int)(widx1 & 63u));
+        const uint32_t k0 = lane - woff0, k1 = lane + 64u - woff1;
+        const uint32_t fe0 = tab[k0 < 28u ? (wword0 >> 28) * 28u + k0 : 0u];
+        const uint32_t fe1 = tab[(lane + 64u < 2 * nexc && k1 < 28u) ? (wword1 >> 28) * 28u + k1 : 0u];
+        const uint32_t val0 = __builtin_amdgcn_ubfe(wword0, fe0 & 0xFFu, fe0 >> 8);
+        const uint32_t val1 = __builtin_amdgcn_ubfe(wword1, fe1 & 0xFFu, fe1 >> 8);
+        const uint32_t hidx = lane + nexc; // field holding the high part of exception `lane`
+        const uint32_t h0 = (uint32_t)__shfl((int)val0, (int)(hidx & 63u)), h1 = (uint32_t)__shfl((int)val1, (int)(hidx & 63u));
+        hi = hidx < 64u ? h0 : h1;
+        lpos = wave_incl_scan(lane < nexc ? val0 + 1u : 0u) - 1u;
+    }
+    wave_sync();
+    out[lane] = 0;
+    out[lane + 64] = 0;
+    if (lane < nexc && lpos < 128u) out[lpos] = hi + 1u;
+    wave_sync();
+    v0 |= out[lane] << b;
+    v1 |= out[lane + 64] << b;
+    wave_sync();
+    return true;
+}
+
 // ---- VarInt-G8IU full block. Values are scattered to out[] (LDS) then re-read.
 DS2I_DEV uint32_t varint_g8iu_decode(const Window& w, const uint8_t* p, uint32_t* out, uint32_t& v0, uint32_t& v1) {
     const uint32_t lane = lane_id();

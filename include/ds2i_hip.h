@@ -105,6 +105,24 @@ void ds2i_hip_index_close(ds2i_hip_index* idx);
 uint64_t ds2i_hip_index_size(const ds2i_hip_index* idx);
 uint64_t ds2i_hip_index_num_docs(const ds2i_hip_index* idx);
 uint64_t ds2i_hip_index_device_bytes(const ds2i_hip_index* idx);
+/* What the upload put into HBM beside the index image. The pruning tables are accelerators: an upload that cannot
+ * afford them (or was told not to build them) still succeeds and the query kernels take their slower table-free paths,
+ * so a caller that cares checks has_range_tables here (the library also says so once on stderr). With
+ * DS2I_RMW_REQUIRE=1 in the environment such an upload fails with DS2I_ENOMEM instead. */
+typedef struct ds2i_hip_index_info {
+    uint64_t index_bytes;        /* the posting lists (block indexes) / chunk directory + bit vectors (freq_index layouts) */
+    uint64_t skip_table_bytes;   /* interleaved {block_max, end offset} rows (block indexes) */
+    uint64_t block_weight_bytes; /* bmw[]: one float per block / chunk */
+    uint64_t range_table_bytes;  /* doc-id-range tables, their two coarser levels, membership bit tables, dense bitmaps */
+    uint64_t norm_len_bytes;
+    uint64_t total_blocks;
+    uint64_t total_postings;
+    int has_block_weights;
+    int has_range_tables;
+    int has_bitmaps;
+    int range_table_entries_per_posting; /* DS2I_RMW_G in effect */
+} ds2i_hip_index_info;
+int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out);
 /* document_enumerator::size() of index[term] (block_posting_list.hpp:178-181) */
 int ds2i_hip_list_size(const ds2i_hip_index* idx, uint32_t term, uint64_t* n);
 /* index[term] followed by a full enumeration docid()/freq()/next(): decodes every block of the
