@@ -481,7 +481,7 @@ DS2I_DEV bool optpfor_decode_lds(const uint32_t* blk, uint32_t avail_dw, uint32_
     const uint32_t hdr = uniform(blk[0]);
     const uint32_t b = hdr >> 26, nexc = (hdr >> 16) & 0x3FFu, ew = hdr & 0xFFFFu;
     const uint32_t total_dw = 1u + ew + 4u * b;
-    if (b >= 32u || nexc > 64u || ew > 64u || total_dw + 1u > avail_dw) return false;
+    if (__builtin_expect(b >= 32u || nexc > 64u || ew > 64u || total_dw + 1u > avail_dw, 0)) return false;
     consumed = 4u * total_dw;
     const uint32_t* data = blk + 1 + ew;
     const uint32_t mask = (1u << b) - 1u; // b == 0: mask 0, every value 0
@@ -495,7 +495,7 @@ DS2I_DEV bool optpfor_decode_lds(const uint32_t* blk, uint32_t avail_dw, uint32_
     const uint32_t cnt = lane < ew ? (uint32_t)tab[448u + (word >> 28)] : 0u;
     const uint32_t off = wave_incl_scan(cnt) - cnt; // index of my word's first field
     uint32_t hi, lpos;
-    if (nexc <= 32u) { // <= 64 fields: one per lane
+    if (__builtin_expect(nexc <= 32u, 1)) { // <= 64 fields: one per lane
         out[lane] = 0; // (LDS operations of one wave are performed in issue order: no fence between the clear and the marks)
         if (lane < ew && off < 64u) out[off] = 1u; // words hold >= 1 field: starts are distinct
         wave_sync();

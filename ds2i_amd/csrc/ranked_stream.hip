@@ -49,7 +49,8 @@ static_assert(DS2I_RS_FLOOR_EVERY > 0 && (DS2I_RS_FLOOR_EVERY & (DS2I_RS_FLOOR_E
 
 template <int NT>
 struct LdsRS {
-    uint32_t stage[2][STAGE_DW]; // list 0: bytes of the block in stage B/C and of the block in stage A
+    uint32_t stage[3][STAGE_DW]; // list 0: bytes of the blocks in stage B/C, in stage A and on their way in (LDS-DMA)
+    uint32_t gb[2][64];          // list 1's range-table byte of every posting of the block in stage B (LDS-DMA, one dword per lane)
     uint32_t stb[STAGE_DW];      // bytes of the other lists' block decoded last
     uint32_t dj[NT - 1][128];    // lists 1 .. NT-1: doc-ids of their current block
     uint32_t fj[128];            // freqs of the block of the list that decoded its freqs last (f_owner)
@@ -152,6 +153,34 @@ DS2I_DEV KArgs rs_args() {
     return p;
 }
 
+// ---- loads the compiler must not count. hipcc drains vmcnt to 0 wherever control flow joins with a load pending on
+// some path, which would put every round trip back on the critical path; these are issued and waited for by hand.
+// (i) block bytes: LDS-DMA, global -> LDS with no register in between (nothing the compiler could copy or spill early);
+DS2I_DEV uint32_t rs_lds_offset(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+// 512 bytes at g (4-byte aligned) -> LDS byte offset `lds`; voff = lane * 4. M0 is the DMA's LDS base: compiler-reserved,
+// so it is saved, set and restored inside each statement.
+DS2I_DEV void rs_prefetch512(const uint8_t* g, uint32_t lds, uint32_t voff) {
+    uint32_t keep;
+    // (the instruction offset moves the global AND the LDS address: measured, profiles/probes/ldsdma_probe.hip)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(lds) : "memory");
+}
+// (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
+// lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
+// destination is written when the statement ends, and under register pressure it did copy the still-pending register
+// (tests/asm_audit.py found it before the GPU did).
+DS2I_DEV void rs_gather_u8(const uint8_t* tab, uint32_t off, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(tab), "s"(lds) : "memory");
+}
+// one lane of a VGPR takes a wave-uniform value (v_writelane_b32; there is no builtin for it in this toolchain)
+template <int LANE> DS2I_DEV void rs_writelane(uint32_t& dst, uint32_t v) {
+    const uint32_t sv = uniform(v);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "n"(LANE));
+}
+template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // optpfor / interpolative block -> gaps or freqs-1 in (v0, v1), value i in lane i & 63, slot i >> 6. The common case
 // (full block inside the staged 512 bytes) never touches global memory; anything else takes the general decoder and is
 // made opaque, so that no output of this function is ever "pending on vmcnt" for the compiler: the caller's prefetches
@@ -159,7 +188,7 @@ DS2I_DEV KArgs rs_args() {
 DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out, uint32_t* exc, uint32_t& v0, uint32_t& v1) {
     uint32_t consumed = 0;
     const uint32_t woff = (uint32_t)((uintptr_t)p & 3u);
-    if (n == 128u && woff == 0u && optpfor_decode_lds(st, STAGE_DW, exc, out, v0, v1, consumed)) return consumed;
+    if (__builtin_expect(n == 128u && woff == 0u && optpfor_decode_lds(st, STAGE_DW, exc, out, v0, v1, consumed), 1)) return consumed;
     Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, st};
     uint32_t a0, a1;
     consumed = uniform(decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, w, p, sum, n, out, exc, a0, a1));
@@ -192,11 +221,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // ---- list 0: the stream
         const uint32_t n0 = qt[0].n, nb0 = (n0 + 127u) >> 7;
         const uint32_t vl0 = 1u + (n0 >= (1u << 7)) + (n0 >= (1u << 14)) + (n0 >= (1u << 21)) + (n0 >= (1u << 28));
-        const uint8_t* const arena = a->arena;
-        const uint2* const skip = (const uint2*)a->skip;
-        const uint8_t* const data0 = arena + qt[0].list_off + vl0 + 4ull * nb0 + 4ull * (nb0 - 1);
-        const uint2* const tab0 = skip + qt[0].blk_base;
-        const float* const w0tab = a->bmw + qt[0].blk_base;
+        const uint8_t* const data0 = a->arena + qt[0].list_off + vl0 + 4ull * nb0 + 4ull * (nb0 - 1);
         const float qw0 = qt[0].q_weight;
         // ---- lists 1 .. NT-1: range table (hot), the rest of the QTerm is read when a candidate gets that far
         const uint8_t* rt[NT];
@@ -209,13 +234,16 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             rsc[j] = qt[j].rmw_scale;
         };
         rs_for<1, NT>(bind_one);
-        uint32_t cur[NT], bmaxj[NT], szj[NT]; // block of list j whose doc-ids are in L.dj[j-1] (cur = ~0: none)
-        unsigned long long foj[NT];           // arena offset of that block's freqs part
-        auto clr_one = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; cur[j] = 0xFFFFFFFFu; bmaxj[j] = 0; szj[j] = 0; foj[j] = 0; };
-        rs_for<1, NT>(clr_one);
-        uint32_t f_owner = 0;    // list whose current block's freqs are in L.fj (0 = nobody)
-        uint32_t stb_owner = 0;  // list whose current block's bytes are in L.stb
-        const uint8_t* stb_base = nullptr;
+        // block of list j whose doc-ids are in L.dj[j-1] (cur = ~0: none), its block_max, size and the arena offset of its
+        // freqs part; f_owner = list whose current block's freqs are in L.fj (0 = nobody); stb_owner = list whose current
+        // block's bytes are in L.stb (from stb_base on). Only stage C touches them: they live in the lanes of one VGPR
+        // (v_readlane / v_writelane at a constant lane) instead of ~20 SGPRs the hot loop would have to carry.
+        uint32_t cold = 0xFFFFFFFFu;
+        enum { C_CUR = 0, C_BMAX = 1, C_SZ = 2, C_FOLO = 3, C_FOHI = 4, C_PER = 5, C_FOWNER = 60, C_SOWNER = 61, C_SBLO = 62, C_SBHI = 63 };
+#define cget(l) ((uint32_t)__builtin_amdgcn_readlane((int)cold, (l)))
+#define cset(l, v) rs_writelane<(l)>(cold, (v))
+        cset(C_FOWNER, 0u);
+        cset(C_SOWNER, 0u);
         // ---- pruning state: the parts of a split query share a score histogram (device_score.hpp)
         unsigned int* const q_hist = a->q_hist;
         const bool shared_floor = !whole && q_hist;
@@ -247,7 +275,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             const uint32_t idx = first + lane;
             s_e = make_uint2(0xFFFFFFFFu, 0u);
             float s_w = 0.f;
-            if (idx < u.blk_end) { s_e = tab0[idx]; s_w = w0tab[idx]; }
+            {   // (once per 63 blocks: the table pointers are re-derived here rather than carried through the loop)
+                const uint32_t bb = qt[0].blk_base;
+                const uint2* const tab0 = (const uint2*)rs_args()->skip + bb;
+                const float* const w0tab = rs_args()->bmw + bb;
+                if (idx < u.blk_end) { s_e = tab0[idx]; s_w = w0tab[idx]; }
+            }
             const uint32_t prev_max = (uint32_t)__shfl_up((int)s_e.x, 1);
             const uint32_t base = (lane == 0) ? 0u : prev_max + 1u, top = s_e.x;
             const bool row = idx < u.blk_end && (lane > 0 || idx == 0) && top != 0xFFFFFFFFu && base <= top;
@@ -281,7 +314,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             for (;;) {
                 if (from >= u.blk_end) return false;
                 const uint64_t hit = s_live(from);
-                if (hit) {
+                if (__builtin_expect(hit != 0, 1)) {
                     const uint32_t f = (uint32_t)__builtin_ctzll(hit), fp = f ? f - 1 : 0;
                     o.blk = s_first + f;
                     o.bmax = bcast(s_e.x, f);
@@ -291,7 +324,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     return true;
                 }
                 if (s_first + 64 >= u.blk_end) return false;
-                s_fill(s_first + 63);
+                s_fill(s_first + 63); // (once per 63 blocks)
                 from = from > s_first + 1 ? from : s_first + 1;
             }
         };
@@ -299,39 +332,32 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         s_bm_examined += 1;
         s_bytes += 4;
 
-        Blk A{}, B{};            // A: decoded this iteration (gathers issued); B: its gathers are consumed this iteration
+        Blk A{}, B{};            // A: decoded this iteration; B: its gathers are consumed this iteration, then stage C if needed
         bool haveA, haveB = false;
-        uint32_t pf0 = 0, pf1 = 0; // bytes of the block entering stage A (requested an iteration ago)
         uint32_t dA0 = 0xFFFFFFFFu, dA1 = 0xFFFFFFFFu, dB0 = 0xFFFFFFFFu, dB1 = 0xFFFFFFFFu; // doc-ids (value lane, lane + 64)
         uint32_t gB0[NT] = {}, gB1[NT] = {};                                                    // range-table bytes of lists 1..
         uint32_t consA = 0, consB = 0, szA = 0, szB = 0; // bytes of the docs part, postings of the block
-        uint32_t par = 0;                                // staging buffer of block A (B's is par ^ 1)
+        // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
+        const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]);
+        uint32_t bufB = 0, bufA = 1, bufN = 2;
+        const uint32_t voff = lane * 4u;
         bool finished = false;
         haveA = select(u.blk_begin, A);
-        if (haveA) {
-            const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + A.ep) & ~(uintptr_t)3);
-            pf0 = g[lane];
-            pf1 = g[lane + 64];
-        }
+        if (haveA) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + A.ep) & ~(uintptr_t)3), st_base + bufA * (STAGE_DW * 4u), voff);
         while (haveA || haveB) {
             Blk N{};
             bool haveN = false;
             if (haveA) {
-                // ---------------- stage A: block A's bytes -> LDS, the bytes of the block after it requested, docs decoded, gathers issued
+                // ---------------- stage A: the bytes of the block after A requested, A's docs decoded
                 ++s_rounds;
                 if (shared_floor && (floor_tick++ & (DS2I_RS_FLOOR_EVERY - 1)) == 0) adopt_floor();
-                L.stage[par][lane] = pf0;
-                L.stage[par][lane + 64] = pf1;
-                wave_sync();
                 haveN = select(A.blk + 1, N); // as things stand now: the heap may still rule it out before its turn
-                if (haveN) {
-                    const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3);
-                    pf0 = g[lane];
-                    pf1 = g[lane + 64];
-                }
+                // A's bytes were requested an iteration ago; the only loads issued after them are B's two gathers
+                if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                if (haveN) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), voff);
                 szA = ((A.blk + 1) * 128u <= n0) ? 128u : (n0 & 127u);
                 uint32_t v0, v1;
-                consA = rs_decode(L.stage[par], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
+                consA = rs_decode(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
                 const uint32_t g0 = (lane < szA) ? v0 + 1u : 0u, g1 = (lane + 64 < szA) ? v1 + 1u : 0u;
                 const uint32_t i0 = wave_incl_scan(g0);
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
@@ -342,15 +368,19 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 s_bytes += 8 + consA; // block_max + endpoint + docs part
             }
             if (haveB) {
-                // ---------------- stage B: the gathers of block B (issued an iteration ago)
-                bool ok0 = dB0 != 0xFFFFFFFFu && gB0[1] != 0u, ok1 = dB1 != 0xFFFFFFFFu && gB1[1] != 0u;
+                // ---------------- stage B: the gathers of block B, issued before stage A ran; the only loads issued after them are
+                // the two of the prefetch above
+                if (haveA && haveN) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                gB0[1] = L.gb[0][lane];
+                gB1[1] = L.gb[1][lane];
+                bool ok0 = (dB0 != 0xFFFFFFFFu) & (gB0[1] != 0u), ok1 = (dB1 != 0xFFFFFFFFu) & (gB1[1] != 0u);
                 if constexpr (NT > 2) {
                     // lists 2.. : their bytes only for the candidates list 1's byte lets through (list maxima for the others)
                     float rest = 0.f;
                     auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest = rest + rsc[j] * 255.0f; };
                     rs_for_down<NT, 2>(add_max);
-                    ok0 = ok0 && enters((B.wq + (rest + rsc[1] * (float)gB0[1])) * BOUND_SLACK);
-                    ok1 = ok1 && enters((B.wq + (rest + rsc[1] * (float)gB1[1])) * BOUND_SLACK);
+                    ok0 = ok0 & enters((B.wq + (rest + rsc[1] * (float)gB0[1])) * BOUND_SLACK);
+                    ok1 = ok1 & enters((B.wq + (rest + rsc[1] * (float)gB1[1])) * BOUND_SLACK);
                     if (ballot(ok0) | ballot(ok1)) {
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
@@ -360,8 +390,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         rs_for<2, NT>(load_one);
                         auto test_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            ok0 = ok0 && gB0[j] != 0u;
-                            ok1 = ok1 && gB1[j] != 0u;
+                            ok0 = ok0 & (gB0[j] != 0u);
+                            ok1 = ok1 & (gB1[j] != 0u);
                         };
                         rs_for<2, NT>(test_one);
                     }
@@ -378,18 +408,19 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     return r;
                 };
                 float r0 = rest_of(gB0, 0), r1 = rest_of(gB1, 0);
-                ok0 = ok0 && enters((B.wq + r0) * BOUND_SLACK);
-                ok1 = ok1 && enters((B.wq + r1) * BOUND_SLACK);
-                if (ballot(ok0) | ballot(ok1)) {
+                ok0 = ok0 & enters((B.wq + r0) * BOUND_SLACK);
+                ok1 = ok1 & enters((B.wq + r1) * BOUND_SLACK);
+                if (__builtin_expect((ballot(ok0) | ballot(ok1)) != 0, 0)) {
                     // ---------------- stage C: somebody of block B may enter the heap
                     // freqs of the block (its bytes are still staged), freq-only bound (doc_term_weight falls with norm_len, so the
                     // collection's shortest document bounds the term score from the freq alone), norm_len, exact list-0 score
                     const float min_nl = rs_args()->min_norm_len;
                     const float* const norm_lens = rs_args()->norm_lens;
+                    const uint8_t* const arena = rs_args()->arena;
                     uint32_t fv0, fv1, consF;
                     {
                         const uint8_t* p = data0 + B.ep; // (full blocks are dword aligned and a multiple of 4 bytes long)
-                        uint32_t* const stB = L.stage[par ^ 1u];
+                        uint32_t* const stB = L.stage[bufB];
                         const uint32_t skip_dw = consB >> 2;
                         if (szB == 128u && ((uintptr_t)p & 3u) == 0u && (consB & 3u) == 0u && skip_dw < STAGE_DW &&
                             optpfor_decode_lds(stB + skip_dw, STAGE_DW - skip_dw, L.exc, L.out, fv0, fv1, consF)) {
@@ -405,8 +436,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     ++s_freqs_blocks;
                     s_bytes += consF;
                     const uint32_t f0 = fv0 + 1u, f1 = fv1 + 1u;
-                    ok0 = ok0 && enters((qw0 * doc_term_weight(f0, min_nl) + r0) * BOUND_SLACK);
-                    ok1 = ok1 && enters((qw0 * doc_term_weight(f1, min_nl) + r1) * BOUND_SLACK);
+                    ok0 = ok0 & enters((qw0 * doc_term_weight(f0, min_nl) + r0) * BOUND_SLACK);
+                    ok1 = ok1 & enters((qw0 * doc_term_weight(f1, min_nl) + r1) * BOUND_SLACK);
                     const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
                     float pa0 = qw0 * doc_term_weight(f0, nl0), pa1 = qw0 * doc_term_weight(f1, nl1);
                     {
@@ -414,44 +445,46 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         s_scored += nv;
                         s_bytes += 4ull * nv;
                     }
-                    ok0 = ok0 && enters((pa0 + r0) * BOUND_SLACK);
-                    ok1 = ok1 && enters((pa1 + r1) * BOUND_SLACK);
+                    ok0 = ok0 & enters((pa0 + r0) * BOUND_SLACK);
+                    ok1 = ok1 & enters((pa1 + r1) * BOUND_SLACK);
                     // lists 1 .. NT-1 in order: a candidate moves on only while partial score + what the later lists can add to IT
                     // can still enter the heap
                     auto probe = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
+                        constexpr int CB = (j - 1) * C_PER; // this list's lanes of `cold`
                         uint64_t todo0 = ballot(ok0), todo1 = ballot(ok1);
                         if (!(todo0 | todo1)) return;
                         const QTerm* const tj = qt + j;
                         const uint32_t nj = tj->n, nbj = (nj + 127u) >> 7;
                         const uint32_t vlj = 1u + (nj >= (1u << 7)) + (nj >= (1u << 14)) + (nj >= (1u << 21)) + (nj >= (1u << 28));
                         const uint8_t* const dataj = arena + tj->list_off + vlj + 4ull * nbj + 4ull * (nbj - 1);
-                        const uint2* const tabj = skip + tj->blk_base;
+                        const uint2* const tabj = (const uint2*)rs_args()->skip + tj->blk_base;
                         const float* const wtabj = rs_args()->bmw + tj->blk_base;
                         const float qwj = tj->q_weight;
                         const float rj0 = rest_of(gB0, j), rj1 = rest_of(gB1, j); // the lists after j
                         const float bj0 = rsc[j] * (float)gB0[j], bj1 = rsc[j] * (float)gB1[j];
                         uint32_t* const dj = L.dj[j - 1];
                         bool mem0 = false, mem1 = false;
+                        uint32_t curj = cget(CB + C_CUR), bmj = cget(CB + C_BMAX);
                         while (todo0 | todo1) {
                             const uint32_t amin = todo0 ? bcast(dB0, (uint32_t)__builtin_ctzll(todo0)) : bcast(dB1, (uint32_t)__builtin_ctzll(todo1));
-                            if (cur[j] == 0xFFFFFFFFu || amin > bmaxj[j]) {
+                            if (curj == 0xFFFFFFFFu || amin > bmj) {
                                 Found fb;
-                                const bool found = find_block_rows(tabj, wtabj, nbj, cur[j] + 1u, amin, fb);
+                                const bool found = find_block_rows(tabj, wtabj, nbj, curj + 1u, amin, fb);
                                 if (!found) { // list j has nothing >= amin: no later document of list 0 can be a result either
                                     s_bm_examined += 1;
                                     s_bytes += 4;
                                     finished = true;
                                     break;
                                 }
-                                s_bm_examined += (cur[j] == 0xFFFFFFFFu) ? 1u : fb.blk - cur[j];
-                                s_bytes += 4ull * ((cur[j] == 0xFFFFFFFFu) ? 1u : fb.blk - cur[j]);
+                                s_bm_examined += (curj == 0xFFFFFFFFu) ? 1u : fb.blk - curj;
+                                s_bytes += 4ull * ((curj == 0xFFFFFFFFu) ? 1u : fb.blk - curj);
                                 // before the block is decoded: partial + min(block weight, own byte) + later lists, per candidate inside it
                                 const float cbw = qwj * fb.w;
                                 const bool in0 = ((todo0 >> lane) & 1) && dB0 <= fb.bmax, in1 = ((todo1 >> lane) & 1) && dB1 <= fb.bmax;
                                 const float t0 = bj0 < cbw ? bj0 : cbw, t1 = bj1 < cbw ? bj1 : cbw;
-                                const bool can0 = in0 && enters(((pa0 + t0) + rj0) * BOUND_SLACK);
-                                const bool can1 = in1 && enters(((pa1 + t1) + rj1) * BOUND_SLACK);
+                                const bool can0 = in0 & enters(((pa0 + t0) + rj0) * BOUND_SLACK);
+                                const bool can1 = in1 & enters(((pa1 + t1) + rj1) * BOUND_SLACK);
                                 if (!(ballot(can0) | ballot(can1))) { // nobody inside the block can enter: it is not decoded
                                     todo0 &= ~ballot(in0);
                                     todo1 &= ~ballot(in1);
@@ -460,27 +493,33 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 const uint8_t* pb = dataj + fb.ep;
                                 Window wb{nullptr, 0, L.stb};
                                 wb.load(pb, STAGE_DW * 4u - 4u);
-                                stb_owner = j;
-                                stb_base = wb.gbase;
                                 const uint32_t szb = ((fb.blk + 1) * 128u <= nj) ? 128u : (nj & 127u);
                                 uint32_t v0, v1;
-                                const uint32_t consD = decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1);
+                                const uint32_t consD = uniform(decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
                                 const uint32_t g0 = (lane < szb) ? v0 + 1u : 0u, g1 = (lane + 64 < szb) ? v1 + 1u : 0u;
                                 const uint32_t i0 = wave_incl_scan(g0);
                                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
                                 dj[lane] = (lane < szb) ? fb.base + i0 - 1u : 0xFFFFFFFFu;
                                 dj[lane + 64] = (lane + 64 < szb) ? fb.base + i1 - 1u : 0xFFFFFFFFu;
                                 wave_sync();
-                                cur[j] = fb.blk;
-                                bmaxj[j] = fb.bmax;
-                                szj[j] = szb;
-                                foj[j] = (unsigned long long)(pb + consD - arena);
-                                if (f_owner == (uint32_t)j) f_owner = 0;
+                                curj = fb.blk;
+                                bmj = fb.bmax;
+                                const unsigned long long fo = (unsigned long long)(pb + consD - arena);
+                                const unsigned long long sb = (unsigned long long)(uintptr_t)wb.gbase;
+                                cset(CB + C_CUR, curj);
+                                cset(CB + C_BMAX, bmj);
+                                cset(CB + C_SZ, szb);
+                                cset(CB + C_FOLO, (uint32_t)fo);
+                                cset(CB + C_FOHI, (uint32_t)(fo >> 32));
+                                cset(C_SOWNER, (uint32_t)j);
+                                cset(C_SBLO, (uint32_t)sb);
+                                cset(C_SBHI, (uint32_t)(sb >> 32));
+                                if (cget(C_FOWNER) == (uint32_t)j) cset(C_FOWNER, 0u);
                                 ++s_docs_blocks;
                                 s_bytes += 4 + consD;
                             }
                             // candidates inside the block: members or not, settled now
-                            const bool in0 = ((todo0 >> lane) & 1) && dB0 <= bmaxj[j], in1 = ((todo1 >> lane) & 1) && dB1 <= bmaxj[j];
+                            const bool in0 = ((todo0 >> lane) & 1) && dB0 <= bmj, in1 = ((todo1 >> lane) & 1) && dB1 <= bmj;
                             const uint64_t ib0 = ballot(in0), ib1 = ballot(in1);
                             uint32_t q0 = 0, q1 = 0;
                             bool m0, m1;
@@ -510,19 +549,20 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             todo0 &= ~ib0;
                             todo1 &= ~ib1;
                             if (ballot(m0) | ballot(m1)) { // members take list j's term score at once
-                                if (f_owner != (uint32_t)j) {
-                                    const uint8_t* pf = arena + foj[j];
-                                    Window wf{stb_base, STAGE_DW * 4u, L.stb};
-                                    if (stb_owner != (uint32_t)j || !wf.covers(pf, 64)) {
+                                if (cget(C_FOWNER) != (uint32_t)j) {
+                                    const uint8_t* pf = arena + (((unsigned long long)cget(CB + C_FOHI) << 32) | cget(CB + C_FOLO));
+                                    const uint8_t* sbase = (const uint8_t*)(uintptr_t)(((unsigned long long)cget(C_SBHI) << 32) | cget(C_SBLO));
+                                    Window wf{sbase, STAGE_DW * 4u, L.stb};
+                                    if (cget(C_SOWNER) != (uint32_t)j || !wf.covers(pf, 64)) {
                                         wf.load(pf, 256u);
-                                        stb_owner = 0; // (the window no longer starts at the block)
+                                        cset(C_SOWNER, 0u); // (the window no longer starts at the block)
                                     }
                                     uint32_t v0, v1;
-                                    const uint32_t consF2 = decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wf, pf, 0xFFFFFFFFu, szj[j], L.fj, L.exc, v0, v1);
+                                    const uint32_t consF2 = decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wf, pf, 0xFFFFFFFFu, cget(CB + C_SZ), L.fj, L.exc, v0, v1);
                                     L.fj[lane] = v0 + 1u;
                                     L.fj[lane + 64] = v1 + 1u;
                                     wave_sync();
-                                    f_owner = j;
+                                    cset(C_FOWNER, (uint32_t)j);
                                     ++s_freqs_blocks;
                                     s_bytes += consF2;
                                 }
@@ -532,14 +572,14 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         }
                         // members whose score can still enter go on to the next list (a candidate the loop left unsettled -- list j
                         // ended below it -- is not a member)
-                        ok0 = ok0 && mem0 && enters((pa0 + rj0) * BOUND_SLACK);
-                        ok1 = ok1 && mem1 && enters((pa1 + rj1) * BOUND_SLACK);
+                        ok0 = ok0 & mem0 & enters((pa0 + rj0) * BOUND_SLACK);
+                        ok1 = ok1 & mem1 & enters((pa1 + rj1) * BOUND_SLACK);
                     };
                     rs_for<1, NT>(probe);
                     // pa0 / pa1 are complete scores of documents of the intersection now
                     for (int half = 0; half < 2; ++half) {
                         const float sc = half ? pa1 : pa0;
-                        uint64_t todo = ballot((half ? ok1 : ok0) && enters(sc));
+                        uint64_t todo = ballot((half ? ok1 : ok0) & enters(sc));
                         while (todo) {
                             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                             todo &= todo - 1;
@@ -552,8 +592,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     }
                 }
             }
-            if (finished) break;
-            // ---------------- rotate: A becomes B, the block whose bytes were requested becomes A
+            if (__builtin_expect(finished, 0)) break;
+            // ---------------- rotate: A becomes B (its gathers are issued now and consumed an iteration later, behind the next
+            // block's decode), the block whose bytes were requested becomes A
             B = A;
             haveB = haveA;
             dB0 = dA0;
@@ -561,16 +602,21 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             consB = consA;
             szB = szA;
             if (haveB) {
-                // one byte per candidate from list 1's table, consumed an iteration later, behind the next block's decode (the other
-                // lists' bytes are fetched in stage B for the candidates inside list 1's ranges only: a gather is one cache-line
-                // request per lane, and most candidates die at list 1)
-                gB0[1] = (uint32_t)rt[1][(dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]];
-                gB1[1] = (uint32_t)rt[1][(dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]];
+                // one byte per candidate from list 1's table (the other lists' bytes are fetched in stage B for the candidates inside
+                // list 1's ranges only: a gather is one cache-line request per lane, and most candidates die at list 1)
+                rs_gather_u8(rt[1], (dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1], gb_base);
+                rs_gather_u8(rt[1], (dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1], gb_base + 256u);
             }
             A = N;
             haveA = haveN;
-            par ^= 1u;
+            const uint32_t t = bufB;
+            bufB = bufA;
+            bufA = bufN;
+            bufN = t;
         }
+        rs_wait_vm<0>(); // (a unit left early -- list exhausted -- may still have a prefetch or gathers in flight)
+#undef cget
+#undef cset
         KArgs r = rs_args();
         if (whole) {
             if (lane == 0) { r->out_count[q] = tk.n; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }

@@ -81,6 +81,39 @@ def test_device_code_has_no_function_calls(built_lib, tmp_path):
         assert k in seen
 
 
+def test_hand_issued_loads_have_no_register_destination(tmp_path):
+    """ranked_stream.hip issues its prefetches and range-table gathers from inline asm and waits for them with counted
+    s_waitcnt statements, because hipcc drains vmcnt wherever control flow joins. hipcc does not know such a load is
+    pending: a VGPR destination counts as written when the statement ends, and under register pressure the compiler did
+    copy the still-pending register (a v_mov of garbage; tests/asm_audit.py walks the control-flow graph for exactly that).
+    The kernels therefore use LDS-DMA only (global_load_lds_*: no register destination). This holds them to it: every
+    global load inside an asm statement of the compiled kernels is an LDS-DMA, and the audit finds nothing."""
+    import subprocess
+    import asm_audit
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "rs.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-o", out, os.path.join(root, "ds2i_amd", "csrc", "ranked_stream.hip")], stderr=subprocess.DEVNULL)
+    ks = asm_audit.kernels(open(out).read())
+    assert len(ks) >= 6  # NT = 2, 3, 4 with and without counters
+    for name, lines in ks.items():
+        in_asm, dma = False, 0
+        for l in lines:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and re.match(r"(global|buffer|flat)_load", t):
+                assert "_lds_" in t.split()[0], (name, t)
+                dma += 1
+        assert dma >= 4, name  # two prefetch sites (two loads each) + the gathers
+        assert asm_audit.audit(lines) == [], name
+
+
 def test_documented_knobs_exist_in_the_source():
     """DESIGN.md section 7c lists the environment knobs of the library: every name in that table must be read somewhere in
     the product sources (a renamed or removed knob would otherwise stay documented, and an A/B reported against it would
