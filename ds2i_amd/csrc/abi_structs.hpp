@@ -101,6 +101,12 @@ struct BatchArgs {
     // in <= 16 bytes of the level whose entries are wide enough, and bounds every candidate of that block at once.
     const uint8_t* rmw;
     uint32_t rmw_bitmaps;        // the dense lists' exact bitmaps exist behind their tables (RmwLevels::has_bitmap)
+    // Membership hints (or null): a second byte per level-1 range-table entry, at the same offsets in a parallel buffer.
+    // 0 = the range holds no posting of the list, 255 = it holds two or more, otherwise 1 + (offset of its ONE posting
+    // inside the range) mod 254. A candidate whose range holds a single posting at another offset is provably not in the
+    // list: for a list with 32 doc-ids per entry that settles 30 of 31 candidates the weight byte lets through, without the
+    // block search + block decode a lookup costs (k_ranked_stream; block_optpfor indexes).
+    const uint8_t* rmh;
     // k_union_topk (wand / maxscore / ranked_or as streams): units belong to VIRTUAL queries = (query, driving list); qterms /
     // q_off then describe the virtual queries, and vq_info holds 3 words per virtual query: the real query, the number
     // of exclusion lists (slots 1 .. nexcl: lists of higher max score -- a document found there is theirs), and the float
@@ -118,6 +124,8 @@ struct BmwItem {
     uint32_t list, blk_begin;
 };
 // geometry of one list's range-table levels, derived from the collection size and the list's shift alone
+// membership hint of a doc-id inside its level-1 range (BatchArgs::rmh)
+__host__ __device__ inline uint32_t rmh_code(uint32_t doc, uint32_t shift) { return 1u + (doc & ((1u << shift) - 1u)) % 254u; }
 struct RmwLevels {
     uint32_t e[3];   // entries of level 1, 2, 3
     uint64_t off[3]; // byte offset of each level from the start of the list's table
@@ -150,6 +158,7 @@ struct BmwArgs {
     float* bmw;             // out: one per block
     unsigned int* list_bmw; // out: per list max (float bits; weights are >= 0 so the bit patterns order like the values)
     uint8_t* rmw;           // second pass (k_range_max_weights): the range tables; lists[].max_weight = the list maximum of pass 1
+    uint8_t* rmh;           // second pass, level-1 fill: the membership hints (BatchArgs::rmh) or null
     uint32_t bitmaps;       // level-1 pass: also set the bits of the dense lists' bitmaps
     uint32_t rmw_level;     // 0: fill level 1 from the postings; 1 / 2: items = {list, first entry of a 4096-entry run of level
                             // rmw_level + 1}, each entry the maximum of 64 entries of the level below

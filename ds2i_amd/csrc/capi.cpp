@@ -73,8 +73,10 @@ void free_index(ds2i_hip_index* x) {
     if (x->oneshot) ds2i_batch_destroy(x->oneshot);
     if (x->d_bmw) (void)hipFree(x->d_bmw);
     if (x->d_rmw) (void)hipFree(x->d_rmw);
+    if (x->d_rmh) (void)hipFree(x->d_rmh);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
+    for (auto& s : x->stream_b) if (s) (void)hipStreamDestroy(s);
     if (x->s_up) (void)hipStreamDestroy(x->s_up);
     if (x->s_merge) (void)hipStreamDestroy(x->s_merge);
     delete x;
@@ -201,6 +203,21 @@ int build_block_max_weights(ds2i_hip_index* x) {
         }
     }
     x->rmw_bytes = bytes;
+    // membership hints (abi_structs.hpp, BatchArgs::rmh): the pipelined ranked_and kernel of block_optpfor indexes reads
+    // them; a parallel buffer with the tables' offsets (only the level-1 regions are written). Optional like the tables.
+    if (x->kind == DS2I_BLOCK_OPTPFOR && !std::getenv("DS2I_NO_RMH")) {
+        static std::mutex hint_alloc_mu;
+        std::lock_guard<std::mutex> g(hint_alloc_mu);
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        if (bytes <= free_b / 2 && hipMalloc((void**)&x->d_rmh, bytes) == hipSuccess) {
+            HIP_OK(hipMemsetAsync(x->d_rmh, 0, bytes, x->stream[0]));
+        } else {
+            (void)hipGetLastError();
+            x->d_rmh = nullptr;
+            std::fprintf(stderr, "ds2i_hip: index uploaded without membership hints (%.2f GB wanted); ranked_and looks more candidates up\n", bytes / 1e9);
+        }
+    }
     HIP_OK(hipMemsetAsync(x->d_rmw, 0, bytes, x->stream[0]));
     for (uint64_t t = 0; t < V; ++t) {
         lists[t].rmw_off64 = x->list_rmw_off64[t];
@@ -209,6 +226,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
     }
     HIP_OK(hipMemcpyAsync(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice, x->stream[0]));
     a.rmw = x->d_rmw;
+    a.rmh = x->d_rmh;
     a.rmw_level = 0;
     a.bitmaps = std::getenv("DS2I_NO_BITMAPS") ? 0u : 1u;
     x->has_bitmaps = a.bitmaps != 0;
@@ -229,7 +247,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
         HIP_OK(ds2i_launch_block_max_weights(&a, (unsigned)std::min<size_t>(items.size(), (size_t)x->num_cus * 64), x->stream[0]));
     }
     HIP_OK(hipStreamSynchronize(x->stream[0]));
-    x->extra_bytes += bytes;
+    x->extra_bytes += bytes + (x->d_rmh ? bytes : 0);
     return DS2I_OK;
 }
 
@@ -441,6 +459,7 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
             int pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
             if (flat) pri = (lo_pri + hi_pri) / 2;
             HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, pri));
+            if (c < 3) HIP_OK(hipStreamCreateWithPriority(&x->stream_b[c], hipStreamNonBlocking, pri));
         }
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
@@ -471,7 +490,8 @@ int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out)
     std::memset(out, 0, sizeof *out);
     const bool freq_layout = idx->kind >= DS2I_OPT;
     out->block_weight_bytes = idx->d_bmw ? 4 * idx->total_blocks : 0;
-    out->range_table_bytes = idx->d_rmw ? idx->rmw_bytes : 0;
+    out->range_table_bytes = idx->d_rmw ? idx->rmw_bytes + (idx->d_rmh ? idx->rmw_bytes : 0) : 0;
+    out->has_membership_hints = idx->d_rmh != nullptr;
     out->skip_table_bytes = idx->d_skip ? 8 * idx->total_blocks : 0;
     out->norm_len_bytes = idx->has_wand ? 4 * idx->num_docs : 0;
     out->index_bytes = idx->arena_bytes + idx->extra_bytes - out->block_weight_bytes - out->range_table_bytes - out->skip_table_bytes;
@@ -544,7 +564,18 @@ int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint32_t level
     *shift = 0;
     *list_max = 0.f;
     if (!idx->d_rmw) return DS2I_OK;
-    if (level > 3) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: level must be 0 (the bitmap), 1, 2 or 3");
+    if (level > 4) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: level must be 0 (the bitmap), 1, 2, 3 or 4 (the membership hints)");
+    if (level == 4) { // membership hints: one byte per level-1 entry (0 entries = this index has none)
+        *shift = idx->list_rmw_shift[term];
+        *list_max = idx->list_bmw[term];
+        if (!idx->d_rmh) return DS2I_OK;
+        const ds2i_dev::RmwLevels gh((uint32_t)idx->num_docs, idx->list_rmw_shift[term]);
+        *entries = gh.e[0];
+        if (!out || capacity < *entries) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_list_range_table: capacity too small");
+        HIP_OK(hipSetDevice(idx->device));
+        HIP_OK(hipMemcpy(out, idx->d_rmh + 64ull * idx->list_rmw_off64[term], *entries, hipMemcpyDeviceToHost));
+        return DS2I_OK;
+    }
     const ds2i_dev::RmwLevels g((uint32_t)idx->num_docs, idx->list_rmw_shift[term]);
     if (level == 0) { // the exact bitmap of a dense list: (num_docs + 7) / 8 bytes, bit d = doc-id d; 0 entries = the list has none
         *list_max = idx->list_bmw[term];

@@ -74,6 +74,7 @@ struct ds2i_hip_batch {
     std::vector<SubLaunch> sub[NCLS];
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
+    int sset = 0;                 // which set of class streams this launch uses (alternates between consecutive launches)
     bool uploaded = false, launched = false;
     float cls_ms[NCLS] = {};
     Stats cls_stats[NCLS] = {};
@@ -207,7 +208,27 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 // most of them are left after one decode and one gather per other list -- so a unit's time goes with its
                 // number of list-0 blocks, a little more per block the more lists there are (measured wave time per round:
                 // 6 / 10 / 15 us for the <=2- / <=4- / <=8-list classes)
-                if (ranked && idx->d_rmw && tf.size() > 1) cost = qnb0[q] * (3.0 + (double)tf.size());
+                if (ranked && idx->d_rmw && tf.size() > 1) {
+                    cost = qnb0[q] * (3.0 + (double)tf.size());
+                    // ... unless the bounds have little to work with. A block of the driving list is cheap when the heap threshold
+                    // kills its candidates at the range tables; how many instead get as far as a lookup in the other lists goes with
+                    // (a) how many sit in an occupied range of every other list (~1/4 per list: the tables hold 4-8 entries per
+                    // posting) and (b) how high the threshold can be -- the k-th best of an expected M = n0 * prod(n_j / N) matches:
+                    // with M in the hundreds a few candidates of every block pass, with M in the 100 000s none. A lookup costs a
+                    // block search + a decode of another list's block, about 4x the block's own cost (measured: 9 us per block for
+                    // two 80 k-posting lists against 2 us for the typical unit; left unsplit such queries were the kernel's tail).
+                    double M = (double)qterms[begin].n, inrange = 128.0;
+                    for (size_t i = begin + 1; i < qterms.size(); ++i) {
+                        M *= (double)qterms[i].n / (double)idx->num_docs;
+                        inrange *= 0.25;
+                    }
+                    const double span_entries = 128.0 * (double)idx->num_docs / std::max(1.0, (double)qterms[begin].n) /
+                                                (double)(1u << std::min(31u, qterms[begin + 1].rmw_shift));
+                    const double lookups = inrange * std::min(1.0, 3.0 * (double)k / std::max(1.0, M)) * std::min(1.0, span_entries / 128.0);
+                    static const char* lw = std::getenv("DS2I_LOOKUP_WEIGHT");
+                    static const double lookup_weight = lw ? std::atof(lw) : 3.5;
+                    cost *= 1.0 + lookup_weight * std::min(1.0, lookups);
+                }
                 // a one-term ranked query scans its block weights (64 per probe) and decodes about k blocks
                 if (ranked && idx->d_bmw && tf.size() == 1) cost = qnb0[q] / 16.0 + 4.0 * k;
                 b->match_off[q + 1] = 128ull * qnb0[q];
@@ -312,6 +333,17 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 parts = (uint32_t)std::min<double>(std::max(1.0, want), qnb0[q]);
             }
             const uint32_t nb0 = std::max(1u, qnb0[q]);
+            if (rmw_units && split_ok && nt > 1) {
+                // The cost model prices a block of the driving list at its average, but a query whose conjunction holds fewer than k
+                // documents never gets a threshold: every one of its blocks goes all the way through the other lists (10 us per
+                // block with 2 lists, 25 us with 4, against 2-4 us). Left whole, a 600-block query of that kind ran for 6 ms and WAS
+                // the kernel's span (DS2I_UNIT_CLOCK: 1 700 of 6 144 wave slots busy on average). The cost model above now prices
+                // such queries; DS2I_UNIT_CAP (blocks; half of it beyond 2 lists) additionally bounds every unit -- off by
+                // default: cutting EVERY query that fine cost 20 % (each part warms up its own heap).
+                static const char* uc = std::getenv("DS2I_UNIT_CAP");
+                static const uint32_t cap_env = uc && std::atoi(uc) > 0 ? (uint32_t)std::atoi(uc) : 0u;
+                if (cap_env) parts = std::max(parts, (nb0 + (c == 0 ? cap_env : std::max(8u, cap_env / 2)) - 1) / (c == 0 ? cap_env : std::max(8u, cap_env / 2)));
+            }
             const uint32_t per = (nb0 + parts - 1) / parts;
             parts = (nb0 + per - 1) / per;
             if (parts > 1) b->split_queries.push_back(q);
@@ -639,18 +671,26 @@ int launch_batch(ds2i_hip_batch* b) {
         HIP_OK(hipMemsetAsync(b->d_clk.p, 0, 16 * (size_t)(b->nunits ? b->nunits : 1), idx->s_up));
         HIP_OK(hipStreamSynchronize(idx->s_up));
     }
+    // DS2I_STREAM_SETS=1: consecutive batches alternate between two sets of class streams, so that a class kernel starts
+    // while the tail of the previous batch's kernel of that class is still running. Measured -3 % (the kernels overlap but
+    // each runs longer): off by default.
+    static const char* e_sets = std::getenv("DS2I_STREAM_SETS");
+    static const bool one_set = !(e_sets && std::atoi(e_sets) > 0);
+    b->sset = one_set ? 0 : idx->launch_parity;
+    idx->launch_parity ^= 1;
+    auto cls_stream = [&](int c) { return (b->sset && c < 3) ? idx->stream_b[c] : idx->stream[c]; };
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
     for (int c = 0; c < NCLS; ++c) {
         if (!b->ncls[c]) continue;
-        HIP_OK(hipStreamWaitEvent(idx->stream[c], b->ev_clear, 0));
-        if (b->use_seed) HIP_OK(hipStreamWaitEvent(idx->stream[c], b->seed->ev_done, 0));
+        HIP_OK(hipStreamWaitEvent(cls_stream(c), b->ev_clear, 0));
+        if (b->use_seed) HIP_OK(hipStreamWaitEvent(cls_stream(c), b->seed->ev_done, 0));
     }
     HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
     if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
     for (int ci = NCLS - 1; ci >= 0; --ci) {
         const int c = small_first ? NCLS - 1 - ci : ci;
         if (!b->ncls[c]) continue;
-        hipStream_t s = idx->stream[c];
+        hipStream_t s = cls_stream(c);
         HIP_OK(hipEventRecord(b->ev_c0[c], s));
         BatchArgs a{};
         a.arena = idx->d_arena;
@@ -695,6 +735,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.rmw = (no_rmw_use || (base_op == DS2I_OP_RANKED_AND && !a.bmw)) ? nullptr : idx->d_rmw;
         static const bool no_bm_use = std::getenv("DS2I_NO_BITMAP_USE") != nullptr; // A/B: bitmaps built but not consulted
         a.rmw_bitmaps = (a.rmw && idx->has_bitmaps && !no_bm_use) ? 1u : 0u;
+        static const bool no_rmh_use = std::getenv("DS2I_NO_RMH_USE") != nullptr; // A/B: hints built but not consulted
+        a.rmh = (a.rmw && !no_rmh_use) ? idx->d_rmh : nullptr;
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;
@@ -703,11 +745,10 @@ int launch_batch(ds2i_hip_batch* b) {
             a.order = order_base + sl.begin;
             a.nslice = sl.end - sl.begin;
             a.dyn_lists = sl.lists;
-            if (sl.stream && !a.block_profile && !a.unit_clock && a.skip && a.bmw && a.rmw) {
-                HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, s));
-                continue;
-            }
-            HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
+            // (the groups of a class run back to back on its stream: launching them beside each other on further streams
+            // was tried -- with that many streams the hardware queues are oversubscribed and steps of 0.5-0.9 s appear)
+            if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw) HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, s));
+            else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
         }
         HIP_OK(hipEventRecord(b->ev_c1[c], s));
         HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[c], 0));
@@ -832,6 +873,7 @@ void ds2i_batch_destroy(ds2i_hip_batch* b) {
             (void)hipEventDestroy(b->ev_c1[c]);
         }
     }
+
     delete b; // DevBuf / PinBuf members release their memory
 }
 

@@ -98,6 +98,7 @@ struct ds2i_hip_index {
     float* d_bmw = nullptr;         // per block / chunk: max doc_term_weight of its postings (ranked_and pruning), or null
     uint8_t* d_rmw = nullptr;       // doc-id-range max-weight tables (abi_structs.hpp, BatchArgs::rmw), or null
     uint64_t rmw_bytes = 0;
+    uint8_t* d_rmh = nullptr;       // membership hints: one more byte per level-1 range-table entry, same offsets (BatchArgs::rmh), or null
     int rmw_g = 0;                  // entries per posting the tables were built with (DS2I_RMW_G)
     bool d_skip_or_pef() const { return d_skip != nullptr || kind >= DS2I_OPT; } // what the streaming kernels walk the driving list by
     bool has_bitmaps = false;       // dense lists carry an exact bitmap behind their range-table levels
@@ -109,6 +110,11 @@ struct ds2i_hip_index {
     // class kernels of consecutive batches queue up on the class streams; uploads and merges / result copies have
     // their own streams so that the next batch's H2D never waits behind the previous batch's merge
     hipStream_t stream[NCLS] = {};
+    // Consecutive batches alternate between two sets of class streams (classes 0..2; the rare classes share one), so that the
+    // class kernel of batch i+1 starts while the last, longest units of batch i's kernel of the same class are still running
+    // -- on one stream the whole GPU would wait for that tail (DS2I_STREAM_SETS=1; off by default: measured -3 %).
+    hipStream_t stream_b[3] = {};
+    int launch_parity = 0;
     hipStream_t s_up = nullptr, s_merge = nullptr;
     unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
     ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)

@@ -2334,6 +2334,19 @@ DS2I_DEV void rmw_raise(uint8_t* tab, uint32_t entry, uint32_t q) {
     }
 }
 
+// membership hint of a range: first posting -> its code, any further posting -> 255 (bytes have no atomics: CAS on the dword)
+DS2I_DEV void rmh_mark(uint8_t* tab, uint32_t entry, uint32_t code) {
+    unsigned int* word = (unsigned int*)(tab + (entry & ~3u));
+    const uint32_t sh = 8u * (entry & 3u);
+    unsigned int old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint32_t cur = (old >> sh) & 255u;
+        if (cur == 255u) break;
+        const unsigned int want = (old & ~(255u << sh)) | ((cur ? 255u : code) << sh);
+        if (__hip_atomic_compare_exchange_strong(word, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
     __shared__ Lds<1> L;
     BatchArgs ba{};
@@ -2378,6 +2391,7 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
         const uint32_t end = it.blk_begin + 64u < nb ? it.blk_begin + 64u : nb;
         float mine = 0.f;
         uint8_t* const rtab = a.rmw ? a.rmw + 64ull * t.rmw_off64 : nullptr;
+        uint8_t* const htab = (a.rmw && a.rmh) ? a.rmh + 64ull * t.rmw_off64 : nullptr;
         const float rinv = t.max_weight > 0.f ? 255.0f / t.max_weight : 0.f; // second pass: max_weight = the list's largest weight
         unsigned int* const bm = (a.rmw && a.bitmaps && RmwLevels::has_bitmap(t.n, a.num_docs))
                                      ? (unsigned int*)(a.rmw + 64ull * t.rmw_off64 + RmwLevels(a.num_docs, t.rmw_shift).bytes()) : nullptr;
@@ -2388,6 +2402,10 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
             float w = 0.f;
             if (lane < sz) w = doc_term_weight(L.freqs[0][lane], a.norm_lens[L.docs[0][lane]]);
             if (a.rmw && lane < sz) rmw_raise(rtab, L.docs[0][lane] >> t.rmw_shift, rmw_quantise(w, rinv));
+            if (htab) {
+                if (lane < sz) rmh_mark(htab, L.docs[0][lane] >> t.rmw_shift, rmh_code(L.docs[0][lane], t.rmw_shift));
+                if (lane + 64 < sz) rmh_mark(htab, L.docs[0][lane + 64] >> t.rmw_shift, rmh_code(L.docs[0][lane + 64], t.rmw_shift));
+            }
             if (bm) { // dense list: its exact bitmap
                 if (lane < sz) atomicOr(bm + (L.docs[0][lane] >> 5), 1u << (L.docs[0][lane] & 31u));
                 if (lane + 64 < sz) atomicOr(bm + (L.docs[0][lane + 64] >> 5), 1u << (L.docs[0][lane + 64] & 31u));

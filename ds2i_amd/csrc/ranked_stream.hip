@@ -213,6 +213,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         KArgs a = rs_args(); // (fields read below stay live for the unit; the cold ones are re-read at their use site)
         const uint32_t uid = a->order[tkt];
         const Unit u = a->units[uid];
+        if constexpr (STATS) { // diagnostic (DS2I_UNIT_CLOCK=1): when the unit started / ended
+            unsigned long long* const clk = a->unit_clock;
+            if (clk && lane == 0) clk[2ull * uid] = wall_clock64();
+        }
         const uint32_t q = u.q;
         const bool whole = u.nparts == 1;
         const QTerm* const qt = a->qterms + a->q_off[q]; // exactly NT terms (the planner's launch groups)
@@ -234,6 +238,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             rsc[j] = qt[j].rmw_scale;
         };
         rs_for<1, NT>(bind_one);
+        const long long hdelta = a->rmh ? (long long)(a->rmh - a->rmw) : 0ll; // hint of an entry = the byte at the same offset of the parallel buffer
         // block of list j whose doc-ids are in L.dj[j-1] (cur = ~0: none), its block_max, size and the arena offset of its
         // freqs part; f_owner = list whose current block's freqs are in L.fj (0 = nobody); stb_owner = list whose current
         // block's bytes are in L.stb (from stb_base on). Only stage C touches them: they live in the lanes of one VGPR
@@ -410,6 +415,19 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 float r0 = rest_of(gB0, 0), r1 = rest_of(gB1, 0);
                 ok0 = ok0 & enters((B.wq + r0) * BOUND_SLACK);
                 ok1 = ok1 & enters((B.wq + r1) * BOUND_SLACK);
+                if (hdelta && (ballot(ok0) | ballot(ok1))) {
+                    // membership hints (BatchArgs::rmh): a weight byte only says that SOME posting of list j lies in the candidate's
+                    // range; where that range holds exactly one posting its hint byte says which. A candidate at another offset is
+                    // not in the list -- settled here, by one more byte, instead of by a block search and a block decode in stage C.
+                    auto hint_one = [&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        const uint8_t* const ht = rt[j] + hdelta;
+                        const uint32_t h0 = ok0 ? (uint32_t)ht[dB0 >> rsh[j]] : 255u, h1 = ok1 ? (uint32_t)ht[dB1 >> rsh[j]] : 255u;
+                        ok0 = ok0 & ((h0 == 255u) | (h0 == rmh_code(dB0, rsh[j])));
+                        ok1 = ok1 & ((h1 == 255u) | (h1 == rmh_code(dB1, rsh[j])));
+                    };
+                    rs_for<1, NT>(hint_one);
+                }
                 if (__builtin_expect((ballot(ok0) | ballot(ok1)) != 0, 0)) {
                     // ---------------- stage C: somebody of block B may enter the heap
                     // freqs of the block (its bytes are still staged), freq-only bound (doc_term_weight falls with norm_len, so the
@@ -618,6 +636,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 #undef cget
 #undef cset
         KArgs r = rs_args();
+        if constexpr (STATS) {
+            unsigned long long* const clk = r->unit_clock;
+            if (clk && lane == 0) clk[2ull * uid + 1] = wall_clock64();
+        }
         if (whole) {
             if (lane == 0) { r->out_count[q] = tk.n; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }
             store_topk_rs(r->out_topk, r->out_topk_len, tk.k, q, tk);

@@ -14,7 +14,9 @@
 // std::invalid_argument / std::runtime_error too; its query path only asserts).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <deque>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -124,7 +126,10 @@ public:
             for (uint32_t q = 0; q < nq; ++q) m_topk[q].assign(topk.begin() + (size_t)q * k, topk.begin() + (size_t)q * k + len[q]);
         return m_counts;
     }
-    std::vector<float> const& topk() const { return m_topk.back(); }          // last query (reference shape)
+    std::vector<float> const& topk() const {                                  // last query (reference shape)
+        static const std::vector<float> none;
+        return m_topk.empty() ? none : m_topk.back();
+    }
     std::vector<std::vector<float>> const& topk_batch() const { return m_topk; }
     ds2i_hip_stats const& stats() const { return m_stats; }
     void collect_counters(bool on) { m_counters = on; }
@@ -155,19 +160,24 @@ public:
     gpu_pipeline& operator=(gpu_pipeline const&) = delete;
     ~gpu_pipeline() { ds2i_hip_pipeline_destroy(m_h); }
     uint32_t depth() const { return m_depth; }
-    uint64_t submit(int op, uint32_t k, std::vector<term_id_vec> const& queries) {
-        std::vector<uint32_t> terms, offs(queries.size() + 1, 0);
-        for (size_t q = 0; q < queries.size(); ++q) {
-            terms.insert(terms.end(), queries[q].begin(), queries[q].end());
+    uint64_t submit(int op, uint32_t k, std::vector<term_id_vec> const& queries) { return submit(op, k, queries.begin(), queries.end()); }
+    // a run of queries of a larger batch, without copying it
+    template <class It> uint64_t submit(int op, uint32_t k, It first, It last) {
+        const size_t nq = (size_t)(last - first);
+        std::vector<uint32_t> terms, offs(nq + 1, 0);
+        size_t q = 0;
+        for (It it = first; it != last; ++it, ++q) {
+            terms.insert(terms.end(), it->begin(), it->end());
             offs[q + 1] = (uint32_t)terms.size();
         }
         if (terms.empty()) terms.push_back(0);
         uint64_t ticket = 0;
-        check(ds2i_hip_pipeline_submit(m_h, op, k, terms.data(), offs.data(), (uint32_t)queries.size(), &ticket), "ds2i_hip_pipeline_submit");
+        check(ds2i_hip_pipeline_submit(m_h, op, k, terms.data(), offs.data(), (uint32_t)nq, &ticket), "ds2i_hip_pipeline_submit");
         if (m_meta.size() <= ticket % m_depth) m_meta.resize(m_depth);
-        m_meta[ticket % m_depth] = {(uint32_t)queries.size(), ((op & 0xFF) >= DS2I_OP_RANKED_AND) ? k : 1u};
+        m_meta[ticket % m_depth] = {(uint32_t)nq, ((op & 0xFF) >= DS2I_OP_RANKED_AND) ? k : 1u};
         return ticket;
     }
+    void set_instrumented(bool on) { check(ds2i_hip_pipeline_set_instrumented(m_h, on ? 1 : 0), "ds2i_hip_pipeline_set_instrumented"); }
     result wait(uint64_t ticket) {
         const auto meta = m_meta.at(ticket % m_depth);
         result r;
@@ -223,7 +233,12 @@ private:
     std::vector<std::unique_ptr<gpu_index>> m_replicas;
 };
 
-// the query-operator concept over a replica set: same calls, same answers as gpu_query_op over one index
+// the query-operator concept over a replica set: same calls, same answers as gpu_query_op over one index.
+// A batch is cut into TICKETS (contiguous runs of queries, several per replica) that the replicas' host threads take off a
+// shared counter -- profile_queries.cpp:21-39 hands query i to thread i mod N; a counter does the same without assuming
+// that all queries cost alike -- and every replica drives its tickets through its own pipeline (ds2i_hip_pipeline_*), two
+// in flight: while the kernels of one ticket run, the next is being planned and uploaded. A batch that fits one ticket
+// (the per-query latency loop of the `queries` driver) is answered inline on replica 0: no thread is created for it.
 template <int OP>
 class gpu_set_query_op {
 public:
@@ -234,53 +249,92 @@ public:
         return (*this)(set, one)[0];
     }
     std::vector<uint64_t> const& operator()(gpu_index_set const& set, std::vector<term_id_vec> const& queries) {
-        const size_t parts = set.replicas();
-        if (m_ops.size() != parts) m_ops.assign(parts, gpu_query_op<OP>(m_k));
-        std::vector<std::vector<term_id_vec>> slices(parts);
-        std::vector<std::vector<uint64_t>> counts(parts);
-        std::vector<std::string> errors(parts);
-        std::vector<std::thread> pool;
-        for (size_t r = 0; r < parts; ++r) {
-            const auto range = gpu_index_set::slice(queries.size(), r, parts);
-            slices[r].assign(queries.begin() + range.first, queries.begin() + range.second);
-            m_ops[r].collect_counters(m_counters);
-            if (slices[r].empty()) continue;
-            pool.emplace_back([&, r] { // one host thread per replica: its slice crosses the C ABI on that device's streams
-                try { counts[r] = m_ops[r](set.replica(r), slices[r]); }
-                catch (std::exception const& e) { errors[r] = e.what(); }
-            });
+        const size_t parts = set.replicas(), n = queries.size();
+        const size_t per = ticket_size(n, parts), ntickets = per ? (n + per - 1) / per : 0;
+        m_stats = ds2i_hip_stats{};
+        if (ntickets <= 1) { // one ticket: inline, through the one-shot call of replica 0
+            if (m_ops.empty()) m_ops.assign(1, gpu_query_op<OP>(m_k));
+            m_ops[0].collect_counters(m_counters);
+            m_counts = m_ops[0](set.replica(0), queries);
+            m_topk = m_ops[0].topk_batch();
+            m_stats = m_ops[0].stats();
+            return m_counts;
         }
+        if (m_pipes.size() != parts || m_pipes_of != &set) {
+            m_pipes.clear();
+            for (size_t r = 0; r < parts; ++r) m_pipes.emplace_back(new gpu_pipeline(set.replica(r), 2));
+            m_pipes_of = &set;
+        }
+        m_counts.assign(n, 0);
+        m_topk.assign(n, std::vector<float>());
+        const uint32_t k = ranked() ? (uint32_t)m_k : 1u;
+        std::atomic<size_t> next(0);
+        std::vector<std::string> errors(parts);
+        std::vector<ds2i_hip_stats> stats(parts, ds2i_hip_stats{});
+        auto worker = [&](size_t r) {
+            try {
+                gpu_pipeline& pipe = *m_pipes[r];
+                pipe.set_instrumented(m_counters);
+                std::deque<std::pair<uint64_t, size_t>> inflight; // (pipeline ticket, first query)
+                for (;;) {
+                    while (inflight.size() < pipe.depth()) {
+                        const size_t t = next.fetch_add(1);
+                        if (t >= ntickets) break;
+                        const size_t lo = t * per, hi = std::min(n, lo + per);
+                        inflight.emplace_back(pipe.submit(OP, k, queries.begin() + lo, queries.begin() + hi), lo);
+                    }
+                    if (inflight.empty()) break;
+                    const auto head = inflight.front();
+                    inflight.pop_front();
+                    gpu_pipeline::result res = pipe.wait(head.first);
+                    for (size_t i = 0; i < res.counts.size(); ++i) {
+                        m_counts[head.second + i] = res.counts[i];
+                        if (ranked()) m_topk[head.second + i].assign(res.topk.begin() + i * k, res.topk.begin() + i * k + res.topk_len[i]);
+                    }
+                    stats[r].kernel_ms += res.stats.kernel_ms;
+                    stats[r].docs_blocks_decoded += res.stats.docs_blocks_decoded;
+                    stats[r].freqs_blocks_decoded += res.stats.freqs_blocks_decoded;
+                    stats[r].block_max_examined += res.stats.block_max_examined;
+                    stats[r].algorithmic_bytes += res.stats.algorithmic_bytes;
+                    stats[r].postings_scored += res.stats.postings_scored;
+                    stats[r].rounds += res.stats.rounds;
+                }
+            } catch (std::exception const& e) { errors[r] = e.what(); }
+        };
+        std::vector<std::thread> pool; // one host thread per replica: its tickets cross the C ABI on that device's streams
+        for (size_t r = 1; r < parts; ++r) pool.emplace_back(worker, r);
+        worker(0);
         for (auto& t : pool) t.join();
         for (auto const& e : errors) if (!e.empty()) throw std::runtime_error(e);
-        m_counts.clear();
-        m_topk.clear();
-        m_stats = ds2i_hip_stats{};
-        for (size_t r = 0; r < parts; ++r) { // the host concatenates the slices in order: that is the whole "merge"
-            if (slices[r].empty()) continue;
-            m_counts.insert(m_counts.end(), counts[r].begin(), counts[r].end());
-            auto const& tk = m_ops[r].topk_batch();
-            m_topk.insert(m_topk.end(), tk.begin(), tk.end());
-            ds2i_hip_stats const& st = m_ops[r].stats();
-            m_stats.kernel_ms = std::max(m_stats.kernel_ms, st.kernel_ms);
-            m_stats.docs_blocks_decoded += st.docs_blocks_decoded;
-            m_stats.freqs_blocks_decoded += st.freqs_blocks_decoded;
-            m_stats.block_max_examined += st.block_max_examined;
-            m_stats.algorithmic_bytes += st.algorithmic_bytes;
-            m_stats.postings_scored += st.postings_scored;
-            m_stats.rounds += st.rounds;
+        for (size_t r = 0; r < parts; ++r) {
+            m_stats.kernel_ms = std::max(m_stats.kernel_ms, stats[r].kernel_ms);
+            m_stats.docs_blocks_decoded += stats[r].docs_blocks_decoded;
+            m_stats.freqs_blocks_decoded += stats[r].freqs_blocks_decoded;
+            m_stats.block_max_examined += stats[r].block_max_examined;
+            m_stats.algorithmic_bytes += stats[r].algorithmic_bytes;
+            m_stats.postings_scored += stats[r].postings_scored;
+            m_stats.rounds += stats[r].rounds;
         }
         return m_counts;
     }
-    std::vector<float> const& topk() const { return m_topk.back(); }
-    std::vector<std::vector<float>> const& topk_batch() const { return m_topk; }
-    ds2i_hip_stats const& stats() const { return m_stats; } // kernel_ms = slowest replica, counters summed
+    // scores of the last query of the last batch (reference shape); empty for an empty batch and for and / or
+    std::vector<float> const& topk() const {
+        static const std::vector<float> none;
+        return m_topk.empty() ? none : m_topk.back();
+    }
+    std::vector<std::vector<float>> const& topk_batch() const { return m_topk; } // one entry per query (empty for and / or)
+    ds2i_hip_stats const& stats() const { return m_stats; } // kernel_ms = busiest replica (sum of its tickets' windows), counters summed
     void collect_counters(bool on) { m_counters = on; }
     static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
+    // queries per ticket: about eight tickets per replica, never fewer than 64 queries (a ticket is a kernel launch)
+    static size_t ticket_size(size_t n, size_t parts) { return std::max<size_t>(64, (n + parts * 8 - 1) / (parts * 8)); }
 
 private:
     uint64_t m_k;
     bool m_counters = false;
     std::vector<gpu_query_op<OP>> m_ops;
+    std::vector<std::unique_ptr<gpu_pipeline>> m_pipes;
+    gpu_index_set const* m_pipes_of = nullptr;
     std::vector<uint64_t> m_counts;
     std::vector<std::vector<float>> m_topk;
     ds2i_hip_stats m_stats{};

@@ -120,6 +120,7 @@ typedef struct ds2i_hip_index_info {
     int has_block_weights;
     int has_range_tables;
     int has_bitmaps;
+    int has_membership_hints;    /* one more byte per level-1 range-table entry (block_optpfor indexes): see ds2i_hip_list_range_table */
     int range_table_entries_per_posting; /* DS2I_RMW_G in effect */
 } ds2i_hip_index_info;
 int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out);
@@ -219,7 +220,9 @@ int ds2i_hip_synth_encode(int device, const struct ds2i_synth_params* p, int thr
  * range table, level 1..3: byte e covers the doc-ids [e << *shift, (e + 1) << *shift): 0 = no posting of the list there,
  * else entry * (*list_max / 255) >= the largest doc_term_weight of the range; level l + 1 halves the resolution six
  * times (its entry e is the maximum of entries 64 e .. 64 e + 63 of level l). out gets *entries bytes. A table that
- * was not built (no wand data, DS2I_NO_BMW / DS2I_NO_RMW) reports 0 entries. */
+ * was not built (no wand data, DS2I_NO_BMW / DS2I_NO_RMW) reports 0 entries.
+ * level 4: the membership hints, one byte per level-1 entry: 0 = the range holds no posting, 255 = two or more, else
+ * 1 + (offset of its one posting inside the range) mod 254 (block_optpfor indexes; 0 entries elsewhere). */
 int ds2i_hip_list_block_weights(ds2i_hip_index* idx, uint32_t term, float* out, uint64_t capacity, uint64_t* nblocks);
 int ds2i_hip_list_range_table(ds2i_hip_index* idx, uint32_t term, uint32_t level, uint8_t* out, uint64_t capacity,
                               uint64_t* entries, uint32_t* shift, float* list_max);

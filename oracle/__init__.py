@@ -74,6 +74,7 @@ def lib(path=None):
     L.oracle_query.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, C.POINTER(Profile)]
     L.oracle_query.restype = C.c_int64
     L.oracle_query_batch.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(Profile)]
+    L.oracle_query_batch_mt.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     L.oracle_perftest.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp]
     if path is None:
         _lib = L
@@ -278,6 +279,28 @@ class Index:
         if rc:
             raise RuntimeError("oracle_query_batch failed (%d)" % rc)
         return count[:nq], topk[:nq], tlen[:nq], fsum[:nq], (prof.as_dict() if profile else None)
+
+    def query_batch_mt(self, op, queries, k=10, threads=None, match_hash=False):
+        """query_batch on `threads` host threads (default: the CPUs this process may use); no profile. With match_hash
+        (and / and_freq) also returns, per query, sum_i doc_i * (2 i + 1) mod 2^64 over its doc-id list."""
+        import os
+        if threads is None:
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+        terms, offs = _flatten(queries)
+        nq = len(queries)
+        count = np.zeros(max(nq, 1), dtype=np.uint64)
+        topk = np.full((max(nq, 1), k), -np.inf, dtype=np.float32)
+        tlen = np.zeros(max(nq, 1), dtype=np.uint32)
+        fsum = np.zeros(max(nq, 1), dtype=np.uint64)
+        mh = np.zeros(max(nq, 1), dtype=np.uint64) if match_hash else None
+        rc = self._L.oracle_query_batch_mt(self._h, _op(op), k, _p(terms), _p(offs), nq, int(max(1, threads)), _p(count), _p(topk), _p(tlen),
+                                           _p(fsum), _p(mh) if mh is not None else None)
+        if rc:
+            raise RuntimeError("oracle_query_batch_mt failed (%d)" % rc)
+        return count[:nq], topk[:nq], tlen[:nq], fsum[:nq], (mh[:nq] if mh is not None else None)
 
     def perftest(self, op, queries, k=10, runs=2):
         """op_perftest (queries.cpp:13-62): returns dict(avg,q50,q90,q95 in microseconds, seconds)."""

@@ -41,6 +41,8 @@
 #include <sys/time.h>
 #include <utility>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "oracle_pef.hpp"
 
@@ -1068,6 +1070,47 @@ int query_batch_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_
     if (prof) fill_profile(prof, p);
     return 0;
 }
+// The batch answered by `nthreads` host threads (the analogue of profile_queries.cpp:21-39: the index is immutable, every
+// thread owns its query_ctx and takes queries off a shared counter). Profiling is off (the profile hook is per index).
+// match_hash (optional, `and` / `and_freq`): per query, the order-sensitive checksum sum_i doc_i * (2 i + 1) mod 2^64 of
+// its doc-id list -- the full lists of a 4096-query batch at 25 M docs are hundreds of MB, the checksums are not.
+template <class Index>
+int query_batch_mt_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq, uint32_t nthreads,
+                     uint64_t* out_count, float* out_topk, uint32_t* out_topk_len, uint64_t* out_freq_sum, uint64_t* match_hash) {
+    idx.begin_profile(nullptr);
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> failed(0);
+    auto worker = [&]() {
+        try {
+            query_ctx<Index> c(&idx, &h->wdata, k ? k : 1);
+            std::vector<uint32_t> m;
+            if (match_hash) c.matches = &m;
+            for (;;) {
+                const uint32_t q = next.fetch_add(1);
+                if (q >= nq) break;
+                term_id_vec t(terms + offs[q], terms + offs[q + 1]);
+                c.freq_sum = 0;
+                c.topk.clear();
+                m.clear();
+                const uint64_t r = run_op(c, op, t);
+                if (out_count) out_count[q] = r;
+                if (out_topk)
+                    for (uint32_t i = 0; i < k; ++i) out_topk[(size_t)q * k + i] = i < c.topk.topk().size() ? c.topk.topk()[i] : -INFINITY;
+                if (out_topk_len) out_topk_len[q] = (uint32_t)c.topk.topk().size();
+                if (out_freq_sum) out_freq_sum[q] = c.freq_sum;
+                if (match_hash) {
+                    uint64_t hsh = 0;
+                    for (size_t i = 0; i < m.size(); ++i) hsh += (uint64_t)m[i] * (2 * (uint64_t)i + 1);
+                    match_hash[q] = hsh;
+                }
+            }
+        } catch (...) { failed = 1; }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t i = 0; i < std::max(1u, nthreads); ++i) pool.emplace_back(worker);
+    for (auto& th : pool) th.join();
+    return failed ? -1 : 0;
+}
 // op_perftest (queries.cpp:13-62)
 template <class Index>
 int perftest_t(const Index& idx, handle* h, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq, uint32_t runs, double* stats_out) {
@@ -1153,6 +1196,16 @@ int oracle_query_batch(void* hv, int op, uint32_t k, const uint32_t* terms, cons
     try {
         if (op >= OP_RANKED_AND && !h->has_wand) return -5;
         return visit(h, [&](auto& idx) { return query_batch_t(idx, h, op, k, terms, offs, nq, out_count, out_topk, out_topk_len, out_freq_sum, prof); });
+    } catch (...) { return -1; }
+}
+
+// oracle_query_batch on nthreads host threads (no profile); match_hash: see query_batch_mt_t
+int oracle_query_batch_mt(void* hv, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq, uint32_t nthreads,
+                          uint64_t* out_count, float* out_topk, uint32_t* out_topk_len, uint64_t* out_freq_sum, uint64_t* match_hash) {
+    handle* h = (handle*)hv;
+    try {
+        if (op >= OP_RANKED_AND && !h->has_wand) return -5;
+        return visit(h, [&](auto& idx) { return query_batch_mt_t(idx, h, op, k, terms, offs, nq, nthreads, out_count, out_topk, out_topk_len, out_freq_sum, match_hash); });
     } catch (...) { return -1; }
 }
 

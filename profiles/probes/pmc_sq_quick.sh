@@ -14,7 +14,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob("%s/pmc/**/*counter_collection.csv" % out, recursive=True):
     for r in csv.DictReader(open(f)):
         if ", true>(" in r["Kernel_Name"] or "rocclr" in r["Kernel_Name"]: continue
-        if not any(k in r["Kernel_Name"] for k in ("k_conjunctive", "k_union", "k_disjunctive")): continue
+        if not any(k in r["Kernel_Name"] for k in ("k_conjunctive", "k_union", "k_disjunctive", "k_ranked_stream")): continue
         agg[(r["Kernel_Name"][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
 tot = collections.defaultdict(float)
 for (k, n), v in sorted(agg.items()):

@@ -146,6 +146,41 @@ def _scale_properties(gidx, oidx, queries, nsample=48, k=10):
     return rtopk, rlen
 
 
+def _full_batch_equals_oracle(gidx, oidx, queries, k=10, union_n=1024, chunk=512):
+    """The WHOLE batch against the oracle, whatever the scale: the oracle answers it on every host core the process may use
+    (oracle.Index.query_batch_mt: one query_ctx per thread over the immutable index, profile_queries.cpp:21-39 style).
+    ranked_and: top-k of every query; and: counts and doc-id LISTS of every query (bit-exact, compared through an
+    order-sensitive 64-bit checksum per query -- the lists of a 4096-query batch at 25 M docs are gigabytes);
+    wand / maxscore: the first union_n queries."""
+    rc, rtopk, rlen, _ = gidx.query_batch("ranked_and", queries, k=k)
+    oc, otk, otl, _, _ = oidx.query_batch_mt("ranked_and", queries, k=k)
+    assert np.array_equal(rlen, otl) and np.array_equal(rc, oc)
+    f = np.isfinite(otk)
+    assert np.array_equal(np.isfinite(rtopk), f)
+    np.testing.assert_allclose(rtopk[f], otk[f], rtol=RTOL)
+    oac, _, _, _, ohash = oidx.query_batch_mt("and", queries, match_hash=True)
+    for lo in range(0, len(queries), chunk):  # (the doc-id buffer of a batch is sized for the shortest lists' full lengths)
+        part = queries[lo:lo + chunk]
+        b = d.Batch(gidx, "and", part, want_matches=True)
+        b.run()
+        count = b.fetch()[0]
+        got = b.fetch_matches(count)
+        b.close()
+        assert np.array_equal(count, oac[lo:lo + chunk])
+        for i, m in enumerate(got):
+            m64 = m.astype(np.uint64)
+            h = (m64 * (2 * np.arange(len(m64), dtype=np.uint64) + 1)).sum(dtype=np.uint64)
+            assert h == ohash[lo + i], (lo + i, part[i])
+    for op in ("wand", "maxscore"):
+        sub = queries[:union_n]
+        _, gt, gl, _ = gidx.query_batch(op, sub, k=k)
+        _, ot, ol, _, _ = oidx.query_batch_mt(op, sub, k=k)
+        assert np.array_equal(gl, ol), op
+        f = np.isfinite(ot)
+        assert np.array_equal(np.isfinite(gt), f), op
+        np.testing.assert_allclose(gt[f], ot[f], rtol=RTOL, err_msg=op)
+
+
 def _and_match_lists_equal_oracle(gidx, oidx, sample):
     """north_star: and_query doc-id LISTS bit-exact (not only their lengths), at whatever scale the index has"""
     b = d.Batch(gidx, "and", sample, want_matches=True)
@@ -217,6 +252,17 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
             padded[:len(prev)] = prev
             assert np.array_equal(up, padded.reshape(-1, 64).max(axis=1)), (codec, t, level)
             prev = up
+        hints, hsh, _ = gidx.range_table(t, 4)  # membership hints (block_optpfor): 0 empty, 255 several postings, else 1 + offset % 254
+        if codec == "block_optpfor":
+            assert hsh == sh and len(hints) == len(tab)
+            cnt = np.bincount(docs >> sh, minlength=len(tab))
+            exp = np.zeros(len(tab), dtype=np.uint8)
+            exp[cnt > 1] = 255
+            single = cnt[docs >> sh] == 1
+            exp[(docs >> sh)[single]] = (1 + (docs[single] & ((1 << sh) - 1)) % 254).astype(np.uint8)
+            assert np.array_equal(hints, exp), (codec, t)
+        else:
+            assert len(hints) == 0
 
 
 def test_block_mixed_image_holds_all_three_block_types(images):
@@ -848,6 +894,7 @@ def test_gov2_scale_properties(built_lib):
     oidx = o.Index("block_optpfor", img, wand)
     rtopk, rlen = _scale_properties(gidx, oidx, queries)
     _union_topk_equals_oracle(gidx, oidx, queries, nsample=40)     # configs[3]: wand + maxscore vs the oracle at 25 M docs
+    _full_batch_equals_oracle(gidx, oidx, queries)                 # every query of the batch, not a sample
     and_count, _, _, _ = gidx.query_batch("and", queries[:256])
     # or >= and; wand == maxscore == ranked_or (test_ranked_queries.cpp:39-57), and they dominate ranked_and
     or_count, _, _, _ = gidx.query_batch("or", queries[:256])
@@ -998,6 +1045,7 @@ def test_gov2_scale_opt_index_configs2(built_lib):
     oidx = o.Index("opt", img, wand)
     rtopk, rlen = _scale_properties(gidx, oidx, queries)
     _union_topk_equals_oracle(gidx, oidx, queries, nsample=32)
+    _full_batch_equals_oracle(gidx, oidx, queries, union_n=512)  # every query of the batch, not a sample
     # wand == maxscore (test_ranked_queries.cpp:39-57) and they dominate ranked_and, on a slice of the batch
     sub = queries[:512]
     _, wt, wl, _ = gidx.query_batch("wand", sub, k=10)

@@ -68,3 +68,18 @@ def test_profile_counts_reference_traversal(coll, queries):
     p = r["profile"]
     assert p["docs_blocks"] >= 2 and p["block_max_examined"] >= p["docs_blocks"]
     assert p["algorithmic_bytes"] > 0 and p["postings_scored"] == len(brute_and(coll, [0, 1]))
+
+
+@pytest.mark.parametrize("codec", ["block_optpfor", "opt"])
+def test_threaded_oracle_batch_equals_sequential(coll, queries, codec):
+    """query_batch_mt (the oracle on every host core: what the GPU tests compare a FULL 4096-query batch against at 25 M
+    docs) gives the single-thread answers, and its per-query doc-id checksum is the checksum of the brute-force list."""
+    idx = o.Index(codec, coll.index_image(codec), coll.wand_image())
+    for op in ("and", "ranked_and", "wand", "maxscore"):
+        a = idx.query_batch(op, queries, k=10)
+        b = idx.query_batch_mt(op, queries, k=10, threads=4, match_hash=(op == "and"))
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), op
+        if op == "and":
+            for i, q in enumerate(queries):
+                m = brute_and(coll, q).astype(np.uint64)
+                assert (m * (2 * np.arange(len(m), dtype=np.uint64) + 1)).sum(dtype=np.uint64) == b[4][i]
