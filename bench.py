@@ -167,6 +167,10 @@ def main():
                     if nqc:
                         cls_ms[c][0] += st.kernel_ms
                         cls_ms[c][1] += 1
+                        for g in pipe.class_groups(c):  # a class may run several kernels (one per exact list count): time each
+                            acc = grp_ms.setdefault((c, g["lists"], g["pipelined_stream"]), [0.0, 0])
+                            acc[0] += g["kernel_ms"]
+                            acc[1] += 1
         for i in range(first, first + n):
             if len(tickets) == args.depth:
                 reap()
@@ -176,11 +180,15 @@ def main():
         return results, cls_ms
 
     done_at = []
+    grp_ms = {}
     _, warm_ms = run_stream(0, args.warmup, True)
+    warm_grp_ms = grp_ms
     barrier()
     t0 = time.perf_counter()
     done_at = []
+    grp_ms = {}
     results, cls_ms = run_stream(args.warmup, args.steps, True)
+    timed_grp_ms = grp_ms
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sh.max_over_ranks(dist, elapsed)
@@ -200,10 +208,15 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     res_ms = [0.0] * NCLS
+    res_grp_ms = {}
     for _ in range(args.steps):
         batch.run()
         for c in range(NCLS):
             res_ms[c] += batch.class_stats(c)[0].kernel_ms
+            for g in batch.class_groups(c):
+                acc = res_grp_ms.setdefault((c, g["lists"], g["pipelined_stream"]), [0.0, 0])
+                acc[0] += g["kernel_ms"]
+                acc[1] += 1
     torch.cuda.synchronize()
     resident_s = (time.perf_counter() - t1) / args.steps
     count_r, topk_r, tlen_r, _ = batch.fetch()
@@ -265,6 +278,7 @@ def main():
     cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3 if n <= 16 else 4
     nterms = [len(set(q)) for q in queries]
     a_skip_q = [None] * NCLS  # reference-traversal bytes per query of each class (SURVEY.md §8(d) A_skip)
+    a_skip_g = {}             # ... and per launch group (class, lists, pipelined): (bytes of its queries, queries)
     cpu = None
     if not args.no_oracle:
         import oracle as o
@@ -281,6 +295,20 @@ def main():
         log("oracle profile pass (reference traversal A_skip): %.1fs" % (time.time() - t0))
         a_skip_q = [prof[c]["algorithmic_bytes"] / len(cls_q[c]) if prof[c] else None for c in range(NCLS)]
         out["a_skip_bytes_per_step"] = sum(pr["algorithmic_bytes"] for pr in prof if pr)
+        # a class may run several kernels (ranked_and: k_ranked_stream<n> per exact list count n + the class kernel for
+        # the rest): the reference traversal's bytes of exactly the queries each of them answers
+        for c in range(NCLS):
+            gs = batch.class_groups(c)
+            exact = set(g["lists"] for g in gs if g["pipelined_stream"])
+            for g in gs:
+                if g["pipelined_stream"]:
+                    gq = [q for q in cls_q[c] if len(set(q)) == g["lists"]]
+                else:
+                    gq = [q for q in cls_q[c] if len(set(q)) not in exact]
+                if len(gs) == 1:
+                    a_skip_g[(c, g["lists"], g["pipelined_stream"])] = (prof[c]["algorithmic_bytes"] if prof[c] else None, len(cls_q[c]))
+                else:
+                    a_skip_g[(c, g["lists"], g["pipelined_stream"])] = (oidx.query_batch(args.op, gq, k=10, profile=True)[4]["algorithmic_bytes"] if gq else 0, len(gq))
         # (2) parity spot check in the same run (count + top-k within 1e-5) on the sample the CPU baseline is timed on
         probe = queries[:64]
         t0 = time.time()
@@ -380,13 +408,38 @@ def main():
                           "postings_scored": int(cls_stats[c][0].postings_scored),
                           "docs_blocks_decoded": int(cls_stats[c][0].docs_blocks_decoded),
                           "freqs_blocks_decoded": int(cls_stats[c][0].freqs_blocks_decoded)})
-    # dominant kernel = the class kernel that moves the most algorithmic bytes per launch. (Launch durations are not a
-    # good criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched
-    # to the length of the step by the big ones.)
-    if any(x is not None for x in a_skip_q):
+    # ... and per KERNEL: a class stream runs its launch groups back to back, each timed with its own pair of hipEvents on
+    # that stream (ds2i_hip_pipeline_class_groups); rocprofv3 --kernel-trace --stats reports the same kernels by name
+    def group_kernel_name(c, lists, pipelined):
+        return "k_ranked_stream<%d>" % lists if pipelined else kernel_name(c)
+    per_kernel = []
+    for key, (tot, n) in sorted(timed_grp_ms.items()):
+        c, lists, pipelined = key
+        if not n:
+            continue
+        ms = tot / n
+        ab, nqg = a_skip_g.get(key, (None, None))
+        ra = res_grp_ms.get(key, [0.0, 0])
+        wa = warm_grp_ms.get(key, [0.0, 0])
+        n_all = wa[1] + n + ra[1]
+        per_kernel.append({"kernel": group_kernel_name(c, lists, pipelined), "class": c, "queries": nqg, "ms_per_launch": ms,
+                           "ms_alone": ra[0] / ra[1] if ra[1] else None,
+                           "ms_all_launches": (wa[0] + tot + ra[0]) / n_all if n_all else None, "launches_all": n_all, "launches_timed": n,
+                           "algorithmic_bytes": int(ab) if ab is not None else None,
+                           "achieved_gbs": (ab / (ms * 1e-3) / 1e9) if ab is not None and ms > 0 else None})
+    # dominant kernel = the kernel that moves the most algorithmic bytes per launch. (Launch durations are not a good
+    # criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched to the
+    # length of the step by the big ones.)
+    dom_k = None
+    if any(k["algorithmic_bytes"] for k in per_kernel):
+        dom_k = max(per_kernel, key=lambda k: k["algorithmic_bytes"] or 0)
+        dom = dom_k["class"]
+        dom_ms = dom_k["ms_per_launch"]
+        a_skip_dom = dom_k["algorithmic_bytes"]
+        src = "oracle-counted reference traversal (A_skip) of the queries this kernel answers, per launch"
+    elif any(x is not None for x in a_skip_q):
         dom = max(range(NCLS), key=lambda c: (a_skip_q[c] or 0) * cls_stats[c][1] if mean_ms[c] else -1)
         dom_ms = mean_ms[dom]
-    if a_skip_q[dom] is not None:
         a_skip_dom = a_skip_q[dom] * cls_stats[dom][1]
         src = "oracle-counted reference traversal (A_skip) per query x queries in the launch"
     else:  # oracle skipped: price the device's own (pruned) traversal with the same pricing
@@ -398,23 +451,30 @@ def main():
     # labelled as such; otherwise null.
     traffic = None
     traffic_src = None
-    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r03_traffic_%s_%s.json" % (wl, args.op))
+    traffic_step = None
+    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r04_traffic_%s_%s.json" % (wl, args.op))
     if os.path.exists(tj) and args.codec == "block_optpfor":
         tjson = json.load(open(tj))
-        if tjson.get("kernel_class") == dom:
-            traffic = tjson.get("hbm_bytes_per_launch")
-            traffic_src = "committed profile: " + os.path.relpath(tj, ROOT)
+        name = dom_k["kernel"] if dom_k else kernel_name(dom)
+        traffic = tjson.get("hbm_bytes_per_launch", {}).get(name)
+        traffic_step = tjson.get("hbm_bytes_per_step")
+        traffic_src = "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE pass of the same command, committed as " + os.path.relpath(tj, ROOT)
     # mean over EVERY launch of that kernel in this process (warm-up + timed + the prepared-batch re-runs): the figure a
     # `rocprofv3 --kernel-trace --stats` of this command reports as the kernel's average duration
-    n_all = warm_ms[dom][1] + cls_ms[dom][1] + 1 + args.steps
-    ms_all = (warm_ms[dom][0] + cls_ms[dom][0] + first_res_ms[dom] + res_ms[dom]) / n_all
+    if dom_k:
+        n_all, ms_all, ms_alone = dom_k["launches_all"], dom_k["ms_all_launches"], dom_k["ms_alone"]
+        n_timed, nq_dom, kname_dom = dom_k["launches_timed"], dom_k["queries"], dom_k["kernel"]
+    else:
+        n_all = warm_ms[dom][1] + cls_ms[dom][1] + 1 + args.steps
+        ms_all = (warm_ms[dom][0] + cls_ms[dom][0] + first_res_ms[dom] + res_ms[dom]) / n_all
+        ms_alone, n_timed, nq_dom, kname_dom = res_ms[dom] / args.steps, cls_ms[dom][1], cls_stats[dom][1], kernel_name(dom)
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                       "kernel": kernel_name(dom), "kernel_ms": dom_ms, "kernel_ms_alone": res_ms[dom] / args.steps,
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_per_step": traffic_step, "traffic_source": traffic_src,
+                       "kernel": kname_dom, "kernel_ms": dom_ms, "kernel_ms_alone": ms_alone,
                        "kernel_ms_all_launches": ms_all, "launches_all": n_all,
-                       "launches_timed": cls_ms[dom][1], "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
-                       "device_counted_bytes": int(cls_stats[dom][0].algorithmic_bytes),
-                       "queries_in_kernel": cls_stats[dom][1], "per_class": per_class}
+                       "launches_timed": n_timed, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
+                       "device_counted_bytes_of_class": int(cls_stats[dom][0].algorithmic_bytes),
+                       "queries_in_kernel": nq_dom, "per_kernel": per_kernel, "per_class": per_class}
     # the class kernels of a batch (and of the neighbouring batches) overlap, so one kernel's launch duration stretches
     # when another class is given more of the GPU; the whole step is the figure that cannot: every class's algorithmic
     # bytes over the wall time of a step

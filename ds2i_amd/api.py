@@ -38,6 +38,19 @@ class Stats(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class GroupStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("lists", C.c_uint32), ("units", C.c_uint32), ("queries", C.c_uint32), ("pipelined_stream", C.c_int)]
+
+
+def _class_groups(fn, handle, cls):
+    n = C.c_uint32()
+    _check(fn(handle, cls, None, 0, C.byref(n)))
+    arr = (GroupStats * max(1, n.value))()
+    _check(fn(handle, cls, arr, n.value, C.byref(n)))
+    return [{"kernel_ms": g.kernel_ms, "lists": g.lists, "units": g.units, "queries": g.queries, "pipelined_stream": bool(g.pipelined_stream)}
+            for g in arr[:n.value]]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("num_docs", C.c_uint32), ("num_terms", C.c_uint32), ("zipf_exp", C.c_double),
                 ("top_df_frac", C.c_double), ("min_len", C.c_uint32), ("clustered_every", C.c_uint32)]
@@ -75,6 +88,8 @@ def lib():
         L.ds2i_hip_batch_run.argtypes = [vp, C.POINTER(Stats)]
         L.ds2i_hip_batch_class_stats.argtypes = [vp, C.c_int, C.POINTER(Stats), u32p]
         L.ds2i_hip_batch_phase_cycles.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.ds2i_hip_batch_class_groups.argtypes = [vp, C.c_int, vp, C.c_uint32, u32p]
+        L.ds2i_hip_pipeline_class_groups.argtypes = [vp, C.c_int, vp, C.c_uint32, u32p]
         L.ds2i_hip_batch_fetch.argtypes = [vp, vp, vp, vp, vp]
         L.ds2i_hip_batch_match_total.argtypes = [vp, u64p]
         L.ds2i_hip_batch_fetch_matches.argtypes = [vp, vp, vp]
@@ -425,6 +440,10 @@ class Batch:
         _check(lib().ds2i_hip_batch_class_stats(self._h, cls, C.byref(st), C.byref(n)))
         return st, n.value
 
+    def class_groups(self, cls):
+        """launch groups of kernel class `cls` in the last run (ds2i_hip_batch_class_groups)"""
+        return _class_groups(lib().ds2i_hip_batch_class_groups, self._h, cls)
+
     def phase_cycles(self, cls):
         names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert", "stream", "prefetch", "floor", "unit",
                  "n_visit", "n_surv1", "n_surv2", "n_bdocs", "n_bfreqs", "n_heap", "n_liverounds")
@@ -498,6 +517,10 @@ class Pipeline:
         st, n = Stats(), C.c_uint32()
         _check(lib().ds2i_hip_pipeline_class_stats(self._h, cls, C.byref(st), C.byref(n)))
         return st, n.value
+
+    def class_groups(self, cls):
+        """launch groups of kernel class `cls` for the ticket collected last (ds2i_hip_pipeline_class_groups)"""
+        return _class_groups(lib().ds2i_hip_pipeline_class_groups, self._h, cls)
 
     def close(self):
         if self._h:

@@ -75,6 +75,9 @@ struct ds2i_hip_batch {
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
     int sset = 0;                 // which set of class streams this launch uses (alternates between consecutive launches)
+    // a class may run several kernels back to back (ranked_and: one per exact list count): hipEvents around each launch group
+    std::vector<hipEvent_t> ev_g[NCLS];
+    std::vector<float> grp_ms[NCLS];
     bool uploaded = false, launched = false;
     float cls_ms[NCLS] = {};
     Stats cls_stats[NCLS] = {};
@@ -317,7 +320,13 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         const bool rmw_cost = rmw_units; // (cost already counts the class's time per block)
         static const char* udr = std::getenv("DS2I_UNIT_DIV_RMW");
         static const double unit_div_rmw = udr && std::atof(udr) > 0 ? std::atof(udr) : 4.0;
-        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div));
+        // the 9-16-term class runs one wave per SIMD (23 KiB of LDS per wave) next to kernels that run five or six: a unit of it
+        // gets a fraction of the issue slots and its few, long units were the last thing every batch waited for (rocprofv3: 5.3 ms
+        // per launch for 18 queries, the longest kernel of the step) -- cut them DS2I_UNIT_DIV_MANY (4) times finer still
+        static const char* udm = std::getenv("DS2I_UNIT_DIV_MANY");
+        static const double unit_div_many = udm && std::atof(udm) > 0 ? std::atof(udm) : 4.0;
+        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
+                                                 (c == 3 && rmw_cost ? unit_div_many : 1.0));
         ++b->nqcls[c];
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);
@@ -747,8 +756,16 @@ int launch_batch(ds2i_hip_batch* b) {
             a.dyn_lists = sl.lists;
             // (the groups of a class run back to back on its stream: launching them beside each other on further streams
             // was tried -- with that many streams the hardware queues are oversubscribed and steps of 0.5-0.9 s appear)
+            const size_t gi = (size_t)(&sl - &b->sub[c].front());
+            while (b->ev_g[c].size() < 2 * (gi + 1)) {
+                hipEvent_t e = nullptr;
+                HIP_OK(hipEventCreate(&e));
+                b->ev_g[c].push_back(e);
+            }
+            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], s));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw) HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, s));
             else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
+            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], s));
         }
         HIP_OK(hipEventRecord(b->ev_c1[c], s));
         HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[c], 0));
@@ -796,6 +813,9 @@ int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     for (int c = 0; c < NCLS; ++c) {
         b->cls_ms[c] = 0.f;
         if (b->ncls[c]) HIP_OK(hipEventElapsedTime(&b->cls_ms[c], b->ev_c0[c], b->ev_c1[c]));
+        b->grp_ms[c].assign(b->ncls[c] ? b->sub[c].size() : 0, 0.f);
+        for (size_t g = 0; g < b->grp_ms[c].size() && 2 * g + 1 < b->ev_g[c].size(); ++g)
+            HIP_OK(hipEventElapsedTime(&b->grp_ms[c][g], b->ev_g[c][2 * g], b->ev_g[c][2 * g + 1]));
     }
     if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, b->d_stats.p, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     else std::memset(b->cls_stats, 0, sizeof(b->cls_stats));
@@ -873,6 +893,7 @@ void ds2i_batch_destroy(ds2i_hip_batch* b) {
             (void)hipEventDestroy(b->ev_c1[c]);
         }
     }
+    for (auto& v : b->ev_g) for (hipEvent_t e : v) (void)hipEventDestroy(e);
 
     delete b; // DevBuf / PinBuf members release their memory
 }
@@ -964,6 +985,31 @@ int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, 
     out->postings_scored = b->cls_stats[cls].postings_scored;
     out->rounds = b->cls_stats[cls].rounds;
     if (nqueries) *nqueries = b->nqcls[cls];
+    return DS2I_OK;
+}
+
+// the launch groups of class `cls` in the last run: hipEvent duration, list slots the group's kernel was launched with, units
+// (= workgroups), queries, and whether it ran the pipelined ranked_and kernel (k_ranked_stream<lists>, ranked_stream.hip)
+int ds2i_hip_batch_class_groups(ds2i_hip_batch* b, int cls, ds2i_hip_group_stats* out, uint32_t capacity, uint32_t* ngroups) {
+    if (!b || !ngroups || cls < 0 || cls >= NCLS) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_class_groups: bad argument");
+    const uint32_t n = b->ncls[cls] ? (uint32_t)b->sub[cls].size() : 0u;
+    *ngroups = n;
+    if (!out) return DS2I_OK;
+    for (uint32_t g = 0; g < n && g < capacity; ++g) {
+        const auto& sl = b->sub[cls][g];
+        out[g].kernel_ms = g < b->grp_ms[cls].size() ? b->grp_ms[cls][g] : 0.0;
+        out[g].lists = sl.lists;
+        out[g].units = sl.end - sl.begin;
+        out[g].pipelined_stream = sl.stream ? 1 : 0;
+        uint32_t nq = 0, last = 0xFFFFFFFFu; // distinct queries of the group (its units are grouped by query only loosely: count by marking)
+        std::vector<char> seen(b->nq ? b->nq : 1, 0);
+        for (uint32_t i = sl.begin; i < sl.end; ++i) {
+            const uint32_t q = b->union_stream ? 0u : b->units[b->order[cls][i]].q;
+            if (q < seen.size() && !seen[q]) { seen[q] = 1; ++nq; }
+        }
+        (void)last;
+        out[g].queries = nq;
+    }
     return DS2I_OK;
 }
 
@@ -1104,6 +1150,11 @@ int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_
 int ds2i_hip_pipeline_class_stats(ds2i_hip_pipeline* p, int cls, ds2i_hip_stats* out, uint32_t* nqueries) {
     if (!p || !p->last_waited) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_class_stats: no collected ticket");
     return ds2i_hip_batch_class_stats(p->last_waited, cls, out, nqueries);
+}
+
+int ds2i_hip_pipeline_class_groups(ds2i_hip_pipeline* p, int cls, ds2i_hip_group_stats* out, uint32_t capacity, uint32_t* ngroups) {
+    if (!p || !p->last_waited) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_class_groups: no collected ticket");
+    return ds2i_hip_batch_class_groups(p->last_waited, cls, out, capacity, ngroups);
 }
 
 int ds2i_hip_pipeline_set_instrumented(ds2i_hip_pipeline* p, int on) {

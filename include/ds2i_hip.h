@@ -167,6 +167,16 @@ int ds2i_hip_batch_block_profile(ds2i_hip_batch* b, uint32_t* counts, uint64_t c
 /* per kernel class of the last run (class 0: <=2 distinct terms, 1: 3..4, 2: 5..8, 3: 9..16 -- four
  * template instantiations with different LDS footprints -- 4: more than 16; launched concurrently on their own streams) */
 int ds2i_hip_batch_class_stats(ds2i_hip_batch* b, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
+/* A class may run more than one kernel: ranked_and on a block_optpfor index launches the pipelined stream kernel once per
+ * exact list count (2, 3, 4 terms) and the class kernel for what is left (one-term queries), back to back on the class
+ * stream. Per launch group of class cls in the last run: the hipEvent duration on that stream, the list slots the kernel
+ * was launched with, its units (= workgroups) and queries. out may be NULL to ask for *ngroups only. */
+typedef struct ds2i_hip_group_stats {
+    double kernel_ms;
+    uint32_t lists, units, queries;
+    int pipelined_stream; /* 1: k_ranked_stream<lists> (ranked_stream.hip); 0: the class kernel */
+} ds2i_hip_group_stats;
+int ds2i_hip_batch_class_groups(ds2i_hip_batch* b, int cls, ds2i_hip_group_stats* out, uint32_t capacity, uint32_t* ngroups);
 /* diagnostic build only (-DDS2I_PHASE_TIMING): per-phase shader-cycle sums {total, docs decode, freqs
  * decode, block search, membership, scoring, top-k} of class cls; zeros otherwise */
 int ds2i_hip_batch_phase_cycles(ds2i_hip_batch* b, int cls, uint64_t* out, int n);
@@ -193,6 +203,7 @@ int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_
                            uint32_t* out_topk_len, ds2i_hip_stats* stats);
 /* like ds2i_hip_batch_class_stats, for the ticket collected last */
 int ds2i_hip_pipeline_class_stats(ds2i_hip_pipeline* p, int cls, ds2i_hip_stats* out, uint32_t* nqueries);
+int ds2i_hip_pipeline_class_groups(ds2i_hip_pipeline* p, int cls, ds2i_hip_group_stats* out, uint32_t capacity, uint32_t* ngroups);
 /* default off: pipelines run the kernels compiled without counters */
 int ds2i_hip_pipeline_set_instrumented(ds2i_hip_pipeline* p, int on);
 void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p);
