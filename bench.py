@@ -35,6 +35,12 @@ WORKLOADS = {
                  seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf (metric config)"),
     # BASELINE.json configs[4] ("ClueWeb09-B-scale"): 50M docs, ~3.5 B postings; meant for --codec block_mixed and
     # --gpus 8 (every rank holds a replica and answers its own batch, so one rank alone runs the per-GPU work)
+    # robustness workload (no BASELINE config): the GOV2-scale collection with CORRELATED terms -- 256 topics, a term 64 times
+    # as likely in the documents of its home topic, 25 % of the multi-term queries drawn from one topic. The independent
+    # lists of "gov2" are the easy case for range-table pruning; this says how much of the rate hangs on that
+    "gov2c": dict(num_docs=25_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
+                  topics=256, topic_boost=64, same_topic_pct=25,
+                  seed=0xD5210004, label="synthetic GOV2-scale 25M-doc Zipf, correlated terms (256 topics x64, 25% same-topic queries)"),
     "cw09": dict(num_docs=50_000_000, num_terms=32768, zipf_exp=0.6, top_df_frac=0.25, min_len=4096, clustered_every=4,
                  seed=0xD5210005, label="synthetic ClueWeb09-B-scale 50M-doc Zipf (configs[4])"),
 }
@@ -53,7 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mixed-policy", default="optimised", choices=["optimised", "fixed"],
                     help="block_mixed only: ds2i_hybrid optimiser (default) or the fixed per-block size policy")
-    ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2", "cw09"])
+    ap.add_argument("--workload", default=os.environ.get("DS2I_BENCH_WORKLOAD", "auto"), choices=["auto", "c2", "gov2", "gov2c", "cw09"])
     ap.add_argument("--op", default="ranked_and")
     ap.add_argument("--codec", default="block_optpfor")
     ap.add_argument("--batch", type=int, default=4096)
@@ -101,7 +107,8 @@ def main():
         wl = "gov2" if sh.broadcast_int(dist, 1 if wl == "gov2" else 0) else "c2"
     W = WORKLOADS[wl]
     p = d.SynthParams(seed=W["seed"], num_docs=W["num_docs"], num_terms=W["num_terms"], zipf_exp=W["zipf_exp"],
-                      top_df_frac=W["top_df_frac"], min_len=W["min_len"], clustered_every=W["clustered_every"])
+                      top_df_frac=W["top_df_frac"], min_len=W["min_len"], clustered_every=W["clustered_every"],
+                      topics=W.get("topics", 0), topic_boost=W.get("topic_boost", 0))
     import tempfile
     need = 4 << 30  # rank 0 hands the index image (~3 GB at GOV2 scale) to the other ranks through a file
     shm = tempfile.gettempdir()
@@ -136,7 +143,11 @@ def main():
     #           (sharding.query_slice) and rank 0 gathers the results (sharding.gather_concat)
     nbatches = args.steps + args.warmup
     strong = args.scaling == "strong"
-    all_queries = [d.synth_queries(0x51E21 + (0 if strong else 1000003 * rank) + 7919 * i, p.num_terms, args.batch) for i in range(nbatches)]
+    qseed = lambda i: 0x51E21 + (0 if strong else 1000003 * rank) + 7919 * i
+    if W.get("topics"):
+        all_queries = [d.synth_queries_topical(p, qseed(i), args.batch, W["same_topic_pct"]) for i in range(nbatches)]
+    else:
+        all_queries = [d.synth_queries(qseed(i), p.num_terms, args.batch) for i in range(nbatches)]
     if strong:
         lo_, hi_ = sh.query_slice(args.batch, rank, world)
         my_queries = [q[lo_:hi_] for q in all_queries]

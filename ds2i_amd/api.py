@@ -53,7 +53,8 @@ def _class_groups(fn, handle, cls):
 
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("num_docs", C.c_uint32), ("num_terms", C.c_uint32), ("zipf_exp", C.c_double),
-                ("top_df_frac", C.c_double), ("min_len", C.c_uint32), ("clustered_every", C.c_uint32)]
+                ("top_df_frac", C.c_double), ("min_len", C.c_uint32), ("clustered_every", C.c_uint32),
+                ("topics", C.c_uint32), ("topic_boost", C.c_uint32)]  # correlated terms (0, 0: independent lists)
 
 
 def library_path():
@@ -151,6 +152,7 @@ def lib():
         L.ds2i_synth_list.argtypes = [C.POINTER(SynthParams), C.c_uint32, vp, vp, C.c_uint64, u64p]
         L.ds2i_synth_doc_sizes.argtypes = [C.POINTER(SynthParams), vp]
         L.ds2i_synth_queries.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]
+        L.ds2i_synth_queries_topical.argtypes = [C.POINTER(SynthParams), C.c_uint64, C.c_uint32, C.c_uint32, vp, vp]
         L.ds2i_synth_build.argtypes = [C.POINTER(SynthParams), C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), u64p]
         _lib = L
     return _lib
@@ -374,6 +376,15 @@ def synth_queries(seed, num_terms, nq):
     t = np.empty(11 * nq + 1, dtype=np.uint32)
     o = np.empty(nq + 1, dtype=np.uint32)
     _check(lib().ds2i_synth_queries(seed, num_terms, nq, _ptr(t), _ptr(o)))
+    return [t[o[i]:o[i + 1]].tolist() for i in range(nq)]
+
+
+def synth_queries_topical(p, seed, nq, same_topic_pct=25):
+    """synth_queries over a correlated collection (p.topics > 1): same_topic_pct percent of the multi-term queries take
+    all their terms from one topic"""
+    t = np.empty(11 * nq + 1, dtype=np.uint32)
+    o = np.empty(nq + 1, dtype=np.uint32)
+    _check(lib().ds2i_synth_queries_topical(C.byref(p), seed, nq, same_topic_pct, _ptr(t), _ptr(o)))
     return [t[o[i]:o[i + 1]].tolist() for i in range(nq)]
 
 

@@ -459,7 +459,10 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
             int pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
             if (flat) pri = (lo_pri + hi_pri) / 2;
             HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, pri));
-            if (c < 3) HIP_OK(hipStreamCreateWithPriority(&x->stream_b[c], hipStreamNonBlocking, pri));
+            // (the second set exists only when asked for: every stream is a hardware queue, and two replicas on one device --
+            // or anything else that shares the GPU -- push the total past what the queues serve without time-slicing)
+            static const char* e_sets = std::getenv("DS2I_STREAM_SETS");
+            if (c < 3 && e_sets && std::atoi(e_sets) > 0) HIP_OK(hipStreamCreateWithPriority(&x->stream_b[c], hipStreamNonBlocking, pri));
         }
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));

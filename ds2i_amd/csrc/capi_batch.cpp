@@ -687,7 +687,7 @@ int launch_batch(ds2i_hip_batch* b) {
     static const bool one_set = !(e_sets && std::atoi(e_sets) > 0);
     b->sset = one_set ? 0 : idx->launch_parity;
     idx->launch_parity ^= 1;
-    auto cls_stream = [&](int c) { return (b->sset && c < 3) ? idx->stream_b[c] : idx->stream[c]; };
+    auto cls_stream = [&](int c) { return (b->sset && c < 3 && idx->stream_b[c]) ? idx->stream_b[c] : idx->stream[c]; };
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
     for (int c = 0; c < NCLS; ++c) {
         if (!b->ncls[c]) continue;

@@ -33,6 +33,7 @@ synth_params to_params(const ds2i_synth_params* p) {
     synth_params s;
     s.seed = p->seed; s.num_docs = p->num_docs; s.num_terms = p->num_terms; s.zipf_exp = p->zipf_exp;
     s.top_df_frac = p->top_df_frac; s.min_len = p->min_len; s.clustered_every = p->clustered_every;
+    s.topics = p->topics; s.topic_boost = p->topic_boost;
     return s;
 }
 } // namespace
@@ -241,6 +242,17 @@ int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t*
     DS2I_TRY
     std::vector<uint32_t> t, o;
     synth_queries(seed, num_terms, nq, t, o);
+    std::memcpy(terms, t.data(), 4 * t.size());
+    std::memcpy(offsets, o.data(), 4 * o.size());
+    return 0;
+    DS2I_CATCH
+}
+
+int ds2i_synth_queries_topical(const ds2i_synth_params* pp, uint64_t seed, uint32_t nq, uint32_t same_topic_pct, uint32_t* terms, uint32_t* offsets) {
+    if (!pp || !terms || !offsets || !pp->num_terms) return ds2i_set_error(-1, "ds2i_synth_queries_topical: bad argument");
+    DS2I_TRY
+    std::vector<uint32_t> t, o;
+    synth_queries_topical(to_params(pp), seed, nq, same_topic_pct, t, o);
     std::memcpy(terms, t.data(), 4 * t.size());
     std::memcpy(offsets, o.data(), 4 * o.size());
     return 0;

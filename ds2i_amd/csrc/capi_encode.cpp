@@ -184,6 +184,7 @@ extern "C" int ds2i_hip_synth_encode(int device, const ds2i_synth_params* pp, in
         synth_params p;
         p.seed = pp->seed; p.num_docs = pp->num_docs; p.num_terms = pp->num_terms; p.zipf_exp = pp->zipf_exp;
         p.top_df_frac = pp->top_df_frac; p.min_len = pp->min_len; p.clustered_every = pp->clustered_every;
+        p.topics = pp->topics; p.topic_boost = pp->topic_boost;
         if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint32_t> sizes;

@@ -12,14 +12,32 @@
 namespace ds2i_host {
 
 struct synth_params {
-    uint64_t seed;
+    uint64_t seed = 0;
     uint32_t num_docs;
     uint32_t num_terms;
     double zipf_exp;       // list length of rank r = max(min_len, top_df_frac*N * r^-zipf_exp)
     double top_df_frac;
     uint32_t min_len;
     uint32_t clustered_every; // every k-th list alternates 8x / (1/8)x density segments; 0 = never
+    // Correlated terms (0 = lists are independent thinnings of the doc-id space): documents come in runs of 4096 doc-ids,
+    // each run belongs to one of `topics` topics, every term has a home topic, and a term is `topic_boost` times as likely
+    // in a document of its home topic as its collection-wide rate says (the other documents are thinned so that the list
+    // length stays what the Zipf law gives). Two terms of one topic then co-occur far above chance:
+    // P(d in t2 | d in t1) ~ (boost^2 / topics) x df2 / N for boost << topics.
+    uint32_t topics = 0;
+    uint32_t topic_boost = 0;
 };
+
+inline uint32_t synth_home_topic(synth_params const& p, uint32_t term) {
+    uint64_t x = p.seed ^ (0xA24BAED4963EE407ull * (uint64_t(term) + 1));
+    x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29;
+    return (uint32_t)(x % p.topics);
+}
+inline uint32_t synth_run_topic(synth_params const& p, uint64_t run) {
+    uint64_t x = (p.seed * 0x2545F4914F6CDD1Dull) ^ (0xD1342543DE82EF95ull * (run + 1));
+    x ^= x >> 32; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 30;
+    return (uint32_t)(x % p.topics);
+}
 
 struct xoshiro256ss {
     uint64_t s[4];
@@ -56,7 +74,12 @@ inline uint64_t synth_list(synth_params const& p, uint32_t term, std::vector<uin
     const uint64_t target = synth_target_len(p, term);
     xoshiro256ss rng(p.seed ^ (0xD6E8FEB86659FD93ull * (uint64_t(term) + 1)));
     const double q0 = double(target) / double(N);
-    const bool clustered = p.clustered_every && (term % p.clustered_every) == p.clustered_every - 1;
+    const bool topical = p.topics > 1 && p.topic_boost > 1;
+    const bool clustered = !topical && p.clustered_every && (term % p.clustered_every) == p.clustered_every - 1;
+    const uint32_t home = topical ? synth_home_topic(p, term) : 0;
+    const double f_in = topical ? 1.0 / double(p.topics) : 0.0;
+    const double q_in = topical ? std::min(0.9, q0 * double(p.topic_boost)) : 0.0;
+    const double q_out = topical ? std::max(0.0, (q0 - f_in * q_in) / (1.0 - f_in)) : 0.0;
     docs.reserve(target + target / 8 + 16);
     freqs.reserve(target + target / 8 + 16);
     uint64_t pos = 0; // next candidate docid
@@ -64,7 +87,12 @@ inline uint64_t synth_list(synth_params const& p, uint32_t term, std::vector<uin
     while (pos < N) {
         uint64_t seg_end = N;
         double q = q0;
-        if (clustered) {
+        if (topical) { // runs of 4096 doc-ids: the term's home topic at q_in, every other run at q_out
+            const uint64_t run = pos >> 12;
+            seg_end = std::min<uint64_t>(N, (run + 1) << 12);
+            q = synth_run_topic(p, run) == home ? q_in : q_out;
+            if (q <= 0.0) { pos = seg_end; continue; }
+        } else if (clustered) {
             uint64_t seg = uint64_t(1) << (12 + (rng.next() % 5));
             seg_end = std::min<uint64_t>(N, pos + seg);
             q = dense ? std::min(0.95, q0 * 8.0) : q0 / 8.0;
@@ -141,6 +169,28 @@ inline void synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, std::v
         }
         if (len > 1 && (rng.next() % 100) == 0) terms.back() = terms[begin];
         offsets.push_back((uint32_t)terms.size());
+    }
+}
+
+// The same query log with `same_topic_pct` percent of the multi-term queries drawn from ONE topic (all terms share the home
+// topic of the first): the queries whose lists are correlated.
+inline void synth_queries_topical(synth_params const& p, uint64_t seed, uint32_t nq, uint32_t same_topic_pct, std::vector<uint32_t>& terms,
+                                  std::vector<uint32_t>& offsets) {
+    synth_queries(seed, p.num_terms, nq, terms, offsets);
+    if (p.topics < 2) return;
+    xoshiro256ss rng(seed ^ 0x70C1CA1ull);
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t b = offsets[q], e = offsets[q + 1];
+        if (e - b < 2 || rng.next() % 100 >= same_topic_pct) continue;
+        const uint32_t home = synth_home_topic(p, terms[b]);
+        for (uint32_t i = b + 1; i < e; ++i) { // same rank distribution (log-uniform), restricted to the topic
+            for (int tries = 0; tries < 100000; ++tries) {
+                const double r = std::pow(double(p.num_terms), 1.0 - rng.unit());
+                uint32_t t = (uint32_t)r;
+                t = t < 1 ? 1 : t > p.num_terms ? p.num_terms : t;
+                if (synth_home_topic(p, t - 1) == home) { terms[i] = t - 1; break; }
+            }
+        }
     }
 }
 

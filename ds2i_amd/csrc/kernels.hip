@@ -1992,6 +1992,79 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
             al0 = al0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
             al1 = al1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
             if (!(ballot(al0) | ballot(al1))) continue; // nobody of this block can enter: its freqs stay undecoded
+            if (a.rmh) {
+                // ---- membership hints (BatchArgs::rmh; block_optpfor indexes): a non-zero byte says SOME posting of list i lies in
+                // the candidate's range; where the range holds exactly one posting the hint says at which offset. A candidate
+                // elsewhere in that range is not in list i: its byte is cleared -- no lookup there (the most expensive thing this
+                // kernel does: a block search and a block decode per list), nothing added to its bound by that list, and for an
+                // exclusion list the verdict "not theirs". One more byte per candidate and list, for the survivors of the test above.
+                const long long hd = (long long)(a.rmh - a.rmw);
+                auto clear_byte = [&](uint32_t* pk, uint32_t i) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k2 = 0; k2 < NW; ++k2)
+                        if ((i >> 2) == (uint32_t)k2) pk[k2] &= ~(255u << (8u * (i & 3u)));
+                };
+                auto hint_chunk = [&](auto i0c) __attribute__((always_inline)) { // lists i0 .. i0+3: their loads first, then the tests
+                    uint32_t hv0[4], hv1[4];
+                    auto ld = [&](auto kc) __attribute__((always_inline)) {
+                        constexpr uint32_t k2 = decltype(kc)::value;
+                        const uint32_t i = (uint32_t)i0c + k2;
+                        hv0[k2] = hv1[k2] = 255u;
+                        if (i < nt) {
+                            const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
+                            const uint32_t sh = cx.m(i, M_RSHIFT);
+                            if (al0 && byte_of(pk0, i) != 0u) hv0[k2] = (uint32_t)ht[c0 >> sh];
+                            if (al1 && byte_of(pk1, i) != 0u) hv1[k2] = (uint32_t)ht[c1 >> sh];
+                        }
+                    };
+                    auto ts = [&](auto kc) __attribute__((always_inline)) {
+                        constexpr uint32_t k2 = decltype(kc)::value;
+                        const uint32_t i = (uint32_t)i0c + k2;
+                        if (i < nt) {
+                            const uint32_t sh = cx.m(i, M_RSHIFT);
+                            if (!((hv0[k2] == 255u) | (hv0[k2] == rmh_code(c0, sh)))) clear_byte(pk0, i);
+                            if (!((hv1[k2] == 255u) | (hv1[k2] == rmh_code(c1, sh)))) clear_byte(pk1, i);
+                        }
+                    };
+                    if constexpr (REG) { // (register-resident list state: slots must be compile-time constants)
+                        constexpr uint32_t I0 = decltype(i0c)::value;
+                        auto ld_c = [&](auto kc) __attribute__((always_inline)) { ld(kc); return true; };
+                        (void)ld_c;
+                        auto one_ld = [&](auto ic) __attribute__((always_inline)) {
+                            constexpr uint32_t i = decltype(ic)::value;
+                            const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
+                            const uint32_t sh = cx.m(i, M_RSHIFT);
+                            hv0[i - I0] = (al0 && byte_of(pk0, i) != 0u) ? (uint32_t)ht[c0 >> sh] : 255u;
+                            hv1[i - I0] = (al1 && byte_of(pk1, i) != 0u) ? (uint32_t)ht[c1 >> sh] : 255u;
+                            return true;
+                        };
+                        static_list_loop<I0, (I0 + 4 < TMAX ? I0 + 4 : TMAX)>(nt, one_ld);
+                        auto one_ts = [&](auto ic) __attribute__((always_inline)) {
+                            constexpr uint32_t i = decltype(ic)::value;
+                            const uint32_t sh = cx.m(i, M_RSHIFT);
+                            if (!((hv0[i - I0] == 255u) | (hv0[i - I0] == rmh_code(c0, sh)))) clear_byte(pk0, i);
+                            if (!((hv1[i - I0] == 255u) | (hv1[i - I0] == rmh_code(c1, sh)))) clear_byte(pk1, i);
+                            return true;
+                        };
+                        static_list_loop<I0, (I0 + 4 < TMAX ? I0 + 4 : TMAX)>(nt, one_ts);
+                    } else {
+                        ld(std::integral_constant<uint32_t, 0>{}); ld(std::integral_constant<uint32_t, 1>{});
+                        ld(std::integral_constant<uint32_t, 2>{}); ld(std::integral_constant<uint32_t, 3>{});
+                        ts(std::integral_constant<uint32_t, 0>{}); ts(std::integral_constant<uint32_t, 1>{});
+                        ts(std::integral_constant<uint32_t, 2>{}); ts(std::integral_constant<uint32_t, 3>{});
+                    }
+                };
+                if constexpr (REG) {
+                    hint_chunk(std::integral_constant<uint32_t, 1>{});
+                } else {
+                    for (uint32_t i0 = 1; i0 < nt; i0 += 4) hint_chunk(i0);
+                }
+                r0 = rest_of(pk0, 0);
+                r1 = rest_of(pk1, 0);
+                al0 = al0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
+                al1 = al1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+                if (!(ballot(al0) | ballot(al1))) continue;
+            }
             // ---- the driver's own term score: freq-only bound first, then the norm_len gather
             cx.decode_freqs(0);
             const uint32_t f0 = L.freqs[0][lane], f1 = L.freqs[0][lane + 64];

@@ -27,6 +27,10 @@ typedef struct ds2i_synth_params {
     double top_df_frac;
     uint32_t min_len;
     uint32_t clustered_every; /* every k-th list alternates dense/sparse segments; 0 = never */
+    /* correlated terms (both 0: independent lists): documents come in runs of 4096 doc-ids of one of `topics` topics, every
+     * term has a home topic and is topic_boost times as likely in its documents (list lengths unchanged) */
+    uint32_t topics;
+    uint32_t topic_boost;
 } ds2i_synth_params;
 
 const uint8_t* ds2i_blob_data(const ds2i_blob* b);
@@ -113,6 +117,8 @@ int ds2i_synth_list(const ds2i_synth_params* p, uint32_t term, uint32_t* docs, u
 int ds2i_synth_doc_sizes(const ds2i_synth_params* p, uint32_t* sizes);
 /* query log: terms gets at most 11*nq entries, offsets nq+1 */
 int ds2i_synth_queries(uint64_t seed, uint32_t num_terms, uint32_t nq, uint32_t* terms, uint32_t* offsets);
+/* the same log with same_topic_pct percent of the multi-term queries drawn from one topic of a correlated collection */
+int ds2i_synth_queries_topical(const ds2i_synth_params* p, uint64_t seed, uint32_t nq, uint32_t same_topic_pct, uint32_t* terms, uint32_t* offsets);
 /* generate + encode the whole collection with `threads` host threads: index image + wand image */
 int ds2i_synth_build(const ds2i_synth_params* p, int codec, int threads, ds2i_blob** index_image,
                      ds2i_blob** wand_image, uint64_t* total_postings);

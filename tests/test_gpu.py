@@ -994,14 +994,18 @@ def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
 @pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_BMW_PRUNE=1", "DS2I_NO_SKIPTAB=1", "DS2I_DYN_GROUP=0", "DS2I_DYN_GROUP=1",
                                   "DS2I_NO_RMW=1", "DS2I_NO_RMW_USE=1", "DS2I_RMW_G=1", "DS2I_NO_BITMAPS=1", "DS2I_NO_BITMAP_USE=1",
                                   "DS2I_NO_UNION_STREAM=1", "DS2I_UNIT_FACTOR=64", "DS2I_NO_TOPK_STREAM=1", "DS2I_UT_BLOCKS=1",
-                                  "DS2I_SEED_STREAM=1", "DS2I_UT_FIRST=0", "DS2I_UT_FIRST=3"])
+                                  "DS2I_SEED_STREAM=1", "DS2I_UT_FIRST=0", "DS2I_UT_FIRST=3",
+                                  "DS2I_NO_RANKED_STREAM=1", "DS2I_NO_RMH=1", "DS2I_NO_RMH_USE=1", "DS2I_STREAM_SETS=1", "DS2I_UNIT_CAP=8",
+                                  "DS2I_LOOKUP_WEIGHT=0", "DS2I_UNIT_DIV_MANY=1"])
 def test_alternative_paths_give_the_same_results(built_lib, knob):
     """The library reads its A/B knobs once per process, so each alternative path -- no block-max table, table present but
     unused, no interleaved skip table (= no list-0 stream), union kernels without / with exact dynamic-LDS groups, no
     range tables / tables unused / coarse tables, no dense-list bitmaps / bitmaps unused, or_query through the windowed
     kernel, very fine work units (many parts per query), wand / maxscore / ranked_or through the windowed kernel, their streams
     cut to one block per unit, seeded by the ranked_and sub-query pass, and gathering the range-table bytes in one trip / with
-    three optional lists in the first of two -- is driven through one fuzz collection (every codec, k,
+    three optional lists in the first of two, ranked_and through the class kernels instead of the pipelined stream kernel,
+    no membership hints / hints unused, two alternating sets of class streams, units capped at 8 blocks, the planner's
+    lookup pricing off, the 9-16-term class not cut finer -- is driven through one fuzz collection (every codec, k,
     operator; oracle-checked) in a process of its own."""
     import os, subprocess, sys
     env = dict(os.environ)
