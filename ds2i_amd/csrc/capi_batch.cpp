@@ -10,7 +10,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <limits>
 #include <memory>
 
@@ -300,7 +305,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     b->voff.assign(1, 0);
     b->vinfo.clear();
     static const char* utb = std::getenv("DS2I_UT_BLOCKS");
-    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 96u; // blocks of the driving list per unit
+    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 160u; // blocks of the driving list per unit (re-measured with the membership hints: 96: 335 k, 128-256: 345-352 k, 384: 335 k queries/s)
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
         u.q = q;
@@ -406,7 +411,11 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 b->vinfo.push_back(e);
                 b->vinfo.push_back(sbits);
                 const uint32_t nbe = std::max(1u, qnbs[begin + ord[e]]);
-                const uint32_t parts_e = (nbe + ut_blocks - 1) / ut_blocks, per = (nbe + parts_e - 1) / parts_e;
+                // (the 9-16-term class runs one wave per SIMD: its units are cut DS2I_UT_DIV_MANY times finer, for more of them at once)
+                static const char* utm = std::getenv("DS2I_UT_DIV_MANY");
+                static const uint32_t ut_div_many = utm && std::atoi(utm) > 0 ? (uint32_t)std::atoi(utm) : 4u;
+                const uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / ut_div_many) : ut_blocks;
+                const uint32_t parts_e = (nbe + utb_c - 1) / utb_c, per = (nbe + parts_e - 1) / parts_e;
                 for (uint32_t lo = 0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
                     add_unit(c, vq, lo, std::min(nbe, lo + per), 0, (double)(nt - e) * 1.0e7 + (double)(std::min(nbe, lo + per) - lo));
             }
@@ -905,7 +914,69 @@ struct ds2i_hip_pipeline {
     std::vector<char> busy;
     uint64_t next_ticket = 0;
     ds2i_hip_batch* last_waited = nullptr;
+    // The host half of a batch (query normalisation, BM25 query weights, work-unit planning: ~3 ms for 4096 queries at GOV2
+    // scale, ~1 ms at configs[1] scale where the kernels take 1.3 ms) runs on a worker thread OF THE LIBRARY, in ticket
+    // order: submit() copies the query arrays into the slot and returns; the caller's own per-batch work (reading the
+    // query log, collecting results) then overlaps with the planning of the batch it has just handed over, and wait()
+    // blocks first on that batch's launch, then on the device. OFF by default (DS2I_PLAN_THREAD=1 turns it on): measured
+    // on the bench loop it LOSES -- end-to-end / kernel-resident 0.80 -> 0.70 at configs[1] scale, 1.01 -> 0.97 at GOV2
+    // scale: the loop's host time per batch is the planning itself, which was already hidden behind the device as long as
+    // one batch is in flight, and the hand-over adds a wake-up and a copy of the query arrays to every batch. What
+    // would help a host-bound loop is planning one batch on several threads, not planning it elsewhere.
+    struct Job {
+        int op = 0;
+        uint32_t k = 0, nq = 0;
+        std::vector<uint32_t> terms, offs;
+        int state = 0; // 0 free, 1 queued, 2 launched, 3 failed
+        int rc = 0;
+        std::string error;
+    };
+    std::vector<Job> jobs;
+    std::deque<size_t> queue;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::thread worker;
+    bool stop = false, threaded = false;
 };
+
+namespace {
+// plan + upload + launch of one slot (caller's thread or the pipeline's worker)
+int pipeline_launch(ds2i_hip_pipeline* p, size_t slot, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq) {
+    HIP_OK(hipSetDevice(p->idx->device));
+    ds2i_hip_batch* b = p->slots[slot];
+    int rc = plan_batch(b, op, k, terms, offs, nq, 0);
+    if (rc) return rc; // (nothing enqueued yet)
+    rc = upload_batch(b);
+    if (!rc) rc = launch_batch(b);
+    if (rc) {
+        const std::string keep = ds2i_get_error();
+        (void)hipDeviceSynchronize(); // nothing of the slot is still running when the error is reported
+        return ds2i_set_error(rc, keep.c_str());
+    }
+    return DS2I_OK;
+}
+void pipeline_worker(ds2i_hip_pipeline* p) {
+    for (;;) {
+        size_t slot;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+            if (p->queue.empty()) return; // (stop, and nothing left to launch)
+            slot = p->queue.front();
+            p->queue.pop_front();
+        }
+        ds2i_hip_pipeline::Job& j = p->jobs[slot];
+        const int rc = pipeline_launch(p, slot, j.op, j.k, j.terms.data(), j.offs.data(), j.nq);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            j.rc = rc;
+            if (rc) j.error = ds2i_get_error(); // (thread-local in this thread: handed to the thread that waits)
+            j.state = rc ? 3 : 2;
+        }
+        p->cv_done.notify_all();
+    }
+}
+} // namespace
 
 extern "C" {
 
@@ -1102,12 +1173,24 @@ int ds2i_hip_pipeline_create(ds2i_hip_index* idx, uint32_t depth, ds2i_hip_pipel
     }
     p->slot_ticket.assign(depth, 0);
     p->busy.assign(depth, 0);
+    p->jobs.resize(depth);
+    const char* pt = std::getenv("DS2I_PLAN_THREAD");
+    p->threaded = pt && std::atoi(pt) > 0;
+    if (p->threaded) p->worker = std::thread(pipeline_worker, p);
     *out = p;
     return DS2I_OK;
 }
 
 void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p) {
     if (!p) return;
+    if (p->threaded) {
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->stop = true;
+        }
+        p->cv_job.notify_all();
+        if (p->worker.joinable()) p->worker.join(); // (finishes the launches already queued: their slots are drained below)
+    }
     for (auto* b : p->slots) ds2i_batch_destroy(b);
     delete p;
 }
@@ -1117,13 +1200,39 @@ int ds2i_hip_pipeline_submit(ds2i_hip_pipeline* p, int op, uint32_t k, const uin
     if (!p || !ticket) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_submit: null argument");
     const size_t slot = (size_t)(p->next_ticket % p->slots.size());
     if (p->busy[slot]) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_pipeline_submit: all slots in flight; wait for the oldest ticket first");
-    HIP_OK(hipSetDevice(p->idx->device));
-    ds2i_hip_batch* b = p->slots[slot];
-    int rc = plan_batch(b, op, k, terms, query_offsets, nq, 0);
-    if (rc) return rc; // (nothing enqueued yet)
-    rc = upload_batch(b);
-    if (!rc) rc = launch_batch(b);
-    if (rc) return drain_after_failure(b, rc); // the slot stays free, and nothing of it is still running
+    if (!p->threaded) {
+        int rc = pipeline_launch(p, slot, op, k, terms, query_offsets, nq);
+        if (rc) return rc; // the slot stays free
+    } else {
+        // what the caller can be told at once is checked at once (the same checks plan_batch makes, in the same order);
+        // device-side failures of the launch surface in wait()
+        if (!query_offsets || (!terms && nq && query_offsets[nq] > 0)) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
+        const int base_op = op & 0xFF;
+        if (base_op < DS2I_OP_AND || base_op > DS2I_OP_RANKED_OR || (op & ~(0xFF | DS2I_OP_REFERENCE_ORDER | DS2I_OP_NO_COUNTERS)))
+            return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
+        const bool ranked = base_op >= DS2I_OP_RANKED_AND;
+        if (ranked && !p->idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
+        if (ranked && (k == 0 || k > DS2I_HIP_MAX_K_LONG)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1, DS2I_HIP_MAX_K_LONG]");
+        for (uint32_t q = 0; q < nq; ++q)
+            if (query_offsets[q + 1] < query_offsets[q]) return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
+        const uint32_t nterms = nq ? query_offsets[nq] : 0;
+        for (uint32_t i = nq ? query_offsets[0] : 0; i < nterms; ++i)
+            if (terms[i] >= p->idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+        ds2i_hip_pipeline::Job& j = p->jobs[slot];
+        j.op = op;
+        j.k = k;
+        j.nq = nq;
+        j.offs.assign(query_offsets, query_offsets + nq + 1);
+        j.terms.assign(terms, terms + nterms);
+        if (j.terms.empty()) j.terms.push_back(0);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            j.state = 1;
+            j.rc = 0;
+            p->queue.push_back(slot);
+        }
+        p->cv_job.notify_one();
+    }
     p->busy[slot] = 1;
     p->slot_ticket[slot] = p->next_ticket;
     *ticket = p->next_ticket++;
@@ -1136,9 +1245,20 @@ int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_
     const size_t slot = (size_t)(ticket % p->slots.size());
     if (!p->busy[slot] || p->slot_ticket[slot] != ticket)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_wait: unknown or already collected ticket");
+    if (p->threaded) { // first the launch (planning + upload + kernels enqueued) ...
+        std::unique_lock<std::mutex> lk(p->mu);
+        ds2i_hip_pipeline::Job& j = p->jobs[slot];
+        p->cv_done.wait(lk, [&] { return j.state != 1; });
+        if (j.state == 3) {
+            p->busy[slot] = 0;
+            j.state = 0;
+            return ds2i_set_error(j.rc, j.error.c_str());
+        }
+        j.state = 0;
+    }
     HIP_OK(hipSetDevice(p->idx->device));
     ds2i_hip_batch* b = p->slots[slot];
-    int rc = finish_batch(b, stats);
+    int rc = finish_batch(b, stats); // ... then the device
     p->busy[slot] = 0;
     if (rc) return rc;
     p->last_waited = b;
