@@ -441,9 +441,15 @@ def main():
     # dominant kernel = the kernel that moves the most algorithmic bytes per launch. (Launch durations are not a good
     # criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched to the
     # length of the step by the big ones.)
+    # dominant kernel = the one that takes the most device time per batch among the kernels that carry a real share (>= 10 %) of
+    # the batch's algorithmic bytes. (Bytes alone would pick the one-term kernel on some workloads: it owns a third of the
+    # reference traversal's bytes and prunes nearly all of them in half a millisecond; time alone would pick a many-list
+    # class whose few units are stretched by sharing the GPU.)
     dom_k = None
     if any(k["algorithmic_bytes"] for k in per_kernel):
-        dom_k = max(per_kernel, key=lambda k: k["algorithmic_bytes"] or 0)
+        tot_b = sum(k["algorithmic_bytes"] or 0 for k in per_kernel)
+        cand = [k for k in per_kernel if (k["algorithmic_bytes"] or 0) >= 0.1 * tot_b] or per_kernel
+        dom_k = max(cand, key=lambda k: k["ms_per_launch"])
         dom = dom_k["class"]
         dom_ms = dom_k["ms_per_launch"]
         a_skip_dom = dom_k["algorithmic_bytes"]

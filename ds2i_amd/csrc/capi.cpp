@@ -203,9 +203,8 @@ int build_block_max_weights(ds2i_hip_index* x) {
         }
     }
     x->rmw_bytes = bytes;
-    // membership hints (abi_structs.hpp, BatchArgs::rmh): the pipelined ranked_and kernel of block_optpfor indexes reads
-    // them; a parallel buffer with the tables' offsets (only the level-1 regions are written). Optional like the tables.
-    if (x->kind == DS2I_BLOCK_OPTPFOR && !std::getenv("DS2I_NO_RMH")) {
+    // membership hints (abi_structs.hpp, BatchArgs::rmh): a parallel buffer with the tables' offsets (only the level-1 regions are written). Optional like the tables.
+    if (!std::getenv("DS2I_NO_RMH")) { // (every index kind: the ranked / and / wand kernels of all of them consult the hints)
         static std::mutex hint_alloc_mu;
         std::lock_guard<std::mutex> g(hint_alloc_mu);
         size_t free_b = 0, total_b = 0;

@@ -481,10 +481,20 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // class stream; one-term queries and everything else keep the class kernel
         static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
         const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= 1 && !no_rs && !tables_off &&
-                           idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
+                           (idx->kind == DS2I_BLOCK_OPTPFOR || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
         if (rs_ok) {
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
-            std::stable_sort(b->order[c].begin(), b->order[c].end(), [&](uint32_t x, uint32_t y) { return nt_of(x) > nt_of(y); });
+            {   // stable partition by list count, longest first (a class holds at most five different counts: one pass per count
+                // would do; a counting sort does it in two)
+                uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
+                for (uint32_t uid : b->order[c]) ++cnt[std::min<uint32_t>(nt_of(uid), DS2I_HIP_MAX_TERMS + 1)];
+                uint32_t start[DS2I_HIP_MAX_TERMS + 2], acc = 0;
+                for (int n = DS2I_HIP_MAX_TERMS + 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
+                std::vector<uint32_t>& tmp = b->scratch_u32;
+                tmp.resize(b->order[c].size());
+                for (uint32_t uid : b->order[c]) tmp[start[std::min<uint32_t>(nt_of(uid), DS2I_HIP_MAX_TERMS + 1)]++] = uid;
+                b->order[c].swap(tmp);
+            }
             for (uint32_t i = 0; i < b->ncls[c];) {
                 uint32_t j = i;
                 const uint32_t l = nt_of(b->order[c][i]);

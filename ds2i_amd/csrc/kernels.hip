@@ -317,6 +317,29 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
             bool ok = valid;
             auto test_one = [&](auto ic) __attribute__((always_inline)) { ok = ok && e[decltype(ic)::value] != 0; return true; };
             static_list_loop<1, RL>(nt, test_one);
+            if (a.rmh && ballot(ok)) {
+                // membership hints (BatchArgs::rmh; block_optpfor indexes): for the candidates every list's byte lets through, the
+                // lists without a bitmap say WHICH document of the candidate's range is theirs (where it is the only one): a
+                // candidate elsewhere in that range is not a member and is never probed. All hint loads first, then the tests.
+                const long long hd = (long long)(a.rmh - a.rmw);
+                uint32_t h[RL] = {};
+                auto load_hint = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    h[i] = 255u;
+                    if (!((bm_lists >> i) & 1u)) {
+                        const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
+                        if (ok) h[i] = (uint32_t)ht[c >> cx.m(i, M_RSHIFT)];
+                    }
+                    return true;
+                };
+                static_list_loop<1, RL>(nt, load_hint);
+                auto test_hint = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    ok = ok && ((h[i] == 255u) | (h[i] == rmh_code(c, cx.m(i, M_RSHIFT))));
+                    return true;
+                };
+                static_list_loop<1, RL>(nt, test_hint);
+            }
             return ok;
         };
         cx.s_bytes += 4;
@@ -552,6 +575,31 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             r1 = rmw_rest(ql1, qh1, 0);
                             v0 = v0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
                             v1 = v1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+                            if (a.rmh && (ballot(v0) | ballot(v1))) {
+                                // membership hints (BatchArgs::rmh): for the candidates the weight bytes let through, every other
+                                // list says WHICH document of the candidate's range is its own (where it is the only one there):
+                                // a candidate elsewhere in that range is in no intersection with the list -- settled by one more
+                                // byte per list instead of a block search and a block decode. All loads first, then the tests.
+                                const long long hd = (long long)(a.rmh - a.rmw);
+                                uint32_t h0[RL] = {}, h1[RL] = {};
+                                auto load_hint = [&](auto ic) __attribute__((always_inline)) {
+                                    constexpr uint32_t i = decltype(ic)::value;
+                                    const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
+                                    const uint32_t sh = cx.m(i, M_RSHIFT);
+                                    h0[i] = v0 ? (uint32_t)ht[c0 >> sh] : 255u;
+                                    h1[i] = v1 ? (uint32_t)ht[c1 >> sh] : 255u;
+                                    return true;
+                                };
+                                static_list_loop<1, RL>(nt, load_hint);
+                                auto test_hint = [&](auto ic) __attribute__((always_inline)) {
+                                    constexpr uint32_t i = decltype(ic)::value;
+                                    const uint32_t sh = cx.m(i, M_RSHIFT);
+                                    v0 = v0 && ((h0[i] == 255u) | (h0[i] == rmh_code(c0, sh)));
+                                    v1 = v1 && ((h1[i] == 255u) | (h1[i] == rmh_code(c1, sh)));
+                                    return true;
+                                };
+                                static_list_loop<1, RL>(nt, test_hint);
+                            }
                             PT_END(cx, PH_PROBE);
 #ifdef DS2I_PHASE_TIMING
                             cx.s_phase[PH_C_SURV1] += __builtin_popcountll(ballot(v0)) + __builtin_popcountll(ballot(v1));

@@ -185,20 +185,25 @@ template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)"
 // (full block inside the staged 512 bytes) never touches global memory; anything else takes the general decoder and is
 // made opaque, so that no output of this function is ever "pending on vmcnt" for the compiler: the caller's prefetches
 // and gathers stay in flight across it.
+template <int CODEC>
 DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out, uint32_t* exc, uint32_t& v0, uint32_t& v1) {
     uint32_t consumed = 0;
     const uint32_t woff = (uint32_t)((uintptr_t)p & 3u);
-    if (__builtin_expect(n == 128u && woff == 0u && optpfor_decode_lds(st, STAGE_DW, exc, out, v0, v1, consumed), 1)) return consumed;
+    if constexpr (CODEC == CODEC_OPTPFOR) {
+        if (__builtin_expect(n == 128u && woff == 0u && optpfor_decode_lds(st, STAGE_DW, exc, out, v0, v1, consumed), 1)) return consumed;
+    }
     Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, st};
     uint32_t a0, a1;
-    consumed = uniform(decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, w, p, sum, n, out, exc, a0, a1));
+    consumed = uniform(decode_block<CODEC>(CODEC, w, p, sum, n, out, exc, a0, a1));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
     v0 = a0;
     v1 = a1;
     return consumed;
 }
 
-template <int NT, bool STATS>
+// CODEC: CODEC_OPTPFOR (block_optpfor) or CODEC_MIXED (block_mixed: a type byte in front of every full block; its OptPFor
+// blocks are then not dword aligned and, like its VarInt-G8IU and interpolative blocks, take the general decoders)
+template <int NT, bool STATS, int CODEC = CODEC_OPTPFOR>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
     static_assert(NT >= 2 && NT <= 4, "exact list counts 2..4");
     __shared__ LdsRS<NT> L;
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 if (haveN) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), voff);
                 szA = ((A.blk + 1) * 128u <= n0) ? 128u : (n0 & 127u);
                 uint32_t v0, v1;
-                consA = rs_decode(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
+                consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
                 const uint32_t g0 = (lane < szA) ? v0 + 1u : 0u, g1 = (lane + 64 < szA) ? v1 + 1u : 0u;
                 const uint32_t i0 = wave_incl_scan(g0);
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
@@ -440,12 +445,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         const uint8_t* p = data0 + B.ep; // (full blocks are dword aligned and a multiple of 4 bytes long)
                         uint32_t* const stB = L.stage[bufB];
                         const uint32_t skip_dw = consB >> 2;
-                        if (szB == 128u && ((uintptr_t)p & 3u) == 0u && (consB & 3u) == 0u && skip_dw < STAGE_DW &&
+                        if (CODEC == CODEC_OPTPFOR && szB == 128u && ((uintptr_t)p & 3u) == 0u && (consB & 3u) == 0u && skip_dw < STAGE_DW &&
                             optpfor_decode_lds(stB + skip_dw, STAGE_DW - skip_dw, L.exc, L.out, fv0, fv1, consF)) {
                         } else {
                             Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, stB};
                             uint32_t a0, a1;
-                            consF = uniform(decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, w, p + consB, 0xFFFFFFFFu, szB, L.out, L.exc, a0, a1));
+                            consF = uniform(decode_block<CODEC>(CODEC, w, p + consB, 0xFFFFFFFFu, szB, L.out, L.exc, a0, a1));
                             asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
                             fv0 = a0;
                             fv1 = a1;
@@ -513,7 +518,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 wb.load(pb, STAGE_DW * 4u - 4u);
                                 const uint32_t szb = ((fb.blk + 1) * 128u <= nj) ? 128u : (nj & 127u);
                                 uint32_t v0, v1;
-                                const uint32_t consD = uniform(decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
+                                const uint32_t consD = uniform(decode_block<CODEC>(CODEC, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
                                 const uint32_t g0 = (lane < szb) ? v0 + 1u : 0u, g1 = (lane + 64 < szb) ? v1 + 1u : 0u;
                                 const uint32_t i0 = wave_incl_scan(g0);
                                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
@@ -576,7 +581,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                         cset(C_SOWNER, 0u); // (the window no longer starts at the block)
                                     }
                                     uint32_t v0, v1;
-                                    const uint32_t consF2 = decode_block<CODEC_OPTPFOR>(CODEC_OPTPFOR, wf, pf, 0xFFFFFFFFu, cget(CB + C_SZ), L.fj, L.exc, v0, v1);
+                                    const uint32_t consF2 = decode_block<CODEC>(CODEC, wf, pf, 0xFFFFFFFFu, cget(CB + C_SZ), L.fj, L.exc, v0, v1);
                                     L.fj[lane] = v0 + 1u;
                                     L.fj[lane + 64] = v1 + 1u;
                                     wave_sync();
@@ -668,6 +673,15 @@ hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hi
     const BatchArgs& a = *(const BatchArgs*)args;
     const dim3 g(grid), b(64);
     const bool st = a.stats != nullptr;
+    if (a.codec == CODEC_MIXED) { // (block_mixed: instrumented and uninstrumented runs share the instantiation with counters)
+        switch (nt) {
+        case 2: hipLaunchKernelGGL((k_ranked_stream<2, true, CODEC_MIXED>), g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_ranked_stream<3, true, CODEC_MIXED>), g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_ranked_stream<4, true, CODEC_MIXED>), g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (nt) {
     case 2: if (st) hipLaunchKernelGGL((k_ranked_stream<2, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<2, false>), g, b, 0, s, a); break;
     case 3: if (st) hipLaunchKernelGGL((k_ranked_stream<3, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<3, false>), g, b, 0, s, a); break;

@@ -253,7 +253,7 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
             assert np.array_equal(up, padded.reshape(-1, 64).max(axis=1)), (codec, t, level)
             prev = up
         hints, hsh, _ = gidx.range_table(t, 4)  # membership hints (block_optpfor): 0 empty, 255 several postings, else 1 + offset % 254
-        if codec == "block_optpfor":
+        if True:  # (every index kind carries them since the ranked / and / wand kernels of all kinds consult them)
             assert hsh == sh and len(hints) == len(tab)
             cnt = np.bincount(docs >> sh, minlength=len(tab))
             exp = np.zeros(len(tab), dtype=np.uint8)
@@ -261,8 +261,6 @@ def test_pruning_tables_are_exact_maxima(coll, images, codec):
             single = cnt[docs >> sh] == 1
             exp[(docs >> sh)[single]] = (1 + (docs[single] & ((1 << sh) - 1)) % 254).astype(np.uint8)
             assert np.array_equal(hints, exp), (codec, t)
-        else:
-            assert len(hints) == 0
 
 
 def test_block_mixed_image_holds_all_three_block_types(images):
