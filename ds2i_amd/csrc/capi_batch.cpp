@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -38,6 +39,73 @@ hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k
 uint32_t ds2i_meta_words(void); // kernels.hip: dwords of enumerator state per list slot (M_WORDS)
 }
 
+// one contiguous range of a batch's queries, planned by one thread (plan_batch)
+struct PlanChunk {
+    uint32_t q0 = 0, q1 = 0;
+    std::vector<QTerm> qterms;
+    std::vector<uint32_t> qnbs;
+    double total_cost[NCLS] = {};
+    uint32_t long_terms = 0;
+    int rc = 0;
+    const char* err = nullptr;
+};
+
+// fn(0) .. fn(n-1), fn(0) on the calling thread and the others on a small pool of planning threads that lives as long as the
+// library (created on first use; a batch is planned ~200 times a second, so the threads are kept, not spawned per batch)
+namespace {
+struct PlanPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    const std::function<void(unsigned)>* fn = nullptr;
+    unsigned next = 0, total = 0, done = 0;
+    uint64_t epoch = 0;
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_work.wait(lk, [&] { return epoch != seen && next < total; });
+            while (next < total) {
+                const unsigned i = next++;
+                const std::function<void(unsigned)>* f = fn;
+                lk.unlock();
+                (*f)(i);
+                lk.lock();
+                if (++done == total) cv_done.notify_all();
+            }
+            seen = epoch;
+        }
+    }
+    void run(unsigned n, const std::function<void(unsigned)>& f) {
+        if (n <= 1) { if (n) f(0); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (threads.size() + 1 < n) { threads.emplace_back([this] { worker(); }); threads.back().detach(); }
+            fn = &f;
+            next = 1; // (index 0 is the caller's)
+            total = n;
+            done = 1;
+            ++epoch;
+        }
+        cv_work.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done == total; });
+        total = 0;
+    }
+};
+std::mutex g_plan_pool_user; // one batch at a time uses the pool (several pipelines / replicas may plan concurrently)
+void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
+    static PlanPool* pool = new PlanPool; // (leaked on purpose: its detached threads may outlive static destruction)
+    if (n > 1 && g_plan_pool_user.try_lock()) {
+        pool->run(n, f);
+        g_plan_pool_user.unlock();
+    } else {
+        for (unsigned i = 0; i < n; ++i) f(i); // the pool is busy with another batch: plan this one on the caller's thread
+    }
+}
+} // namespace
+
 struct ds2i_hip_batch {
     ds2i_hip_index* idx = nullptr;
     int op = 0;
@@ -55,6 +123,7 @@ struct ds2i_hip_batch {
     std::vector<Unit> units;
     std::vector<uint32_t> q_unit_off, split_queries, single_queries, hist_slot, order[NCLS];
     std::vector<float> unit_cost;
+    std::vector<PlanChunk> plan_chunks;
     std::vector<unsigned long long> match_off;
     std::vector<uint32_t> seed_terms, seed_offs;
     // wand / maxscore / ranked_or as streams (k_union_topk): the virtual queries (query, driving list) their units belong to
@@ -161,23 +230,34 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     qnb0.assign(nq, 0);
     b->match_off.assign(nq + 1, 0);
     b->long_terms = 0;
-    std::vector<uint32_t>& t = b->scratch_u32;
-    std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
     const bool split_ok = conj && !(op & DS2I_OP_REFERENCE_ORDER);
     double total_cost[NCLS] = {};
-    for (uint32_t q = 0; q < nq; ++q) {
+    // The per-query half of planning (normalisation, BM25 query weights, list order, costs, bounds) is independent from query
+    // to query: the batch is cut into contiguous ranges, one per planning thread (DS2I_PLAN_THREADS, default 4, the caller's
+    // thread takes the first range), each range fills vectors of its own, and the ranges are joined by one copy. At
+    // configs[1] scale the host's 0.9 ms of planning per 1.3 ms of kernels is what bounds the end-to-end rate, and the
+    // same holds for a batch cut over 8 GPUs; the unit list and the class orders below stay sequential.
+    typedef PlanChunk Chunk;
+    auto plan_range = [&](Chunk& ch) {
+        std::vector<QTerm>& qterms = ch.qterms;
+        std::vector<uint32_t>& qnbs = ch.qnbs;
+        std::vector<uint32_t> t;
+        std::vector<std::pair<uint32_t, uint32_t>> tf; // (term, query term frequency)
+        qterms.clear();
+        qnbs.clear();
+        for (uint32_t q = ch.q0; q < ch.q1; ++q) {
         if (query_offsets[q + 1] < query_offsets[q])
-            return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
+            { ch.rc = DS2I_EINVAL; ch.err = "query_offsets must be non-decreasing"; return; }
         t.assign(terms + query_offsets[q], terms + query_offsets[q + 1]);
         std::sort(t.begin(), t.end()); // queries.hpp:31 / 139
         tf.clear();
         for (size_t i = 0; i < t.size(); ++i) {
-            if (t[i] >= idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
+            if (t[i] >= idx->size) { ch.rc = DS2I_ETERM; ch.err = "term id out of range"; return; }
             if (i == 0 || t[i] != t[i - 1]) tf.emplace_back(t[i], 1u);
             else tf.back().second += 1;
         }
         if (tf.size() > DS2I_HIP_MAX_TERMS_LONG)
-            return ds2i_set_error(DS2I_ETOOLONG, "query has more than DS2I_HIP_MAX_TERMS_LONG distinct terms");
+            { ch.rc = DS2I_ETOOLONG; ch.err = "query has more than DS2I_HIP_MAX_TERMS_LONG distinct terms"; return; }
         const size_t begin = qterms.size();
         for (auto const& p : tf) {
             QTerm qt = idx->term_proto[p.first]; // one cache line: see capi_internal.hpp
@@ -262,10 +342,43 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
                 qterms[begin].floor1 = f;
             }
         }
-        qoff[q + 1] = (uint32_t)qterms.size();
+        qoff[q + 1] = (uint32_t)(qterms.size() - begin); // (terms of this query: turned into offsets once the ranges are joined)
         qcost[q] = cost;
-        total_cost[bigk ? CLS_LONG : class_of(tf.size())] += cost;
-        if (bigk || tf.size() > DS2I_HIP_MAX_TERMS) b->long_terms = std::max<uint32_t>(b->long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
+        ch.total_cost[bigk ? CLS_LONG : class_of(tf.size())] += cost;
+        if (bigk || tf.size() > DS2I_HIP_MAX_TERMS) ch.long_terms = std::max<uint32_t>(ch.long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
+        }
+    };
+    static const char* pth = std::getenv("DS2I_PLAN_THREADS");
+    const unsigned want_threads = pth && std::atoi(pth) > 0 ? (unsigned)std::atoi(pth) : 4u;
+    const unsigned nchunks = nq >= 1024 ? std::max(1u, std::min(want_threads, 16u)) : 1u;
+    std::vector<Chunk>& chunks = b->plan_chunks;
+    if (chunks.size() < nchunks) chunks.resize(nchunks);
+    for (unsigned c = 0; c < nchunks; ++c) {
+        chunks[c].q0 = (uint32_t)((uint64_t)nq * c / nchunks);
+        chunks[c].q1 = (uint32_t)((uint64_t)nq * (c + 1) / nchunks);
+        chunks[c].rc = 0;
+        chunks[c].long_terms = 0;
+        for (double& v : chunks[c].total_cost) v = 0;
+    }
+    ds2i_plan_pool_run(nchunks, [&](unsigned c) { plan_range(chunks[c]); });
+    for (unsigned c = 0; c < nchunks; ++c)
+        if (chunks[c].rc) return ds2i_set_error(chunks[c].rc, chunks[c].err);
+    {
+        size_t total = 0;
+        for (unsigned c = 0; c < nchunks; ++c) total += chunks[c].qterms.size();
+        qterms.resize(total);
+        qnbs.resize(total);
+        size_t at = 0;
+        for (unsigned c = 0; c < nchunks; ++c) {
+            if (!chunks[c].qterms.empty()) {
+                std::memcpy(qterms.data() + at, chunks[c].qterms.data(), chunks[c].qterms.size() * sizeof(QTerm));
+                std::memcpy(qnbs.data() + at, chunks[c].qnbs.data(), chunks[c].qnbs.size() * 4);
+            }
+            at += chunks[c].qterms.size();
+            for (int k2 = 0; k2 < NCLS; ++k2) total_cost[k2] += chunks[c].total_cost[k2];
+            b->long_terms = std::max(b->long_terms, chunks[c].long_terms);
+        }
+        for (uint32_t q = 0; q < nq; ++q) qoff[q + 1] += qoff[q];
     }
     for (uint32_t q = 0; q < nq; ++q) b->match_off[q + 1] += b->match_off[q];
 
