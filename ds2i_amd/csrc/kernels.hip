@@ -2225,7 +2225,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
         const bool whole = u.nparts == 1;
         const uint32_t unit_lo = whole ? 0u : u.blk_begin, unit_hi = whole ? a.num_docs : u.blk_end;
         const uint32_t t0 = a.q_off[q], nt = a.q_off[q + 1] - t0;
-        unsigned long long count = 0, fsum = 0, facc = 0; // facc: this lane's share of the freq checksum (reduced once, below)
+        unsigned long long count = 0, fsum = 0;
         if (nt && nt <= UNION_MAX_LISTS && unit_lo < unit_hi) {
             // position every list on its first block that reaches into the unit
             for (uint32_t i = 0; i < nt; ++i) {
@@ -2304,7 +2304,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                     };
                     if (tabbed && b < nb) wfill(b ? b - 1 : 0);
                     while (b < nb) {
-                        bool freqs_only = false, freqs_done = false;
+                        bool freqs_only = false;
                         if (tabbed) {
                             if (b - wfirst > 63u) wfill(b - 1);
                             const uint32_t f = b - wfirst, fp = f ? f - 1 : 0;
@@ -2325,24 +2325,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                             }
                             if constexpr (WITH_FREQS && CODEC_T == CODEC_OPTPFOR)
                                 freqs_only = from_bitmap && bi.base >= lo && bi.bmax < hi && (b + 1u) * 128u <= cx.m(0, M_N);
-                            if (freqs_only && staged && ((uintptr_t)pblk & 3u) == 0u) {
-                                // the common case of or_freq on a dense list: the block's bytes are staged, its docs part is stepped
-                                // over by its header and its freqs are decoded from LDS straight into registers -- no enumerator
-                                // state, no LDS round trip for the decoded values, the checksum accumulated per lane
-                                const uint32_t hdr = uniform(cx.win.st[0]);
-                                const uint32_t hb = hdr >> 26, hew = hdr & 0xFFFFu;
-                                const uint32_t docs_dw = hb >= 32 ? 129u : 1u + hew + 4u * hb;
-                                uint32_t fv0, fv1, fcons;
-                                if (docs_dw + 2u < STAGE_DW && optpfor_decode_lds(cx.win.st + docs_dw, STAGE_DW - docs_dw, cx.exc, L.freqs[0], fv0, fv1, fcons)) {
-                                    facc += (unsigned long long)fv0 + fv1 + 2ull;
-                                    freqs_done = true;
-                                    ++cx.s_freqs_blocks;
-                                    cx.s_bytes += 8 + fcons; // endpoint + header + the freqs part
-                                    cx.setm(0, M_BMAX, bi.bmax);
-                                    if (STATS && cx.block_profile && lane == 0) atomicAdd(cx.block_profile + 2ull * (cx.m(0, M_PBASE) + b) + 1, 1u);
-                                }
-                            }
-                            if (freqs_only && !freqs_done) {
+                            if (freqs_only) {
                                 if (!staged) {
                                     uint32_t hint = bi.next_ep - bi.ep;
                                     if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
@@ -2374,10 +2357,10 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                             cx.decode_docs(0, b);
                         }
                         if (freqs_only) { // (every posting of the block is inside the piece, and its bits are set already)
-                            if (!freqs_done) {
-                                cx.decode_freqs(0);
-                                facc += (unsigned long long)L.freqs[0][lane] + L.freqs[0][lane + 64]; // (per lane: reduced once per unit)
-                            }
+                            cx.decode_freqs(0);
+                            unsigned long long fs = (unsigned long long)L.freqs[0][lane] + L.freqs[0][lane + 64];
+                            for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                            fsum += fs;
                         } else {
                             const uint32_t d0 = L.docs[0][lane], d1 = L.docs[0][lane + 64];
                             const bool in0 = d0 >= lo && d0 < hi, in1 = d1 >= lo && d1 < hi; // (the padding doc-id 0xFFFFFFFF is never inside)
@@ -2388,7 +2371,9 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                             if constexpr (WITH_FREQS) { // or_query<true> reads the freq of every posting it passes (queries.hpp:118-120)
                                 if (ballot(in0) | ballot(in1)) {
                                     cx.decode_freqs(0);
-                                    facc += (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
+                                    unsigned long long fs = (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
+                                    for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
+                                    fsum += fs;
                                 }
                             }
                         }
@@ -2411,10 +2396,6 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                 count += pc;
                 wave_sync();
             }
-        }
-        if constexpr (WITH_FREQS) {
-            for (int o = 32; o; o >>= 1) facc += __shfl_xor(facc, o);
-            fsum += facc;
         }
         if (whole) {
             if (lane == 0) { a.out_count[q] = count; if (a.out_freq_sum) a.out_freq_sum[q] = fsum; }
