@@ -348,8 +348,23 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         if (bigk || tf.size() > DS2I_HIP_MAX_TERMS) ch.long_terms = std::max<uint32_t>(ch.long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
         }
     };
+    // default: 4, but never more than this process's share of the CPUs it may use -- one rank per GPU under torchrun
+    // (LOCAL_WORLD_SIZE) on a host whose cgroup grants 16 CPUs leaves each of 8 ranks one planning thread
+    static const unsigned default_threads = [] {
+        double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[32] = {0};
+            double per = 0;
+            if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) cpus = std::min(cpus, std::atof(q) / per);
+            std::fclose(f);
+        }
+        const char* lw = std::getenv("LOCAL_WORLD_SIZE");
+        const double ranks = lw && std::atoi(lw) > 0 ? (double)std::atoi(lw) : 1.0;
+        const double mine = cpus / ranks - 1.0; // (one for the thread that drives the pipeline)
+        return (unsigned)std::max(1.0, std::min(4.0, mine));
+    }();
     static const char* pth = std::getenv("DS2I_PLAN_THREADS");
-    const unsigned want_threads = pth && std::atoi(pth) > 0 ? (unsigned)std::atoi(pth) : 4u;
+    const unsigned want_threads = pth && std::atoi(pth) > 0 ? (unsigned)std::atoi(pth) : default_threads;
     const unsigned nchunks = nq >= 1024 ? std::max(1u, std::min(want_threads, 16u)) : 1u;
     std::vector<Chunk>& chunks = b->plan_chunks;
     if (chunks.size() < nchunks) chunks.resize(nchunks);
