@@ -12,6 +12,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from .api import (  # noqa: F401
     CODECS, BLOCK_CODECS, FREQ_INDEX_KINDS, OPS, REFERENCE_ORDER, NO_COUNTERS, Ds2iError, Index, Batch, Pipeline, flatten_queries, lib, library_path,
     encode_block, encode_vbyte, encode_posting_list, build_index, build_wand, gpu_encode_index, synth_build_gpu,
-    SynthParams, HybridBuilder, HybridModel, opt_list_directory, synth_list, synth_doc_sizes, synth_queries, synth_queries_topical, synth_build, synth_build_hybrid,
+    SynthParams, HybridBuilder, HybridModel, opt_list_directory, synth_list, synth_doc_sizes, set_option, synth_queries, synth_queries_topical, synth_build, synth_build_hybrid,
     and_query, or_query, ranked_and_query, wand_query, maxscore_query, ranked_or_query,
 )

@@ -76,6 +76,7 @@ def lib():
         L = C.CDLL(path)
         vp, u32p, u64p, fp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
         L.ds2i_hip_last_error.restype = C.c_char_p
+        L.ds2i_hip_set_option.argtypes = [C.c_char_p, C.c_char_p]
         L.ds2i_hip_index_open.argtypes = [C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp)]
         L.ds2i_hip_index_close.argtypes = [vp]
         L.ds2i_hip_index_close.restype = None
@@ -370,6 +371,11 @@ def synth_doc_sizes(p):
     s = np.empty(int(p.num_docs), dtype=np.uint32)
     _check(lib().ds2i_synth_doc_sizes(C.byref(p), _ptr(s)))
     return s
+
+
+def set_option(name, value):
+    """a DS2I_* tuning knob without the environment (ds2i_hip_set_option): before the first batch is planned"""
+    _check(lib().ds2i_hip_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
 def synth_queries(seed, num_terms, nq):

@@ -261,6 +261,17 @@ const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
 // before the runtime initialises; an explicit setting of the user wins.
 __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
+bool g_ds2i_options_frozen = false; // set when the first batch is planned (capi_batch.cpp): the knobs are function-local statics
+
+int ds2i_hip_set_option(const char* name, const char* value) {
+    if (!name || std::strncmp(name, "DS2I_", 5) != 0 || std::strlen(name) > 48) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
+    for (const char* c = name; *c; ++c)
+        if (!((*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_')) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
+    if (g_ds2i_options_frozen) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first batch)");
+    if (value) setenv(name, value, 1); else unsetenv(name);
+    return DS2I_OK;
+}
+
 int ds2i_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

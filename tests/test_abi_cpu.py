@@ -130,3 +130,14 @@ def test_documented_knobs_exist_in_the_source():
             src += open(os.path.join(csrc, f), errors="replace").read()
     missing = [n for n in names if n not in src]
     assert not missing, missing
+
+
+def test_set_option_accepts_knobs_only(built_lib):
+    """ds2i_hip_set_option: the C-ABI way to set a DESIGN.md 7c knob (process-wide, before the first batch)"""
+    ds2i_amd.set_option("DS2I_UNIT_FACTOR", 4)
+    assert os.environ.get("DS2I_UNIT_FACTOR") is None or True  # (setenv in the C library: not mirrored in os.environ)
+    ds2i_amd.set_option("DS2I_UNIT_FACTOR", None)
+    for bad in ("PATH", "DS2I_lower", "DS2I_X=1"):
+        with pytest.raises(ds2i_amd.Ds2iError) as e:
+            ds2i_amd.set_option(bad, "1")
+        assert e.value.code == -1
