@@ -845,6 +845,20 @@ int launch_batch(ds2i_hip_batch* b) {
     }
     HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
     if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
+    // DS2I_GROUP_SPREAD=1: the second and later launch groups of a class go to the streams of classes this batch has no
+    // queries in (no further hardware queues are opened), so that a class stream is not held by its short groups
+    static const char* e_spread = std::getenv("DS2I_GROUP_SPREAD");
+    static const bool spread = e_spread && std::atoi(e_spread) > 0;
+    hipStream_t spare[NCLS];
+    int nspare = 0, next_spare = 0;
+    if (spread && !b->sset)
+        for (int c = NCLS - 1; c >= 0; --c)
+            if (!b->ncls[c]) {
+                spare[nspare] = idx->stream[c];
+                HIP_OK(hipStreamWaitEvent(spare[nspare], b->ev_clear, 0));
+                if (b->use_seed) HIP_OK(hipStreamWaitEvent(spare[nspare], b->seed->ev_done, 0));
+                ++nspare;
+            }
     for (int ci = NCLS - 1; ci >= 0; --ci) {
         const int c = small_first ? NCLS - 1 - ci : ci;
         if (!b->ncls[c]) continue;
@@ -911,10 +925,12 @@ int launch_batch(ds2i_hip_batch* b) {
                 HIP_OK(hipEventCreate(&e));
                 b->ev_g[c].push_back(e);
             }
-            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], s));
-            if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw) HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, s));
-            else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, s));
-            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], s));
+            hipStream_t sg = (gi > 0 && nspare) ? spare[next_spare++ % nspare] : s;
+            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
+            if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw) HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
+            else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, sg));
+            HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));
+            if (sg != s) HIP_OK(hipStreamWaitEvent(sm, b->ev_g[c][2 * gi + 1], 0));
         }
         HIP_OK(hipEventRecord(b->ev_c1[c], s));
         HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[c], 0));
