@@ -163,7 +163,7 @@ DS2I_DEV void rs_prefetch512(const uint8_t* g, uint32_t lds, uint32_t voff) {
     uint32_t keep;
     // (the instruction offset moves the global AND the LDS address: measured, profiles/probes/ldsdma_probe.hip)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(lds) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(uniform(lds)) : "memory");
 }
 // (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
 // lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
@@ -172,7 +172,7 @@ DS2I_DEV void rs_prefetch512(const uint8_t* g, uint32_t lds, uint32_t voff) {
 DS2I_DEV void rs_gather_u8(const uint8_t* tab, uint32_t off, uint32_t lds) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(tab), "s"(lds) : "memory");
+                 : "=&s"(keep) : "v"(off), "s"(tab), "s"(uniform(lds)) : "memory");
 }
 // one lane of a VGPR takes a wave-uniform value (v_writelane_b32; there is no builtin for it in this toolchain)
 template <int LANE> DS2I_DEV void rs_writelane(uint32_t& dst, uint32_t v) {
@@ -203,6 +203,9 @@ DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32
 
 // CODEC: CODEC_OPTPFOR (block_optpfor) or CODEC_MIXED (block_mixed: a type byte in front of every full block; its OptPFor
 // blocks are then not dword aligned and, like its VarInt-G8IU and interpolative blocks, take the general decoders)
+#ifndef RS_HINT_FIRST
+#define RS_HINT_FIRST(nt) ((nt) > 2)
+#endif
 template <int NT, bool STATS, int CODEC = CODEC_OPTPFOR>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
     static_assert(NT >= 2 && NT <= 4, "exact list counts 2..4");
@@ -213,6 +216,29 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
     typename std::conditional<STATS, unsigned long long, NullCounter>::type s_bytes;
     s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
     s_bytes = 0;
+#ifdef DS2I_LINE_COUNT
+    // diagnostic build: distinct 128-byte lines requested by the hand-placed gathers, by purpose (reported through Stats::phase_cycles)
+    unsigned long long lc[PH_COUNT] = {};
+    // lines touched by one wave instruction whose active lanes read `bytes` bytes at ascending addresses
+    auto lines_of = [&](const void* addr, bool active, uint32_t bytes) -> uint32_t {
+        const unsigned long long lo = (unsigned long long)(uintptr_t)addr >> 7, hi = ((unsigned long long)(uintptr_t)addr + bytes - 1) >> 7;
+        const uint64_t act = ballot(active);
+        // previous ACTIVE lane's last line
+        unsigned long long prev_hi = ~0ull;
+        uint32_t n = 0;
+        for (uint64_t m = act; m; m &= m - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(m);
+            const unsigned long long l = ((unsigned long long)bcast((uint32_t)(lo >> 32), src) << 32) | bcast((uint32_t)lo, src);
+            const unsigned long long h = ((unsigned long long)bcast((uint32_t)(hi >> 32), src) << 32) | bcast((uint32_t)hi, src);
+            n += (uint32_t)(h - l + 1) - ((l == prev_hi) ? 1u : 0u);
+            prev_hi = h;
+        }
+        return n;
+    };
+#define LC(slot, expr) lc[slot] += (expr)
+#else
+#define LC(slot, expr) ((void)0)
+#endif
     const uint32_t nslice = rs_args()->nslice;
     for (uint32_t tkt = blockIdx.x; tkt < nslice; tkt += gridDim.x) {
         KArgs a = rs_args(); // (fields read below stay live for the unit; the cold ones are re-read at their use site)
@@ -244,6 +270,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         };
         rs_for<1, NT>(bind_one);
         const long long hdelta = a->rmh ? (long long)(a->rmh - a->rmw) : 0ll; // hint of an entry = the byte at the same offset of the parallel buffer
+        // Three and four lists: the byte fetched ahead for every candidate is list 1's HINT, not its weight. A weight byte lets a
+        // candidate through whenever its range holds any posting (one candidate in 4..6, each then costing a line per further
+        // list); the hint also settles the ranges with a single posting, so that the further lists are asked about a few per cent
+        // of the candidates only -- first their hints, then, for what is left, every list's weight for the threshold test.
+        // (Two lists: the weight stays first, its threshold test removes more than the hint does.)
+        const bool hint_first = RS_HINT_FIRST(NT) && hdelta != 0;
+        const uint8_t* const gt1 = hint_first ? rt[1] + hdelta : rt[1];
         // block of list j whose doc-ids are in L.dj[j-1] (cur = ~0: none), its block_max, size and the arena offset of its
         // freqs part; f_owner = list whose current block's freqs are in L.fj (0 = nobody); stb_owner = list whose current
         // block's bytes are in L.stb (from stb_base on). Only stage C touches them: they live in the lanes of one VGPR
@@ -290,6 +323,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 const uint2* const tab0 = (const uint2*)rs_args()->skip + bb;
                 const float* const w0tab = rs_args()->bmw + bb;
                 if (idx < u.blk_end) { s_e = tab0[idx]; s_w = w0tab[idx]; }
+                LC(PH_PROLOG, lines_of(tab0 + idx, idx < u.blk_end, 8u) + lines_of(w0tab + idx, idx < u.blk_end, 4u));
             }
             const uint32_t prev_max = (uint32_t)__shfl_up((int)s_e.x, 1);
             const uint32_t base = (lane == 0) ? 0u : prev_max + 1u, top = s_e.x;
@@ -305,6 +339,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 const uint32_t lo = b2 >> lsh, hi = t2 >> lsh;
                 const bool fits = hi - lo < 16u;
                 const uint32_t m = max_of_bytes16(rt[j] + g.off[lvl] + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
+                LC(PH_PROLOG, lines_of(rt[j] + g.off[lvl] + (fits ? lo : 0u), true, 16u));
                 const uint32_t best = (row && fits) ? m : 255u; // (255 = the list maximum)
                 dead = dead || best == 0u;
                 acc = acc + rsc[j] * (float)best;
@@ -365,6 +400,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // A's bytes were requested an iteration ago; the only loads issued after them are B's two gathers
                 if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
                 if (haveN) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), voff);
+                if (haveN) LC(PH_STREAM, lines_of((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3) + 8u * lane, true, 8u));
                 szA = ((A.blk + 1) * 128u <= n0) ? 128u : (n0 & 127u);
                 uint32_t v0, v1;
                 consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
@@ -384,7 +420,39 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 gB0[1] = L.gb[0][lane];
                 gB1[1] = L.gb[1][lane];
                 bool ok0 = (dB0 != 0xFFFFFFFFu) & (gB0[1] != 0u), ok1 = (dB1 != 0xFFFFFFFFu) & (gB1[1] != 0u);
-                if constexpr (NT > 2) {
+                if (hint_first) {
+                    ok0 = ok0 & ((gB0[1] == 255u) | (gB0[1] == rmh_code(dB0, rsh[1])));
+                    ok1 = ok1 & ((gB1[1] == 255u) | (gB1[1] == rmh_code(dB1, rsh[1])));
+                    LC(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
+                    if constexpr (NT > 2) {
+                        if (ballot(ok0) | ballot(ok1)) { // the further lists' hints, all requested before any is tested
+                            uint32_t h0[NT] = {}, h1[NT] = {};
+                            auto hload = [&](auto jc) __attribute__((always_inline)) {
+                                constexpr int j = decltype(jc)::value;
+                                const uint8_t* const ht = rt[j] + hdelta;
+                                h0[j] = ok0 ? (uint32_t)ht[dB0 >> rsh[j]] : 0u;
+                                h1[j] = ok1 ? (uint32_t)ht[dB1 >> rsh[j]] : 0u;
+                                LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1, 1u));
+                            };
+                            rs_for<2, NT>(hload);
+                            auto htest = [&](auto jc) __attribute__((always_inline)) {
+                                constexpr int j = decltype(jc)::value;
+                                ok0 = ok0 & (h0[j] != 0u) & ((h0[j] == 255u) | (h0[j] == rmh_code(dB0, rsh[j])));
+                                ok1 = ok1 & (h1[j] != 0u) & ((h1[j] == 255u) | (h1[j] == rmh_code(dB1, rsh[j])));
+                            };
+                            rs_for<2, NT>(htest);
+                        }
+                    }
+                    if (ballot(ok0) | ballot(ok1)) { // every list's weight byte for what is left
+                        auto wload = [&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            gB0[j] = ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u;
+                            gB1[j] = ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u;
+                            LC(PH_FREQS, lines_of(rt[j] + (dB0 >> rsh[j]), ok0, 1u) + lines_of(rt[j] + (dB1 >> rsh[j]), ok1, 1u));
+                        };
+                        rs_for<1, NT>(wload);
+                    }
+                } else if constexpr (NT > 2) {
                     // lists 2.. : their bytes only for the candidates list 1's byte lets through (list maxima for the others)
                     float rest = 0.f;
                     auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest = rest + rsc[j] * 255.0f; };
@@ -398,6 +466,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             gB1[j] = (uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]];
                         };
                         rs_for<2, NT>(load_one);
+#ifdef DS2I_LINE_COUNT
+                        auto cnt_one = [&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            LC(PH_FREQS, lines_of(rt[j] + ((ok0 ? dB0 : 0u) >> rsh[j]), true, 1u) + lines_of(rt[j] + ((ok1 ? dB1 : 0u) >> rsh[j]), true, 1u));
+                        };
+                        rs_for<2, NT>(cnt_one);
+#endif
                         auto test_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             ok0 = ok0 & (gB0[j] != 0u);
@@ -420,7 +495,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 float r0 = rest_of(gB0, 0), r1 = rest_of(gB1, 0);
                 ok0 = ok0 & enters((B.wq + r0) * BOUND_SLACK);
                 ok1 = ok1 & enters((B.wq + r1) * BOUND_SLACK);
-                if (hdelta && (ballot(ok0) | ballot(ok1))) {
+                LC(PH_C_VISIT, __builtin_popcountll(ballot(dB0 != 0xFFFFFFFFu)) + __builtin_popcountll(ballot(dB1 != 0xFFFFFFFFu)));
+                if (!hint_first) LC(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
+                if (!hint_first && hdelta && (ballot(ok0) | ballot(ok1))) {
                     // membership hints (BatchArgs::rmh): a weight byte only says that SOME posting of list j lies in the candidate's
                     // range; where that range holds exactly one posting its hint byte says which. A candidate at another offset is
                     // not in the list -- settled here, by one more byte, instead of by a block search and a block decode in stage C.
@@ -428,12 +505,15 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         constexpr int j = decltype(jc)::value;
                         const uint8_t* const ht = rt[j] + hdelta;
                         const uint32_t h0 = ok0 ? (uint32_t)ht[dB0 >> rsh[j]] : 255u, h1 = ok1 ? (uint32_t)ht[dB1 >> rsh[j]] : 255u;
+                        LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1, 1u));
                         ok0 = ok0 & ((h0 == 255u) | (h0 == rmh_code(dB0, rsh[j])));
                         ok1 = ok1 & ((h1 == 255u) | (h1 == rmh_code(dB1, rsh[j])));
                     };
                     rs_for<1, NT>(hint_one);
                 }
+                LC(PH_C_SURV2, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 if (__builtin_expect((ballot(ok0) | ballot(ok1)) != 0, 0)) {
+                    LC(PH_C_LIVEROUNDS, 1);
                     // ---------------- stage C: somebody of block B may enter the heap
                     // freqs of the block (its bytes are still staged), freq-only bound (doc_term_weight falls with norm_len, so the
                     // collection's shortest document bounds the term score from the freq alone), norm_len, exact list-0 score
@@ -462,6 +542,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     ok0 = ok0 & enters((qw0 * doc_term_weight(f0, min_nl) + r0) * BOUND_SLACK);
                     ok1 = ok1 & enters((qw0 * doc_term_weight(f1, min_nl) + r1) * BOUND_SLACK);
                     const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
+                    LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
                     float pa0 = qw0 * doc_term_weight(f0, nl0), pa1 = qw0 * doc_term_weight(f1, nl1);
                     {
                         const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
@@ -494,6 +575,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             if (curj == 0xFFFFFFFFu || amin > bmj) {
                                 Found fb;
                                 const bool found = find_block_rows(tabj, wtabj, nbj, curj + 1u, amin, fb);
+                                LC(PH_FIND, 1);
                                 if (!found) { // list j has nothing >= amin: no later document of list 0 can be a result either
                                     s_bm_examined += 1;
                                     s_bytes += 4;
@@ -516,6 +598,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 const uint8_t* pb = dataj + fb.ep;
                                 Window wb{nullptr, 0, L.stb};
                                 wb.load(pb, STAGE_DW * 4u - 4u);
+                                LC(PH_C_BDOCS, 1);
+                                LC(PH_DOCS, lines_of(pb + 8u * lane, true, 8u));
                                 const uint32_t szb = ((fb.blk + 1) * 128u <= nj) ? 128u : (nj & 127u);
                                 uint32_t v0, v1;
                                 const uint32_t consD = uniform(decode_block<CODEC>(CODEC, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
@@ -578,6 +662,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                     Window wf{sbase, STAGE_DW * 4u, L.stb};
                                     if (cget(C_SOWNER) != (uint32_t)j || !wf.covers(pf, 64)) {
                                         wf.load(pf, 256u);
+                                        LC(PH_C_BFREQS, 1);
+                                        LC(PH_PROBE, lines_of(pf + 4u * lane, true, 4u));
                                         cset(C_SOWNER, 0u); // (the window no longer starts at the block)
                                     }
                                     uint32_t v0, v1;
@@ -607,6 +693,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                             todo &= todo - 1;
                             const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
+                            LC(PH_C_HEAP, 1);
                             if (tk.insert(v)) {
                                 refresh();
                                 if (shared_floor && lane == 0) sh.add(v);
@@ -627,8 +714,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             if (haveB) {
                 // one byte per candidate from list 1's table (the other lists' bytes are fetched in stage B for the candidates inside
                 // list 1's ranges only: a gather is one cache-line request per lane, and most candidates die at list 1)
-                rs_gather_u8(rt[1], (dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1], gb_base);
-                rs_gather_u8(rt[1], (dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1], gb_base + 256u);
+                rs_gather_u8(gt1, (dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1], gb_base);
+                rs_gather_u8(gt1, (dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1], gb_base + 256u);
+                LC(PH_TOPK, lines_of(rt[1] + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(rt[1] + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u));
             }
             A = N;
             haveA = haveN;
@@ -661,7 +749,11 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         atomicAdd(&stats->algorithmic_bytes, (unsigned long long)s_bytes);
         atomicAdd(&stats->postings_scored, (unsigned long long)s_scored);
         atomicAdd(&stats->rounds, (unsigned long long)s_rounds);
+#ifdef DS2I_LINE_COUNT
+        for (int i = 0; i < PH_COUNT; ++i) if (lc[i]) atomicAdd(&stats->phase_cycles[i], lc[i]);
+#endif
     }
+#undef LC
 }
 
 } // namespace
