@@ -75,17 +75,29 @@ struct ef_offsets {
 };
 
 // Sampled positions of a finished 0/1 array, straight from their definition (SURVEY.md Appendix A6, and what
-// test_compact_elias_fano.cpp:45-80 / test_compact_ranked_bitvector.cpp:36-68 check by a direct scan): walking the
-// `len` bits at `first`, on_one(pos, ones_before) is called for every 1 and on_zero(pos, zeros_before) for every 0.
-template <class OnOne, class OnZero>
-inline void scan_bits(bitvec_builder const& bv, uint64_t first, uint64_t len, OnOne on_one, OnZero on_zero) {
+// test_compact_elias_fano.cpp:45-80 / test_compact_ranked_bitvector.cpp:36-68 check by a direct scan): the `len` bits at
+// `first` are walked 64 at a time; on_chunk(pos, bits, nbits, ones_before) gets the chunk that starts at relative
+// position pos (bit i of `bits` = bit pos + i; nbits valid, the rest zero) and the number of 1s before it. Callers pick
+// the set bits with ctz and ranks with popcount: the cost is per word and per sampled bit, not per bit of the universe.
+template <class OnChunk>
+inline void scan_bits(bitvec_builder const& bv, uint64_t first, uint64_t len, OnChunk on_chunk) {
     auto const& w = bv.words();
     uint64_t ones = 0;
-    for (uint64_t pos = 0; pos < len; ++pos) {
-        const uint64_t at = first + pos;
-        if ((w[at >> 6] >> (at & 63)) & 1) on_one(pos, ones++);
-        else on_zero(pos, pos - ones);
+    for (uint64_t pos = 0; pos < len; pos += 64) {
+        const uint64_t at = first + pos, wi = at >> 6;
+        const unsigned sh = (unsigned)(at & 63);
+        uint64_t bits = w[wi] >> sh;
+        if (sh && wi + 1 < w.size()) bits |= w[wi + 1] << (64 - sh);
+        const uint64_t nbits = len - pos < 64 ? len - pos : 64;
+        if (nbits < 64) bits &= (uint64_t(1) << nbits) - 1;
+        on_chunk(pos, bits, nbits, ones);
+        ones += (uint64_t)__builtin_popcountll(bits);
     }
+}
+// the positions (relative to the chunk's pos) of the chunk's set bits, in order: fn(pos_of_bit, index among the chunk's set bits)
+template <class Fn>
+inline void for_each_set_bit(uint64_t bits, Fn fn) {
+    for (uint64_t k = 0; bits; bits &= bits - 1, ++k) fn((uint64_t)__builtin_ctzll(bits), k);
 }
 
 // compact_elias_fano image of a sorted sequence (layout: `ef_offsets`): pointers0 | pointers1 | high bits | low bits.
@@ -108,15 +120,23 @@ inline void ef_write(bitvec_builder& bvb, It begin, uint64_t universe, uint64_t 
     if (!of.pointers0 && !of.pointers1) return;
     const uint64_t every1 = (uint64_t(1) << of.log_sampling1) - 1;
     const uint64_t every0 = of.log_sampling0 < 64 ? (uint64_t(1) << of.log_sampling0) - 1 : ~uint64_t(0);
-    scan_bits(bvb, of.higher_bits_offset, of.higher_bits_length,
-              [&](uint64_t pos, uint64_t ones) {
-                  if (ones && !(ones & every1))
-                      bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
-              },
-              [&](uint64_t pos, uint64_t zeros) {
-                  if (zeros && !(zeros & every0))
-                      bvb.set_bits(of.pointers0_offset + ((zeros >> of.log_sampling0) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
-              });
+    scan_bits(bvb, of.higher_bits_offset, of.higher_bits_length, [&](uint64_t pos, uint64_t bits, uint64_t nbits, uint64_t ones_before) {
+        const uint64_t c1 = (uint64_t)__builtin_popcountll(bits), zeros_before = pos - ones_before, c0 = nbits - c1;
+        if (of.pointers1 && c1)
+            for_each_set_bit(bits, [&](uint64_t b, uint64_t k) {
+                const uint64_t ones = ones_before + k;
+                if (ones && !(ones & every1))
+                    bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos + b, (unsigned)of.pointer_size);
+            });
+        if (of.pointers0 && c0) {
+            const uint64_t inv = ~bits & (nbits < 64 ? (uint64_t(1) << nbits) - 1 : ~uint64_t(0));
+            for_each_set_bit(inv, [&](uint64_t b, uint64_t k) {
+                const uint64_t zeros = zeros_before + k;
+                if (zeros && !(zeros & every0))
+                    bvb.set_bits(of.pointers0_offset + ((zeros >> of.log_sampling0) - 1) * of.pointer_size, pos + b, (unsigned)of.pointer_size);
+            });
+        }
+    });
 }
 
 // sequential decode of all n values (upload-time flattening of m_endpoints, a12)

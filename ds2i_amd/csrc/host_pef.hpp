@@ -82,19 +82,23 @@ inline void rb_write(bitvec_builder& bvb, It begin, uint64_t universe, uint64_t 
     }
     if (!of.rank1_samples && !of.pointers1) return;
     const uint64_t every1 = (uint64_t(1) << of.log_sampling1) - 1;
-    const uint64_t every_pos = of.log_rank1_sampling < 64 ? (uint64_t(1) << of.log_rank1_sampling) - 1 : ~uint64_t(0);
-    auto sample_rank = [&](uint64_t pos, uint64_t ones_before) {
-        if (pos && !(pos & every_pos))
-            bvb.set_bits(of.rank1_samples_offset + ((pos >> of.log_rank1_sampling) - 1) * of.rank1_sample_size, ones_before,
-                         (unsigned)of.rank1_sample_size);
-    };
-    scan_bits(bvb, of.bits_offset, universe,
-              [&](uint64_t pos, uint64_t ones) {
-                  sample_rank(pos, ones);
-                  if (ones && !(ones & every1))
-                      bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos, (unsigned)of.pointer_size);
-              },
-              [&](uint64_t pos, uint64_t zeros) { sample_rank(pos, pos - zeros); });
+    const uint64_t rank_step = of.log_rank1_sampling < 64 ? uint64_t(1) << of.log_rank1_sampling : 0; // 0 = no samples
+    scan_bits(bvb, of.bits_offset, universe, [&](uint64_t pos, uint64_t bits, uint64_t nbits, uint64_t ones_before) {
+        // rank samples: rank1_samples[k-1] = number of 1s before position k * 2^r (k >= 1) -- the sampled positions inside
+        // this chunk, each by one popcount
+        if (of.rank1_samples && rank_step)
+            for (uint64_t sp = pos ? (pos + rank_step - 1) / rank_step * rank_step : rank_step; sp < pos + nbits; sp += rank_step) {
+                const uint64_t below = sp - pos; // < 64
+                bvb.set_bits(of.rank1_samples_offset + ((sp >> of.log_rank1_sampling) - 1) * of.rank1_sample_size,
+                             ones_before + (uint64_t)__builtin_popcountll(bits & ((uint64_t(1) << below) - 1)), (unsigned)of.rank1_sample_size);
+            }
+        if (of.pointers1 && bits)
+            for_each_set_bit(bits, [&](uint64_t b, uint64_t k) {
+                const uint64_t ones = ones_before + k;
+                if (ones && !(ones & every1))
+                    bvb.set_bits(of.pointers1_offset + ((ones >> of.log_sampling1) - 1) * of.pointer_size, pos + b, (unsigned)of.pointer_size);
+            });
+    });
 }
 
 // ---------------------------------------------------------------- indexed / strict sequences
