@@ -7,7 +7,7 @@ d, wl, op = sys.argv[1], sys.argv[2], sys.argv[3]
 per = {}
 for line in open(d + "/counters_fetch.txt"):
     k, name, disp, mean = line.rstrip("\n").split("\t")
-    if ", true>(" in k:  # the instrumented instantiations (one launch per bench run): not what a step runs
+    if ", true>(" in k or re.search(r"k_ranked_stream<\d, true", k):  # the instrumented instantiations (one launch per bench run): not what a step runs
         continue
     if name != "FETCH_SIZE" or not re.search(r"k_ranked_stream|k_conjunctive|k_union|k_disjunctive|k_daat|k_merge", k):
         continue
