@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     h[i] = 255u;
                     if (!((bm_lists >> i) & 1u)) {
                         const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
-                        if (ok) h[i] = (uint32_t)ht[c >> cx.m(i, M_RSHIFT)];
+                        if (ok && cx.m(i, M_RSHIFT) != 0u) h[i] = (uint32_t)ht[c >> cx.m(i, M_RSHIFT)]; // (one doc-id per entry: the weight byte was the answer)
                     }
                     return true;
                 };
@@ -586,8 +586,8 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                                     constexpr uint32_t i = decltype(ic)::value;
                                     const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
                                     const uint32_t sh = cx.m(i, M_RSHIFT);
-                                    h0[i] = v0 ? (uint32_t)ht[c0 >> sh] : 255u;
-                                    h1[i] = v1 ? (uint32_t)ht[c1 >> sh] : 255u;
+                                    h0[i] = (v0 && sh != 0u) ? (uint32_t)ht[c0 >> sh] : 255u; // (one doc-id per entry: the weight byte was the answer)
+                                    h1[i] = (v1 && sh != 0u) ? (uint32_t)ht[c1 >> sh] : 255u;
                                     return true;
                                 };
                                 static_list_loop<1, RL>(nt, load_hint);
@@ -2063,8 +2063,8 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                         if (i < nt) {
                             const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
                             const uint32_t sh = cx.m(i, M_RSHIFT);
-                            if (al0 && byte_of(pk0, i) != 0u) hv0[k2] = (uint32_t)ht[c0 >> sh];
-                            if (al1 && byte_of(pk1, i) != 0u) hv1[k2] = (uint32_t)ht[c1 >> sh];
+                            if (al0 && sh != 0u && byte_of(pk0, i) != 0u) hv0[k2] = (uint32_t)ht[c0 >> sh]; // (one doc-id per entry: nothing to add)
+                            if (al1 && sh != 0u && byte_of(pk1, i) != 0u) hv1[k2] = (uint32_t)ht[c1 >> sh];
                         }
                     };
                     auto ts = [&](auto kc) __attribute__((always_inline)) {
@@ -2084,8 +2084,8 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                             constexpr uint32_t i = decltype(ic)::value;
                             const uint8_t* ht = rmw + 64ull * cx.m(i, M_RBASE) + hd;
                             const uint32_t sh = cx.m(i, M_RSHIFT);
-                            hv0[i - I0] = (al0 && byte_of(pk0, i) != 0u) ? (uint32_t)ht[c0 >> sh] : 255u;
-                            hv1[i - I0] = (al1 && byte_of(pk1, i) != 0u) ? (uint32_t)ht[c1 >> sh] : 255u;
+                            hv0[i - I0] = (al0 && sh != 0u && byte_of(pk0, i) != 0u) ? (uint32_t)ht[c0 >> sh] : 255u;
+                            hv1[i - I0] = (al1 && sh != 0u && byte_of(pk1, i) != 0u) ? (uint32_t)ht[c1 >> sh] : 255u;
                             return true;
                         };
                         static_list_loop<I0, (I0 + 4 < TMAX ? I0 + 4 : TMAX)>(nt, one_ld);

@@ -504,8 +504,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     auto hint_one = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         const uint8_t* const ht = rt[j] + hdelta;
-                        const uint32_t h0 = ok0 ? (uint32_t)ht[dB0 >> rsh[j]] : 255u, h1 = ok1 ? (uint32_t)ht[dB1 >> rsh[j]] : 255u;
-                        LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1, 1u));
+                        const bool hashint = rsh[j] != 0u; // (one doc-id per entry: the weight byte was the answer)
+                        const uint32_t h0 = (ok0 & hashint) ? (uint32_t)ht[dB0 >> rsh[j]] : 255u, h1 = (ok1 & hashint) ? (uint32_t)ht[dB1 >> rsh[j]] : 255u;
+                        LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0 & hashint, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1 & hashint, 1u));
                         ok0 = ok0 & ((h0 == 255u) | (h0 == rmh_code(dB0, rsh[j])));
                         ok1 = ok1 & ((h1 == 255u) | (h1 == rmh_code(dB1, rsh[j])));
                     };
@@ -716,7 +717,14 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // list 1's ranges only: a gather is one cache-line request per lane, and most candidates die at list 1)
                 rs_gather_u8(gt1, (dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1], gb_base);
                 rs_gather_u8(gt1, (dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1], gb_base + 256u);
-                LC(PH_TOPK, lines_of(rt[1] + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(rt[1] + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u));
+                LC(PH_TOPK, lines_of(gt1 + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u));
+#ifdef DS2I_LINE_COUNT
+                {   // the same lines by the width of list 1's ranges (shift 0 = one doc-id per byte: the densest lists)
+                    const uint32_t nl = lines_of(gt1 + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u);
+                    const uint32_t shv = rsh[1];
+                    if (shv == 0) lc[PH_TOTAL] += nl; else if (shv == 1) lc[PH_INSERT] += nl; else if (shv == 2) lc[PH_PREFETCH] += nl; else if (shv <= 4) lc[PH_FLOOR] += nl; else lc[PH_UNIT] += nl;
+                }
+#endif
             }
             A = N;
             haveA = haveN;
