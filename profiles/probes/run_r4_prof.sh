@@ -11,7 +11,7 @@ timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o k
 KS=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
 if [ -n "$KS" ]; then cp "$KS" $OUT/kernel_stats.csv; fi
 rm -rf $OUT/kt
-for PASS in "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+for PASS in "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   NAME=${PASS%%:*}; CTRS=${PASS#*:}
   timeout 420 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/pmc_$NAME -o pmc -- \
       python bench.py --workload $WL --op $OP --steps 4 --warmup 1 --no-oracle > /dev/null 2> $OUT/pmc_$NAME.err
