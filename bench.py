@@ -46,6 +46,7 @@ WORKLOADS = {
 }
 NCLS = 5  # kernel classes by distinct query terms: <=2, <=4, <=8, <=16, more
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GATHER_PEAK_GBS = 6320.0  # measured: 49.4 G distinct 128-byte lines/s (profiles/probes/r4_gather_rate.sh), the same as a 16-byte-per-lane copy
 
 
 def log(*a):
@@ -499,6 +500,13 @@ def main():
         out["roofline"]["step_algorithmic_bytes"] = int(out["a_skip_bytes_per_step"])
         out["roofline"]["step_achieved"] = out["a_skip_bytes_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9
         out["roofline"]["step_frac"] = out["roofline"]["step_achieved"] / HBM_PEAK_GBS
+    if traffic_step and out.get("ms_per_step"):
+        # the memory side of the same step: the committed profile's bytes per batch over THIS run's step time (per GPU)
+        rate = traffic_step / (out["ms_per_step"] * 1e-3) / 1e9
+        out["roofline"]["traffic_rate"] = {"gbs": rate, "of_hbm_peak": rate / HBM_PEAK_GBS, "of_measured_gather_peak": rate / GATHER_PEAK_GBS,
+                                           "gather_peak_gbs": GATHER_PEAK_GBS,
+                                           "note": "FETCH_SIZE bytes per batch from the committed profile / this run's ms_per_step; gather peak = 2^30 scattered "
+                                                   "one-byte gathers over 8 GiB on this device (profiles/probes/r4_gather_rate.sh)"}
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
     if dist is not None:
