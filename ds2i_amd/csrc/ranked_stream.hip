@@ -540,8 +540,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     ++s_freqs_blocks;
                     s_bytes += consF;
                     const uint32_t f0 = fv0 + 1u, f1 = fv1 + 1u;
+#ifndef DS2I_RS_NO_FREQ_BOUND
                     ok0 = ok0 & enters((qw0 * doc_term_weight(f0, min_nl) + r0) * BOUND_SLACK);
                     ok1 = ok1 & enters((qw0 * doc_term_weight(f1, min_nl) + r1) * BOUND_SLACK);
+#endif
                     const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
                     LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
                     float pa0 = qw0 * doc_term_weight(f0, nl0), pa1 = qw0 * doc_term_weight(f1, nl1);
