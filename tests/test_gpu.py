@@ -559,6 +559,24 @@ def test_ranked_and_block_max_pruning_prunes(built_lib):
         _check_against_oracle(gidx, oidx, "ranked_and", qs, k=k)
 
 
+@pytest.mark.parametrize("codec", ["block_optpfor", "block_mixed", "opt"])
+def test_correlated_collection_every_operator_equals_oracle(built_lib, codec):
+    """bench.py's robustness workload (`--workload gov2c`) at a size the oracle answers in seconds: topical documents (a
+    term 32 times as likely in the documents of its home topic), half of the multi-term queries drawn from one topic --
+    intersections many times larger than independent lists give, i.e. the case the range tables prune least. Every
+    operator equals the oracle (counts, doc-id lists, top-k), through the stream kernels (block_optpfor / block_mixed: 2-4
+    terms with every upload-time table) and the class kernels (opt; 1 and 5+ terms)."""
+    p = d.SynthParams(seed=0xD5210007, num_docs=1_000_000, num_terms=512, zipf_exp=0.6, top_df_frac=0.25, min_len=2000, clustered_every=4,
+                      topics=16, topic_boost=32)
+    img, wand, postings = d.synth_build(p, codec)
+    gidx = d.Index(codec, img, wand)
+    oidx = o.Index(codec, img, wand)
+    qs = d.synth_queries_topical(p, 0x51E23, 384, same_topic_pct=50) + [[], [3], [3, 3], [9, 4, 9]]
+    for op in ("ranked_and", "and", "and_freq", "wand", "maxscore", "ranked_or", "or", "or_freq"):
+        _check_against_oracle(gidx, oidx, op, qs, k=10)
+    _check_against_oracle(gidx, oidx, "ranked_and", qs, k=64)
+
+
 def test_query_op_concept(coll, images):
     """queries.cpp-style use: op(index, terms) -> uint64, ranked ops expose topk()."""
     gidx = d.Index("block_qmx", images[0]["block_qmx"], images[1])

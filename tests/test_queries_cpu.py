@@ -83,3 +83,53 @@ def test_threaded_oracle_batch_equals_sequential(coll, queries, codec):
             for i, q in enumerate(queries):
                 m = brute_and(coll, q).astype(np.uint64)
                 assert (m * (2 * np.arange(len(m), dtype=np.uint64) + 1)).sum(dtype=np.uint64) == b[4][i]
+
+
+def test_correlated_collection_is_correlated_and_answered_exactly(built_lib):
+    """The robustness workload of bench.py (`--workload gov2c`: topical documents, a term far more likely in the documents of
+    its home topic; queries drawn from one topic) at toy size: its same-topic term pairs really co-occur more than
+    independent lists of the same lengths would -- that is what it is for -- the generator is deterministic, and the
+    oracle answers its queries like the brute force does (the GPU parity tests then compare against that oracle)."""
+    p = d.SynthParams(seed=0xD5210007, num_docs=40000, num_terms=256, zipf_exp=0.6, top_df_frac=0.2, min_len=64, clustered_every=4,
+                      topics=8, topic_boost=32)
+    coll = Collection(p)
+    again = d.synth_list(p, 17)
+    assert np.array_equal(again[0], coll.lists[17][0]) and np.array_equal(again[1], coll.lists[17][1])
+    same = d.synth_queries_topical(p, 0x51E21, 200, same_topic_pct=100)
+    assert same == d.synth_queries_topical(p, 0x51E21, 200, same_topic_pct=100)
+    got = exp = 0.0
+    for q in same:
+        ts = sorted(set(q))
+        for i in range(len(ts)):
+            for j in range(i + 1, len(ts)):
+                a, b = coll.lists[ts[i]][0], coll.lists[ts[j]][0]
+                got += len(np.intersect1d(a, b, assume_unique=True))
+                exp += len(a) * len(b) / coll.num_docs
+    assert exp > 0 and got > 1.5 * exp, (got, exp)  # same-topic pairs: well above what independence predicts
+    p0 = d.SynthParams(seed=p.seed, num_docs=p.num_docs, num_terms=p.num_terms, zipf_exp=p.zipf_exp, top_df_frac=p.top_df_frac,
+                       min_len=p.min_len, clustered_every=p.clustered_every)
+    flat = Collection(p0)
+    g0 = e0 = 0.0
+    for q in same[:60]:
+        ts = sorted(set(q))
+        for i in range(len(ts)):
+            for j in range(i + 1, len(ts)):
+                a, b = flat.lists[ts[i]][0], flat.lists[ts[j]][0]
+                g0 += len(np.intersect1d(a, b, assume_unique=True))
+                e0 += len(a) * len(b) / flat.num_docs
+    assert e0 > 0 and g0 < 1.6 * e0 and got / exp > 1.3 * (g0 / e0), (g0, e0, got, exp)  # the same pairs without topics: far fewer co-occurrences
+    queries = d.synth_queries_topical(p, 0x51E22, 120, same_topic_pct=50)
+    idx = o.Index("block_optpfor", coll.index_image("block_optpfor"), coll.wand_image())
+    for q in queries:
+        r = idx.query("and", q, want_matches=True)
+        e = brute_and(coll, q)
+        assert r["count"] == len(e) and np.array_equal(r["matches"], e)
+        ra = idx.query("ranked_and", q)
+        ea = brute_ranked(coll, q, 10, True, "size")
+        assert ra["count"] == len(ea)
+        np.testing.assert_allclose(ra["topk"], ea, rtol=RTOL)
+        eo = brute_ranked(coll, q, 10, False, "term")
+        for op in ("wand", "maxscore"):
+            ro = idx.query(op, q)
+            assert ro["count"] == len(eo), (op, q)
+            np.testing.assert_allclose(ro["topk"], eo, rtol=RTOL, err_msg=str((op, q)))
