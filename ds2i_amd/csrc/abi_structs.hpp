@@ -16,7 +16,8 @@ struct QTerm {
     uint32_t term;    // block indexes: term id ; opt index: number of chunks of the list
     uint64_t aux0;    // opt index: absolute bit offset of the list's docs sequence (after its gamma header);
                       // block indexes: number of blocks of all preceding lists (access-profile base)
-    uint64_t aux1;    // opt index: absolute bit offset of the list's freqs sequence
+    uint64_t aux1;    // opt index: absolute bit offset of the list's freqs sequence;
+                      // block_optpfor with side tables: dword offset of the list's partial last block in BatchArgs::tails
     uint32_t blk_base; // blocks (chunks) of all preceding lists: index of this list's first entry in bmw[]
     float max_bmw;     // q_weight * (max over the list's blocks of bmw[]): device-computed list bound (ranked_and pruning)
     float suf_bmw;     // sum of max_bmw over the LATER lists of the query (enumerator order)
@@ -107,6 +108,14 @@ struct BatchArgs {
     // list: for a list with 32 doc-ids per entry that settles 30 of 31 candidates the weight byte lets through, without the
     // block search + block decode a lookup costs (k_ranked_stream; block_optpfor indexes).
     const uint8_t* rmh;
+    // Exception side slots (block_optpfor, or null): 64 dwords per block of the index (block b of list t = slot blk_base_t + b)
+    // holding the OptPFor exceptions of its docs and freqs parts as position masks + ready-to-OR values (layout:
+    // device_codecs.hpp, optpfor_decode_side); xovf = the overflow area of the few blocks whose exceptions do not fit.
+    // tails: the partial last block of every list (n % 128 postings; interpolative on disk, serial by construction)
+    // expanded to gaps-1 then freqs-1 (+ the byte counts of its two parts), list t's entry at dword aux1_t -- the stream kernels then carry one decoder.
+    const uint32_t* xslots;
+    const uint32_t* xovf;
+    const uint32_t* tails;
     // k_union_topk (wand / maxscore / ranked_or as streams): units belong to VIRTUAL queries = (query, driving list); qterms /
     // q_off then describe the virtual queries, and vq_info holds 3 words per virtual query: the real query, the number
     // of exclusion lists (slots 1 .. nexcl: lists of higher max score -- a document found there is theirs), and the float
@@ -164,6 +173,25 @@ struct BmwArgs {
                             // rmw_level + 1}, each entry the maximum of 64 entries of the level below
 };
 
+// exception side slot of one block (device_codecs.hpp, optpfor_decode_side): dwords, first add, adds held in-slot, overflow word
+static constexpr uint32_t XSLOT_DW = 64, XSLOT_ADDS = 8, XSLOT_CAP = 55, XSLOT_OVF = 63;
+
+// upload-time pass filling the exception side slots and the tail table (k_build_side_tables): items as in BmwArgs
+struct SideArgs {
+    const uint8_t* arena;
+    const QTerm* lists;
+    const BmwItem* items;
+    uint32_t nitems;
+    uint32_t num_docs;
+    const void* skip;          // interleaved skip table
+    uint32_t* xslots;          // out: XSLOT_DW dwords per block
+    uint32_t* xovf;            // out: overflow area
+    unsigned long long xovf_cap; // dwords
+    unsigned long long* xovf_cursor; // dwords handed out so far (may run past the capacity: the host then re-runs with more)
+    uint32_t* tails;           // out
+    unsigned int* bad;         // out: blocks whose header disagrees with their decoded values (corrupt image)
+};
+
 struct MergeArgs {
     const uint32_t* split_queries; // ids of queries with nparts > 1
     uint32_t nsplit;
@@ -190,6 +218,10 @@ struct DecodeArgs {
     uint32_t* out_docs;
     uint32_t* out_freqs;
     Stats* stats;
+    const void* skip;        // side-slot decode (k_decode_list_side): the interleaved skip table, the slots, their overflow area, the tail table
+    const uint32_t* xslots;
+    const uint32_t* xovf;
+    const uint32_t* tails;
 };
 
 } // namespace ds2i_dev

@@ -29,8 +29,10 @@ using ds2i_dev::Stats;
 
 extern "C" {
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_decode_list_side(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_block_max_weights(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_list_top_bmw(const float* bmw, const void* lists, uint32_t nlists, float* out, unsigned grid, hipStream_t s);
+hipError_t ds2i_launch_build_side_tables(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_calib_read(const uint32_t* base, unsigned long long ndw, uint32_t* out, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_selftest(const uint32_t* in, uint32_t* out, unsigned blocks, hipStream_t s);
 hipError_t ds2i_launch_selftest_bm25(const uint32_t* freqs, const float* norm_lens, float* out, uint32_t n, hipStream_t s);
@@ -74,6 +76,9 @@ void free_index(ds2i_hip_index* x) {
     if (x->d_bmw) (void)hipFree(x->d_bmw);
     if (x->d_rmw) (void)hipFree(x->d_rmw);
     if (x->d_rmh) (void)hipFree(x->d_rmh);
+    if (x->d_xslots) (void)hipFree(x->d_xslots);
+    if (x->d_xovf) (void)hipFree(x->d_xovf);
+    if (x->d_tails) (void)hipFree(x->d_tails);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
     for (auto& s : x->stream_b) if (s) (void)hipStreamDestroy(s);
@@ -248,6 +253,90 @@ int build_block_max_weights(ds2i_hip_index* x) {
     HIP_OK(hipStreamSynchronize(x->stream[0]));
     x->extra_bytes += bytes + (x->d_rmh ? bytes : 0);
     return DS2I_OK;
+}
+
+// block_optpfor: the exception side slots, their overflow area and the tail table (abi_structs.hpp, BatchArgs::xslots).
+// One more pass over the index with the general decoders (k_build_side_tables). Like the range tables they are an
+// accelerator: an upload that cannot afford them (or DS2I_NO_XSLOTS) runs the kernels that parse the Simple16 streams.
+int build_side_tables(ds2i_hip_index* x) {
+    if (std::getenv("DS2I_NO_XSLOTS") || !x->d_skip || !x->total_blocks || x->total_blocks >= (1ull << 32)) return DS2I_OK;
+    const uint64_t V = x->size;
+    x->list_tail_off.assign(V, 0);
+    uint64_t tail = 0;
+    for (uint64_t t = 0; t < V; ++t) {
+        x->list_tail_off[t] = tail; // dwords: an entry = sz gaps-1, sz freqs-1, bytes of the docs part, bytes of the freqs part
+        if (x->list_n[t] & 127u) tail += 2 * (x->list_n[t] & 127u) + 2;
+    }
+    const uint64_t slot_bytes = 4ull * ds2i_dev::XSLOT_DW * x->total_blocks, tail_bytes = 4 * tail + 1024;
+    auto give_up = [&](const char* why) -> int {
+        if (x->d_xslots) (void)hipFree(x->d_xslots);
+        if (x->d_xovf) (void)hipFree(x->d_xovf);
+        if (x->d_tails) (void)hipFree(x->d_tails);
+        x->d_xslots = x->d_xovf = x->d_tails = nullptr;
+        (void)hipGetLastError();
+        std::fprintf(stderr, "ds2i_hip: index uploaded WITHOUT exception side slots (%.2f GB wanted: %s); block decodes parse the Simple16 streams\n",
+                     (slot_bytes + tail_bytes) / 1e9, why);
+        return DS2I_OK;
+    };
+    {
+        static std::mutex side_alloc_mu; // (several replicas may be uploaded to one device at once)
+        std::lock_guard<std::mutex> g(side_alloc_mu);
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        if (slot_bytes + tail_bytes > free_b / 2) return give_up("less than twice their size is free on the device");
+        if (hipMalloc((void**)&x->d_xslots, slot_bytes) != hipSuccess || hipMalloc((void**)&x->d_tails, tail_bytes) != hipSuccess) return give_up("hipMalloc failed");
+    }
+    std::vector<QTerm> lists(V);
+    std::vector<ds2i_dev::BmwItem> items;
+    items.reserve(x->total_blocks / 64 + V);
+    for (uint64_t t = 0; t < V; ++t) {
+        lists[t] = ds2i_make_qterm(x, (uint32_t)t);
+        lists[t].aux1 = x->list_tail_off[t]; // (d_tails is set only once the tables are complete)
+        for (uint32_t b = 0; b < x->list_nb[t]; b += 64) items.push_back(ds2i_dev::BmwItem{(uint32_t)t, b});
+    }
+    DevTemps tmp;
+    QTerm* d_lists = nullptr;
+    ds2i_dev::BmwItem* d_items = nullptr;
+    unsigned long long* d_cursor = nullptr;
+    HIP_OK(tmp.alloc(&d_lists, sizeof(QTerm) * V));
+    HIP_OK(tmp.alloc(&d_items, sizeof(ds2i_dev::BmwItem) * items.size()));
+    HIP_OK(tmp.alloc(&d_cursor, 16));
+    HIP_OK(hipMemcpy(d_lists, lists.data(), sizeof(QTerm) * V, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_items, items.data(), sizeof(ds2i_dev::BmwItem) * items.size(), hipMemcpyHostToDevice));
+    uint64_t ovf_cap = x->total_blocks / 8 + 65536; // dwords; the pass says how much it wanted and is re-run once if that was more
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (x->d_xovf) (void)hipFree(x->d_xovf);
+        x->d_xovf = nullptr;
+        if (hipMalloc((void**)&x->d_xovf, 4 * ovf_cap) != hipSuccess) return give_up("hipMalloc failed (overflow area)");
+        HIP_OK(hipMemsetAsync(x->d_xslots, 0, slot_bytes, x->stream[0]));
+        HIP_OK(hipMemsetAsync(d_cursor, 0, 16, x->stream[0]));
+        ds2i_dev::SideArgs a{};
+        a.arena = x->d_arena;
+        a.lists = d_lists;
+        a.items = d_items;
+        a.nitems = (uint32_t)items.size();
+        a.num_docs = (uint32_t)x->num_docs;
+        a.skip = x->d_skip;
+        a.xslots = x->d_xslots;
+        a.xovf = x->d_xovf;
+        a.xovf_cap = ovf_cap;
+        a.xovf_cursor = d_cursor;
+        a.tails = x->d_tails;
+        a.bad = (unsigned int*)(d_cursor + 1);
+        HIP_OK(ds2i_launch_build_side_tables(&a, (unsigned)std::min<size_t>(items.size(), (size_t)x->num_cus * 64), x->stream[0]));
+        HIP_OK(hipStreamSynchronize(x->stream[0]));
+        unsigned long long res[2] = {0, 0};
+        HIP_OK(hipMemcpy(res, d_cursor, 16, hipMemcpyDeviceToHost));
+        if ((unsigned int)res[1]) return give_up("block headers disagree with the decoded values (corrupt image?)");
+        if (res[0] >= 0xFFFFFFFFull) return give_up("overflow area beyond 16 GB");
+        if (res[0] <= ovf_cap) {
+            x->side_bytes = slot_bytes + tail_bytes + 4 * ovf_cap;
+            x->extra_bytes += x->side_bytes;
+            return DS2I_OK;
+        }
+        ovf_cap = res[0] + 64;
+    }
+    return give_up("overflow area did not converge");
 }
 
 } // namespace
@@ -481,6 +570,10 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;
     }
+    if (kind == DS2I_BLOCK_OPTPFOR) {
+        int rc = build_side_tables(x.get());
+        if (rc) return rc;
+    }
     x->term_proto.resize(V);
     for (uint64_t t = 0; t < V; ++t) {
         QTerm qt = ds2i_make_qterm(x.get(), (uint32_t)t);
@@ -507,7 +600,9 @@ int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out)
     out->has_membership_hints = idx->d_rmh != nullptr;
     out->skip_table_bytes = idx->d_skip ? 8 * idx->total_blocks : 0;
     out->norm_len_bytes = idx->has_wand ? 4 * idx->num_docs : 0;
-    out->index_bytes = idx->arena_bytes + idx->extra_bytes - out->block_weight_bytes - out->range_table_bytes - out->skip_table_bytes;
+    out->side_table_bytes = idx->d_xslots ? idx->side_bytes : 0;
+    out->has_side_tables = idx->d_xslots != nullptr;
+    out->index_bytes = idx->arena_bytes + idx->extra_bytes - out->block_weight_bytes - out->range_table_bytes - out->skip_table_bytes - out->side_table_bytes;
     (void)freq_layout;
     out->total_blocks = idx->total_blocks;
     for (uint32_t n : idx->list_n) out->total_postings += n;
@@ -547,8 +642,14 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     a.out_docs = d_docs;
     a.out_freqs = d_freqs;
     a.stats = nullptr;
+    a.skip = idx->d_skip;
+    a.xslots = idx->d_xslots;
+    a.xovf = idx->d_xovf;
+    a.tails = idx->d_tails;
     unsigned grid = (unsigned)std::min<uint64_t>(nb, uint64_t(idx->num_cus) * 16);
-    hipError_t e = ds2i_launch_decode_list(&a, grid, idx->stream[0]);
+    // block_optpfor with side tables: through the stream kernels' decoder (DS2I_DECODE_GENERAL=1: the general decoders)
+    const bool side = idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && !std::getenv("DS2I_DECODE_GENERAL");
+    hipError_t e = side ? ds2i_launch_decode_list_side(&a, grid, idx->stream[0]) : ds2i_launch_decode_list(&a, grid, idx->stream[0]);
     if (e == hipSuccess) e = hipStreamSynchronize(idx->stream[0]);
     if (e == hipSuccess) e = hipMemcpy(docs, d_docs, 4 * len, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(freqs, d_freqs, 4 * len, hipMemcpyDeviceToHost);

@@ -611,7 +611,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // class stream; one-term queries and everything else keep the class kernel
         static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
         const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= 1 && !no_rs && !tables_off &&
-                           (idx->kind == DS2I_BLOCK_OPTPFOR || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
+                           ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
         if (rs_ok) {
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
             {   // stable partition by list count, longest first (a class holds at most five different counts: one pass per count
@@ -909,6 +909,9 @@ int launch_batch(ds2i_hip_batch* b) {
         a.rmw_bitmaps = (a.rmw && idx->has_bitmaps && !no_bm_use) ? 1u : 0u;
         static const bool no_rmh_use = std::getenv("DS2I_NO_RMH_USE") != nullptr; // A/B: hints built but not consulted
         a.rmh = (a.rmw && !no_rmh_use) ? idx->d_rmh : nullptr;
+        a.xslots = idx->d_xslots;
+        a.xovf = idx->d_xovf;
+        a.tails = idx->d_tails;
         a.long_scratch = (uint32_t*)b->d_long.p;
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;

@@ -100,6 +100,13 @@ struct ds2i_hip_index {
     uint64_t rmw_bytes = 0;
     uint8_t* d_rmh = nullptr;       // membership hints: one more byte per level-1 range-table entry, same offsets (BatchArgs::rmh), or null
     int rmw_g = 0;                  // entries per posting the tables were built with (DS2I_RMW_G)
+    // block_optpfor: exception side slots (64 dwords per block), their overflow area, and the lists' partial last blocks in
+    // plain form (abi_structs.hpp, BatchArgs::xslots / xovf / tails), or null
+    uint32_t* d_xslots = nullptr;
+    uint32_t* d_xovf = nullptr;
+    uint32_t* d_tails = nullptr;
+    uint64_t side_bytes = 0;
+    std::vector<uint64_t> list_tail_off; // postings in the partial last blocks of all preceding lists
     bool d_skip_or_pef() const { return d_skip != nullptr || kind >= DS2I_OPT; } // what the streaming kernels walk the driving list by
     bool has_bitmaps = false;       // dense lists carry an exact bitmap behind their range-table levels
     std::vector<uint32_t> list_rmw_off64, list_rmw_shift;
@@ -138,7 +145,7 @@ static inline ds2i_dev::QTerm ds2i_make_qterm(const ds2i_hip_index* idx, uint32_
     qt.max_weight = 0.f;
     qt.term = freq_layout ? idx->list_nb[term] : term;
     qt.aux0 = freq_layout ? idx->list_aux0[term] : idx->list_blk_base[term];
-    qt.aux1 = freq_layout ? idx->list_aux1[term] : 0;
+    qt.aux1 = freq_layout ? idx->list_aux1[term] : (idx->d_tails ? idx->list_tail_off[term] : 0);
     qt.blk_base = (uint32_t)idx->list_blk_base[term];
     qt.max_bmw = 0.f;
     qt.suf_bmw = 0.f;

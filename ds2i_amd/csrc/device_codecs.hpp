@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "abi_structs.hpp"
+
 namespace ds2i_dev {
 
 #define DS2I_DEV __device__ __forceinline__
@@ -542,6 +544,94 @@ DS2I_DEV bool optpfor_decode_lds(const uint32_t* blk, uint32_t avail_dw, uint32_
     v1 |= out[lane + 64] << b;
     wave_sync();
     return true;
+}
+
+// ---- OptPFor with the upload-time EXCEPTION SIDE SLOTS (block_optpfor indexes; abi_structs.hpp, BatchArgs::xslots).
+// The on-disk block keeps its exceptions as two Simple16 streams (position deltas, high parts: block_codecs.hpp:210-226
+// via FastPFor) -- on a wave that is ~8 dependent LDS round trips and half of a decode's instructions. At upload every
+// full block of the index gets one 64-dword slot that holds the same information in the form a wave wants:
+//   dwords 0..3   docs part:  128-bit mask of the positions that carry an exception (bit i = value i)
+//   dwords 4..7   freqs part: the same
+//   dwords 8..62  the "adds" = (high part + 1) << b of every exception, docs part first (in position order), then freqs part
+//   dword  63     0, or 1 + dword offset of the block's adds in the overflow area when they do not fit (> 55: a few blocks in 10^5)
+// so that value i = low bits | (mask bit i ? adds[first + popcount(mask below i)] : 0): two LDS reads, no Simple16.
+// (XSLOT_* constants: abi_structs.hpp)
+
+// the b-bit low parts of a full block (header dword hdr at dword 0 of the part; RD(i) = dword i of the part)
+template <class RD>
+DS2I_DEV void optpfor_low_bits(RD rd, uint32_t hdr, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const uint32_t b = hdr >> 26, ew = hdr & 0xFFFFu;
+    const uint32_t mask = (1u << b) - 1u; // b == 0: mask 0, every value 0 (b < 32 here)
+    const uint32_t bit0 = lane * b, bit1 = bit0 + 64u * b;
+    const uint32_t i0 = 1u + ew + (bit0 >> 5), i1 = 1u + ew + (bit1 >> 5);
+    v0 = __builtin_amdgcn_alignbit(rd(i0 + 1), rd(i0), bit0 & 31u) & mask;
+    v1 = __builtin_amdgcn_alignbit(rd(i1 + 1), rd(i1), bit1 & 31u) & mask;
+}
+// the exceptions of one part: m = its mask (the same four dwords in every lane), XRD(i) = add i of the block, first = index
+// of the part's first add
+template <class XRD>
+DS2I_DEV void optpfor_apply_adds(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t first, XRD xrd, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const bool has0 = ((lane < 32u ? m0 >> lane : m1 >> (lane - 32u)) & 1u) != 0u;
+    const bool has1 = ((lane < 32u ? m2 >> lane : m3 >> (lane - 32u)) & 1u) != 0u;
+    const uint32_t r0 = __builtin_amdgcn_mbcnt_hi(m1, __builtin_amdgcn_mbcnt_lo(m0, first));
+    const uint32_t r1 = __builtin_amdgcn_mbcnt_hi(m3, __builtin_amdgcn_mbcnt_lo(m2, first + (uint32_t)__builtin_popcount(m0) + (uint32_t)__builtin_popcount(m1)));
+    const uint32_t a0 = xrd(has0 ? r0 : first), a1 = xrd(has1 ? r1 : first);
+    v0 |= has0 ? a0 : 0u;
+    v1 |= has1 ? a1 : 0u;
+}
+
+// One part (docs: part = 0, freqs: part = 1) of a full OptPFor block whose bytes are staged in LDS from `blk` on
+// (avail_dw dwords; blk -> the part's header) and whose side slot is staged at `slot`. `gpart` = the part's address in
+// the arena and `xovf` = the overflow area, touched only by the cases the staging does not cover (a part beyond the staged
+// bytes, a raw b = 32 block, adds in the overflow area); their loads are waited for before the function returns, so that
+// nothing of it is "pending" for the compiler where the caller's paths join. nd = exceptions of the docs part (where the
+// freqs part's adds start; ignored for part 0). Returns the bytes of the part; values in v0 / v1 (value i in lane i & 63,
+// slot i >> 6).
+DS2I_DEV uint32_t optpfor_decode_side(const uint32_t* blk, uint32_t avail_dw, const uint32_t* slot, const uint8_t* gpart, const uint32_t* xovf,
+                                      uint32_t part, uint32_t nd, uint32_t& v0, uint32_t& v1, uint32_t* nexc_out = nullptr) {
+    const uint32_t lane = lane_id();
+    const uint32_t* const g = (const uint32_t*)gpart;
+    const bool staged = avail_dw != 0u;
+    uint32_t hdr;
+    if (__builtin_expect(staged, 1)) hdr = uniform(blk[0]);
+    else hdr = uniform(g[0]);
+    const uint32_t b = hdr >> 26, nexc = (hdr >> 16) & 0x3FFu, ew = hdr & 0xFFFFu;
+    if (nexc_out) *nexc_out = nexc;
+    if (__builtin_expect(b >= 32u, 0)) { // raw block: 128 dwords behind the header
+        uint32_t a0 = g[1 + lane], a1 = g[65 + lane];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+        v0 = a0;
+        v1 = a1;
+        return 4u * 129u;
+    }
+    const uint32_t total_dw = 1u + ew + 4u * b;
+    if (__builtin_expect(staged && total_dw + 1u <= avail_dw, 1)) {
+        optpfor_low_bits([&](uint32_t i) { return blk[i]; }, hdr, v0, v1);
+    } else {
+        uint32_t a0, a1;
+        optpfor_low_bits([&](uint32_t i) { return g[i]; }, hdr, a0, a1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+        v0 = a0;
+        v1 = a1;
+    }
+    if (nexc) {
+        const uint4 m = *(const uint4*)(slot + 4u * part);
+        const uint32_t ovf = uniform(slot[XSLOT_OVF]);
+        const uint32_t first = part ? nd : 0u;
+        if (__builtin_expect(ovf == 0u, 1)) {
+            optpfor_apply_adds(m.x, m.y, m.z, m.w, XSLOT_ADDS + first, [&](uint32_t i) { return slot[i]; }, v0, v1);
+        } else {
+            const uint32_t* const xo = xovf + (ovf - 1u);
+            uint32_t a0 = 0, a1 = 0;
+            optpfor_apply_adds(m.x, m.y, m.z, m.w, first, [&](uint32_t i) { return xo[i]; }, a0, a1);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+            v0 |= a0;
+            v1 |= a1;
+        }
+    }
+    return 4u * total_dw;
 }
 
 // ---- VarInt-G8IU full block. Values are scattered to out[] (LDS) then re-read.

@@ -2435,6 +2435,49 @@ __global__ void __launch_bounds__(64) k_decode_list(DecodeArgs a) {
     cx.flush_stats(a.stats);
 }
 
+// The same through the exception side slots + tail table (block_optpfor with BatchArgs::xslots): the decoder of the stream
+// kernels (optpfor_decode_side), so that every list-decode test of a block_optpfor index exercises it and the tables.
+__global__ void __launch_bounds__(64) k_decode_list_side(DecodeArgs a) {
+    __shared__ uint32_t st[STAGE_DW];
+    __shared__ uint32_t xs[XSLOT_DW];
+    const uint32_t lane = lane_id();
+    const QTerm t = a.term;
+    const uint32_t n = t.n, nb = (n + 127u) >> 7;
+    const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
+    const uint8_t* const data = a.arena + t.list_off + vl + 4ull * nb + 4ull * (nb - 1);
+    const uint2* const tab = (const uint2*)a.skip + t.blk_base;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
+        const uint32_t base = b ? tab[b - 1].x + 1u : 0u, ep = b ? tab[b - 1].y : 0u;
+        uint32_t v0, v1, f0, f1;
+        if (sz == 128u) {
+            const uint32_t* const g = (const uint32_t*)(data + ep);
+            const uint32_t* const gx = a.xslots + (size_t)XSLOT_DW * (t.blk_base + b);
+            st[lane] = g[lane];
+            st[lane + 64] = g[lane + 64];
+            xs[lane] = gx[lane];
+            wave_sync();
+            uint32_t nd = 0;
+            const uint32_t cons = optpfor_decode_side(st, STAGE_DW, xs, data + ep, a.xovf, 0u, 0u, v0, v1, &nd);
+            const uint32_t skip_dw = cons >> 2;
+            optpfor_decode_side(st + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, xs, data + ep + cons, a.xovf, 1u, nd, f0, f1);
+        } else {
+            const uint32_t* const tl = a.tails + t.aux1;
+            v0 = lane < sz ? tl[lane] : 0u;
+            v1 = lane + 64 < sz ? tl[lane + 64] : 0u;
+            f0 = lane < sz ? tl[sz + lane] : 0u;
+            f1 = lane + 64 < sz ? tl[sz + lane + 64] : 0u;
+        }
+        const uint32_t g0 = (lane < sz) ? v0 + 1u : 0u, g1 = (lane + 64 < sz) ? v1 + 1u : 0u;
+        const uint32_t i0 = wave_incl_scan(g0);
+        const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
+        const size_t gpos = (size_t)b * 128u;
+        if (lane < sz) { a.out_docs[gpos + lane] = base + i0 - 1u; a.out_freqs[gpos + lane] = f0 + 1u; }
+        if (lane + 64 < sz) { a.out_docs[gpos + lane + 64] = base + i1 - 1u; a.out_freqs[gpos + lane + 64] = f1 + 1u; }
+        wave_sync();
+    }
+}
+
 // ------------------------------------------------------------------ upload-time block-max weights
 // bmw[block] = max over the block's postings of bm25::doc_term_weight(freq, norm_len[doc]) -- the block-level analogue
 // of wand_data's max_term_weight (wand_data.hpp:40-52), with the scoring code's own float32 arithmetic. One wave per
@@ -2555,6 +2598,97 @@ __global__ void __launch_bounds__(64) k_block_max_weights(BmwArgs a) {
         }
         if (lane == 0) atomicMax(a.list_bmw + it.list, __float_as_uint(lm)); // weights >= 0: bit patterns order like values
     }
+}
+
+// ------------------------------------------------------------------ upload-time exception side slots + tail table
+// block_optpfor: every full block's OptPFor exceptions, re-stated from its two Simple16 streams as position masks + values
+// ready to be OR-ed in (layout: device_codecs.hpp, optpfor_decode_side), and every list's partial last block (interpolative
+// on disk) as plain gaps-1 / freqs-1. Both come out of the general decoders, i.e. they hold exactly what a query-time
+// decode of the on-disk bytes would produce; the image itself is left as it is. One wave per item = <=64 consecutive
+// blocks of one list.
+__global__ void __launch_bounds__(64) k_build_side_tables(SideArgs a) {
+    __shared__ Lds<1> L;
+    BatchArgs ba{};
+    ba.arena = a.arena;
+    ba.codec = CODEC_OPTPFOR;
+    ba.num_docs = a.num_docs;
+    ba.skip = a.skip;
+    auto cx = make_ctx<CODEC_OPTPFOR, MetaLds>(L, ba);
+    const uint32_t lane = lane_id();
+    uint32_t bad = 0;
+    for (uint32_t item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        const BmwItem it = a.items[item];
+        const QTerm t = a.lists[it.list];
+        cx.bind(0, t);
+        const uint32_t nb = cx.m(0, M_NB);
+        const uint32_t end = it.blk_begin + 64u < nb ? it.blk_begin + 64u : nb;
+        const uint2* const tab = (const uint2*)a.skip + t.blk_base;
+        const uint8_t* const data = cx.ptr(0, M_MAXS_LO) + 4ull * nb + 4ull * (nb - 1);
+        for (uint32_t b = it.blk_begin; b < end; ++b) {
+            cx.decode_docs(0, b);
+            cx.decode_freqs(0);
+            const uint32_t sz = cx.m(0, M_SIZE);
+            const uint32_t base = b ? tab[b - 1].x + 1u : 0u, ep = b ? tab[b - 1].y : 0u;
+            // gaps - 1 / freqs - 1 as the block decoders deliver them (value i in lane i & 63, slot i >> 6)
+            const uint32_t d0 = L.docs[0][lane], d1 = L.docs[0][lane + 64];
+            const uint32_t v0 = lane < sz ? (lane ? d0 - L.docs[0][lane - 1] - 1u : d0 - base) : 0u;
+            const uint32_t v1 = lane + 64 < sz ? d1 - L.docs[0][lane + 63] - 1u : 0u;
+            const uint32_t f0 = lane < sz ? L.freqs[0][lane] - 1u : 0u, f1 = lane + 64 < sz ? L.freqs[0][lane + 64] - 1u : 0u;
+            if (sz < 128u) { // the list's partial last block
+                uint32_t* const dst = a.tails + t.aux1; // entry: sz gaps-1, sz freqs-1, bytes of the docs part, bytes of the freqs part
+                if (lane < sz) { dst[lane] = v0; dst[sz + lane] = f0; }
+                if (lane + 64 < sz) { dst[lane + 64] = v1; dst[sz + lane + 64] = f1; }
+                const unsigned long long fo = ((unsigned long long)cx.m(0, M_FREQ_HI) << 32) | cx.m(0, M_FREQ_LO);
+                if (lane == 0) {
+                    dst[2u * sz] = (uint32_t)(fo - (unsigned long long)(data + (b ? tab[b - 1].y : 0u) - a.arena));
+                    dst[2u * sz + 1] = (uint32_t)(t.list_end - fo);
+                }
+                wave_sync();
+                continue;
+            }
+            const uint8_t* const pd = data + ep;
+            const uint8_t* const pf = cx.ptr(0, M_FREQ_LO);
+            const uint32_t hd = uniform(ld32(pd)), hf = uniform(ld32(pf));
+            const uint32_t bd = hd >> 26, bf = hf >> 26;
+            const uint32_t keepd = bd < 32u ? ~((1u << bd) - 1u) : 0u, keepf = bf < 32u ? ~((1u << bf) - 1u) : 0u;
+            const uint32_t a0 = v0 & keepd, a1 = v1 & keepd, g0 = f0 & keepf, g1 = f1 & keepf;
+            const uint64_t md0 = ballot(a0 != 0u), md1 = ballot(a1 != 0u), mf0 = ballot(g0 != 0u), mf1 = ballot(g1 != 0u);
+            const uint32_t nd = (uint32_t)(__builtin_popcountll(md0) + __builtin_popcountll(md1));
+            const uint32_t nf = (uint32_t)(__builtin_popcountll(mf0) + __builtin_popcountll(mf1));
+            if ((bd < 32u && nd != ((hd >> 16) & 0x3FFu)) || (bf < 32u && nf != ((hf >> 16) & 0x3FFu))) ++bad; // (corrupt image)
+            uint32_t* const slot = a.xslots + (size_t)XSLOT_DW * (t.blk_base + b);
+            uint32_t* dst = slot + XSLOT_ADDS;
+            uint32_t ovf = 0;
+            bool ok = true;
+            if (nd + nf > XSLOT_CAP) {
+                unsigned long long off = 0;
+                if (lane == 0) off = atomicAdd(a.xovf_cursor, (unsigned long long)(nd + nf));
+                off = ((unsigned long long)bcast((uint32_t)(off >> 32), 0) << 32) | bcast((uint32_t)off, 0);
+                ok = off + nd + nf <= a.xovf_cap && off + nd + nf < 0xFFFFFFFFull; // (otherwise the host re-runs the pass with the room the cursor asks for)
+                dst = a.xovf + off;
+                ovf = (uint32_t)off + 1u;
+            }
+            const uint32_t words[8] = {(uint32_t)md0, (uint32_t)(md0 >> 32), (uint32_t)md1, (uint32_t)(md1 >> 32),
+                                       (uint32_t)mf0, (uint32_t)(mf0 >> 32), (uint32_t)mf1, (uint32_t)(mf1 >> 32)};
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mine = lane == (uint32_t)i ? words[i] : mine;
+            if (lane < 8u) slot[lane] = mine;
+            if (lane == XSLOT_OVF) slot[lane] = ok ? ovf : 0u;
+            if (ok) {
+                const uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(md0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md0, 0u));
+                const uint32_t r1 = (uint32_t)__builtin_popcountll(md0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(md1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md1, 0u));
+                const uint32_t s0 = nd + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf0, 0u));
+                const uint32_t s1 = nd + (uint32_t)__builtin_popcountll(mf0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf1, 0u));
+                if (a0) dst[r0] = a0;
+                if (a1) dst[r1] = a1;
+                if (g0) dst[s0] = g0;
+                if (g1) dst[s1] = g1;
+            }
+            wave_sync();
+        }
+    }
+    if (bad && lane == 0) atomicAdd(a.bad, bad);
 }
 
 // top[list][0..63] = the 64 largest bmw values of the list, descending, padded with 0 (one wave per list)
@@ -2786,6 +2920,11 @@ hipError_t ds2i_launch_block_max_weights(const void* args, unsigned grid, hipStr
     return hipGetLastError();
 }
 
+hipError_t ds2i_launch_build_side_tables(const void* args, unsigned grid, hipStream_t s) {
+    const SideArgs& a = *(const SideArgs*)args;
+    hipLaunchKernelGGL(k_build_side_tables, dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t ds2i_launch_list_top_bmw(const float* bmw, const void* lists, uint32_t nlists, float* out, unsigned grid, hipStream_t s) {
     hipLaunchKernelGGL(k_list_top_bmw, dim3(grid), dim3(64), 0, s, bmw, (const QTerm*)lists, nlists, out);
     return hipGetLastError();
@@ -2797,6 +2936,11 @@ hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t ds2i_launch_decode_list_side(const void* args, unsigned grid, hipStream_t s) {
+    const DecodeArgs& a = *(const DecodeArgs*)args;
+    hipLaunchKernelGGL(k_decode_list_side, dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t ds2i_launch_decode_list(const void* args, unsigned grid, hipStream_t s) {
     const DecodeArgs& a = *(const DecodeArgs*)args;
     hipLaunchKernelGGL(k_decode_list, dim3(grid), dim3(64), 0, s, a);

@@ -47,15 +47,24 @@ static_assert(DS2I_RS_FLOOR_EVERY > 0 && (DS2I_RS_FLOOR_EVERY & (DS2I_RS_FLOOR_E
 #endif
 #define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : DS2I_RS_OCC4)
 
-template <int NT>
-struct LdsRS {
+// what the decoders need beside the staged bytes: block_optpfor = the blocks' exception side slots (BatchArgs::xslots) and
+// nothing else -- no Simple16 scratch, no field table, no scatter buffer; block_mixed = the general decoders' scratch
+template <int CODEC> struct LdsDec;
+template <> struct LdsDec<CODEC_OPTPFOR> {
+    uint32_t xs[3][XSLOT_DW]; // list 0: side slots of the blocks in stage[] (LDS-DMA, with the bytes)
+    uint32_t xsb[XSLOT_DW];   // side slot of the block in stb
+};
+template <> struct LdsDec<CODEC_MIXED> {
+    uint32_t out[128];        // decoder scratch (OptPFor exception scatter, interpolative prefix sums)
+    uint32_t exc[EXC_LDS_DW]; // Simple16 scratch + field table
+};
+template <int NT, int CODEC>
+struct LdsRS : LdsDec<CODEC> {
     uint32_t stage[3][STAGE_DW]; // list 0: bytes of the blocks in stage B/C, in stage A and on their way in (LDS-DMA)
     uint32_t gb[2][64];          // list 1's range-table byte of every posting of the block in stage B (LDS-DMA, one dword per lane)
     uint32_t stb[STAGE_DW];      // bytes of the other lists' block decoded last
     uint32_t dj[NT - 1][128];    // lists 1 .. NT-1: doc-ids of their current block
     uint32_t fj[128];            // freqs of the block of the list that decoded its freqs last (f_owner)
-    uint32_t out[128];           // decoder scratch (OptPFor exception scatter, interpolative prefix sums)
-    uint32_t exc[EXC_LDS_DW];    // Simple16 scratch + field table
 };
 
 // first block >= from of a list whose block_max >= lb, with its table words; rows = the list's interleaved skip table
@@ -157,6 +166,12 @@ DS2I_DEV KArgs rs_args() {
 // some path, which would put every round trip back on the critical path; these are issued and waited for by hand.
 // (i) block bytes: LDS-DMA, global -> LDS with no register in between (nothing the compiler could copy or spill early);
 DS2I_DEV uint32_t rs_lds_offset(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+// a wave-uniform pointer the compiler could not prove uniform (the "s" constraint of the statements below takes what it is
+// given -- a VGPR pair assembles to nothing): both halves through v_readfirstlane, a plain copy where they were scalar already
+template <class T> DS2I_DEV const T* rs_uniform_ptr(const T* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    return (const T*)(uintptr_t)(((unsigned long long)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v));
+}
 // 512 bytes at g (4-byte aligned) -> LDS byte offset `lds`; voff = lane * 4. M0 is the DMA's LDS base: compiler-reserved,
 // so it is saved, set and restored inside each statement.
 DS2I_DEV void rs_prefetch512(const uint8_t* g, uint32_t lds, uint32_t voff) {
@@ -164,6 +179,13 @@ DS2I_DEV void rs_prefetch512(const uint8_t* g, uint32_t lds, uint32_t voff) {
     // (the instruction offset moves the global AND the LDS address: measured, profiles/probes/ldsdma_probe.hip)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(g), "s"(uniform(lds)) : "memory");
+}
+// the same 512 bytes + the block's 256-byte exception side slot (gx -> lds_x): three loads, M0 set twice
+DS2I_DEV void rs_prefetch_blk(const uint8_t* g, uint32_t lds, const uint32_t* gx, uint32_t lds_x, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(uniform(lds)), "s"(gx), "s"(uniform(lds_x)) : "memory");
 }
 // (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
 // lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
@@ -181,24 +203,40 @@ template <int LANE> DS2I_DEV void rs_writelane(uint32_t& dst, uint32_t v) {
 }
 template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// optpfor / interpolative block -> gaps or freqs-1 in (v0, v1), value i in lane i & 63, slot i >> 6. The common case
-// (full block inside the staged 512 bytes) never touches global memory; anything else takes the general decoder and is
-// made opaque, so that no output of this function is ever "pending on vmcnt" for the compiler: the caller's prefetches
-// and gathers stay in flight across it.
+// block_mixed: any block -> gaps or freqs-1 in (v0, v1), value i in lane i & 63, slot i >> 6, through the general decoders;
+// made opaque, so that no output of this function is ever "pending on vmcnt" for the compiler: the caller's prefetches and
+// gathers stay in flight across it.
 template <int CODEC>
 DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out, uint32_t* exc, uint32_t& v0, uint32_t& v1) {
-    uint32_t consumed = 0;
-    const uint32_t woff = (uint32_t)((uintptr_t)p & 3u);
-    if constexpr (CODEC == CODEC_OPTPFOR) {
-        if (__builtin_expect(n == 128u && woff == 0u && optpfor_decode_lds(st, STAGE_DW, exc, out, v0, v1, consumed), 1)) return consumed;
-    }
     Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, st};
     uint32_t a0, a1;
-    consumed = uniform(decode_block<CODEC>(CODEC, w, p, sum, n, out, exc, a0, a1));
+    const uint32_t consumed = uniform(decode_block<CODEC>(CODEC, w, p, sum, n, out, exc, a0, a1));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
     v0 = a0;
     v1 = a1;
     return consumed;
+}
+// block_optpfor, stage C: the 512 bytes from g (dword aligned) and the 256-byte side slot at gx -> LDS, by plain loads
+DS2I_DEV void rs_stage_block(const uint32_t* g, const uint32_t* gx, uint32_t* st, uint32_t* xs) {
+    const uint32_t lane = lane_id();
+    const uint32_t w0 = g[lane], w1 = g[lane + 64], x = gx[lane];
+    st[lane] = w0;
+    st[lane + 64] = w1;
+    xs[lane] = x;
+    wave_sync();
+}
+// block_optpfor: the partial last block of a list from the tail table (BatchArgs::tails; entry = sz gaps-1, sz freqs-1, bytes
+// of the docs part, bytes of the freqs part). part 0 = docs, 1 = freqs. Rare (once per list and unit at most): plain loads,
+// waited for here.
+DS2I_DEV uint32_t rs_tail(const uint32_t* tails, unsigned long long entry, uint32_t sz, uint32_t part, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const uint32_t* const t = tails + entry;
+    uint32_t a0 = (lane < sz) ? t[part * sz + lane] : 0u, a1 = (lane + 64 < sz) ? t[part * sz + lane + 64] : 0u;
+    uint32_t bytes = t[2u * sz + part];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(bytes)::"memory");
+    v0 = a0;
+    v1 = a1;
+    return uniform(bytes);
 }
 
 // CODEC: CODEC_OPTPFOR (block_optpfor) or CODEC_MIXED (block_mixed: a type byte in front of every full block; its OptPFor
@@ -209,9 +247,11 @@ DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32
 template <int NT, bool STATS, int CODEC = CODEC_OPTPFOR>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
     static_assert(NT >= 2 && NT <= 4, "exact list counts 2..4");
-    __shared__ LdsRS<NT> L;
+    constexpr bool SIDE = CODEC == CODEC_OPTPFOR; // exception side slots + tail table instead of the general decoders
+    constexpr int PF_LOADS = SIDE ? 3 : 2;        // hand-issued loads of one block prefetch (bytes, bytes + 256, side slot)
+    __shared__ LdsRS<NT, CODEC> L;
     const uint32_t lane = lane_id();
-    s16_table_init(L.exc);
+    if constexpr (!SIDE) s16_table_init(L.exc);
     typename std::conditional<STATS, uint32_t, NullCounter>::type s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
     typename std::conditional<STATS, unsigned long long, NullCounter>::type s_bytes;
     s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
@@ -258,6 +298,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         const uint32_t vl0 = 1u + (n0 >= (1u << 7)) + (n0 >= (1u << 14)) + (n0 >= (1u << 21)) + (n0 >= (1u << 28));
         const uint8_t* const data0 = a->arena + qt[0].list_off + vl0 + 4ull * nb0 + 4ull * (nb0 - 1);
         const float qw0 = qt[0].q_weight;
+        const uint32_t* const xs0 = SIDE ? a->xslots + (size_t)XSLOT_DW * qt[0].blk_base : nullptr; // list 0's side slots
         // ---- lists 1 .. NT-1: range table (hot), the rest of the QTerm is read when a candidate gets that far
         const uint8_t* rt[NT];
         uint32_t rsh[NT];
@@ -282,7 +323,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // block's bytes are in L.stb (from stb_base on). Only stage C touches them: they live in the lanes of one VGPR
         // (v_readlane / v_writelane at a constant lane) instead of ~20 SGPRs the hot loop would have to carry.
         uint32_t cold = 0xFFFFFFFFu;
-        enum { C_CUR = 0, C_BMAX = 1, C_SZ = 2, C_FOLO = 3, C_FOHI = 4, C_PER = 5, C_FOWNER = 60, C_SOWNER = 61, C_SBLO = 62, C_SBHI = 63 };
+        // (C_ND / C_CONS, side slots: exceptions and bytes of the block's docs part -- where its freqs part's adds and bytes start)
+        enum { C_CUR = 0, C_BMAX = 1, C_SZ = 2, C_FOLO = 3, C_FOHI = 4, C_ND = 5, C_CONS = 6, C_PER = 7, C_FOWNER = 60, C_SOWNER = 61, C_SBLO = 62, C_SBHI = 63 };
 #define cget(l) ((uint32_t)__builtin_amdgcn_readlane((int)cold, (l)))
 #define cset(l, v) rs_writelane<(l)>(cold, (v))
         cset(C_FOWNER, 0u);
@@ -338,8 +380,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 while (lvl < 2 && (t2 >> lsh) - (b2 >> lsh) >= 16u) { lsh += 6; ++lvl; }
                 const uint32_t lo = b2 >> lsh, hi = t2 >> lsh;
                 const bool fits = hi - lo < 16u;
-                const uint32_t m = max_of_bytes16(rt[j] + g.off[lvl] + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
-                LC(PH_PROLOG, lines_of(rt[j] + g.off[lvl] + (fits ? lo : 0u), true, 16u));
+                const uint64_t loff = lvl == 0 ? 0ull : lvl == 1 ? g.off[1] : g.off[2]; // (selects: a run-time index would put the array into scratch)
+                const uint32_t m = max_of_bytes16(rt[j] + loff + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
+                LC(PH_PROLOG, lines_of(rt[j] + loff + (fits ? lo : 0u), true, 16u));
                 const uint32_t best = (row && fits) ? m : 255u; // (255 = the list maximum)
                 dead = dead || best == 0u;
                 acc = acc + rsc[j] * (float)best;
@@ -382,13 +425,22 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         uint32_t dA0 = 0xFFFFFFFFu, dA1 = 0xFFFFFFFFu, dB0 = 0xFFFFFFFFu, dB1 = 0xFFFFFFFFu; // doc-ids (value lane, lane + 64)
         uint32_t gB0[NT] = {}, gB1[NT] = {};                                                    // range-table bytes of lists 1..
         uint32_t consA = 0, consB = 0, szA = 0, szB = 0; // bytes of the docs part, postings of the block
+        uint32_t ndA = 0, ndB = 0;                       // (side slots) exceptions of the docs part
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]);
-        uint32_t bufB = 0, bufA = 1, bufN = 2;
+        uint32_t xs_base = 0;
+        if constexpr (SIDE) xs_base = rs_lds_offset(&L.xs[0][0]);
         const uint32_t voff = lane * 4u;
+        // request the bytes (and the side slot) of block `blk` of list 0 into staging buffer `buf`
+        auto prefetch = [&](const Blk& o, uint32_t buf) __attribute__((always_inline)) {
+            const uint8_t* const g = rs_uniform_ptr((const uint8_t*)((uintptr_t)(data0 + o.ep) & ~(uintptr_t)3));
+            if constexpr (SIDE) rs_prefetch_blk(g, st_base + buf * (STAGE_DW * 4u), rs_uniform_ptr(xs0 + (size_t)XSLOT_DW * o.blk), xs_base + buf * (XSLOT_DW * 4u), voff);
+            else rs_prefetch512(g, st_base + buf * (STAGE_DW * 4u), voff);
+        };
+        uint32_t bufB = 0, bufA = 1, bufN = 2;
         bool finished = false;
         haveA = select(u.blk_begin, A);
-        if (haveA) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + A.ep) & ~(uintptr_t)3), st_base + bufA * (STAGE_DW * 4u), voff);
+        if (haveA) prefetch(A, bufA);
         while (haveA || haveB) {
             Blk N{};
             bool haveN = false;
@@ -399,11 +451,16 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 haveN = select(A.blk + 1, N); // as things stand now: the heap may still rule it out before its turn
                 // A's bytes were requested an iteration ago; the only loads issued after them are B's two gathers
                 if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
-                if (haveN) rs_prefetch512((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), voff);
+                if (haveN) prefetch(N, bufN);
                 if (haveN) LC(PH_STREAM, lines_of((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3) + 8u * lane, true, 8u));
                 szA = ((A.blk + 1) * 128u <= n0) ? 128u : (n0 & 127u);
                 uint32_t v0, v1;
-                consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
+                if constexpr (SIDE) {
+                    if (__builtin_expect(szA == 128u, 1)) consA = optpfor_decode_side(L.stage[bufA], STAGE_DW, L.xs[bufA], data0 + A.ep, rs_args()->xovf, 0u, 0u, v0, v1, &ndA);
+                    else consA = rs_tail(rs_args()->tails, qt[0].aux1, szA, 0u, v0, v1);
+                } else {
+                    consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
+                }
                 const uint32_t g0 = (lane < szA) ? v0 + 1u : 0u, g1 = (lane + 64 < szA) ? v1 + 1u : 0u;
                 const uint32_t i0 = wave_incl_scan(g0);
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
@@ -415,8 +472,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             }
             if (haveB) {
                 // ---------------- stage B: the gathers of block B, issued before stage A ran; the only loads issued after them are
-                // the two of the prefetch above
-                if (haveA && haveN) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                // those of the prefetch above
+                if (haveA && haveN) rs_wait_vm<PF_LOADS>(); else rs_wait_vm<0>();
                 gB0[1] = L.gb[0][lane];
                 gB1[1] = L.gb[1][lane];
                 bool ok0 = (dB0 != 0xFFFFFFFFu) & (gB0[1] != 0u), ok1 = (dB1 != 0xFFFFFFFFu) & (gB1[1] != 0u);
@@ -522,20 +579,23 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     const float* const norm_lens = rs_args()->norm_lens;
                     const uint8_t* const arena = rs_args()->arena;
                     uint32_t fv0, fv1, consF;
-                    {
-                        const uint8_t* p = data0 + B.ep; // (full blocks are dword aligned and a multiple of 4 bytes long)
-                        uint32_t* const stB = L.stage[bufB];
-                        const uint32_t skip_dw = consB >> 2;
-                        if (CODEC == CODEC_OPTPFOR && szB == 128u && ((uintptr_t)p & 3u) == 0u && (consB & 3u) == 0u && skip_dw < STAGE_DW &&
-                            optpfor_decode_lds(stB + skip_dw, STAGE_DW - skip_dw, L.exc, L.out, fv0, fv1, consF)) {
+                    if constexpr (SIDE) {
+                        if (__builtin_expect(szB == 128u, 1)) {
+                            const uint32_t skip_dw = consB >> 2; // (the bytes of the whole block are still staged)
+                            consF = optpfor_decode_side(L.stage[bufB] + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, L.xs[bufB], data0 + B.ep + consB,
+                                                        rs_args()->xovf, 1u, ndB, fv0, fv1);
                         } else {
-                            Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, stB};
-                            uint32_t a0, a1;
-                            consF = uniform(decode_block<CODEC>(CODEC, w, p + consB, 0xFFFFFFFFu, szB, L.out, L.exc, a0, a1));
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
-                            fv0 = a0;
-                            fv1 = a1;
+                            consF = rs_tail(rs_args()->tails, qt[0].aux1, szB, 1u, fv0, fv1);
                         }
+                    } else {
+                        const uint8_t* p = data0 + B.ep;
+                        uint32_t* const stB = L.stage[bufB];
+                        Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, stB};
+                        uint32_t a0, a1;
+                        consF = uniform(decode_block<CODEC>(CODEC, w, p + consB, 0xFFFFFFFFu, szB, L.out, L.exc, a0, a1));
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
+                        fv0 = a0;
+                        fv1 = a1;
                     }
                     ++s_freqs_blocks;
                     s_bytes += consF;
@@ -599,13 +659,27 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                     continue; // (the list stays where it was: the next search restarts there)
                                 }
                                 const uint8_t* pb = dataj + fb.ep;
-                                Window wb{nullptr, 0, L.stb};
-                                wb.load(pb, STAGE_DW * 4u - 4u);
                                 LC(PH_C_BDOCS, 1);
                                 LC(PH_DOCS, lines_of(pb + 8u * lane, true, 8u));
                                 const uint32_t szb = ((fb.blk + 1) * 128u <= nj) ? 128u : (nj & 127u);
-                                uint32_t v0, v1;
-                                const uint32_t consD = uniform(decode_block<CODEC>(CODEC, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
+                                uint32_t v0, v1, consD, ndj = 0;
+                                unsigned long long sb = 0;
+                                if constexpr (SIDE) {
+                                    if (__builtin_expect(szb == 128u, 1)) { // (full blocks of a block_optpfor list are dword aligned)
+                                        rs_stage_block((const uint32_t*)pb, rs_args()->xslots + (size_t)XSLOT_DW * (tj->blk_base + fb.blk), L.stb, L.xsb);
+                                        consD = optpfor_decode_side(L.stb, STAGE_DW, L.xsb, pb, rs_args()->xovf, 0u, 0u, v0, v1, &ndj);
+                                        cset(C_SOWNER, (uint32_t)j);
+                                    } else {
+                                        consD = rs_tail(rs_args()->tails, tj->aux1, szb, 0u, v0, v1);
+                                        if (cget(C_SOWNER) == (uint32_t)j) cset(C_SOWNER, 0u);
+                                    }
+                                } else {
+                                    Window wb{nullptr, 0, L.stb};
+                                    wb.load(pb, STAGE_DW * 4u - 4u);
+                                    consD = uniform(decode_block<CODEC>(CODEC, wb, pb, fb.bmax - fb.base - (szb - 1), szb, dj, L.exc, v0, v1));
+                                    sb = (unsigned long long)(uintptr_t)wb.gbase;
+                                    cset(C_SOWNER, (uint32_t)j);
+                                }
                                 const uint32_t g0 = (lane < szb) ? v0 + 1u : 0u, g1 = (lane + 64 < szb) ? v1 + 1u : 0u;
                                 const uint32_t i0 = wave_incl_scan(g0);
                                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
@@ -615,15 +689,18 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 curj = fb.blk;
                                 bmj = fb.bmax;
                                 const unsigned long long fo = (unsigned long long)(pb + consD - arena);
-                                const unsigned long long sb = (unsigned long long)(uintptr_t)wb.gbase;
                                 cset(CB + C_CUR, curj);
                                 cset(CB + C_BMAX, bmj);
                                 cset(CB + C_SZ, szb);
                                 cset(CB + C_FOLO, (uint32_t)fo);
                                 cset(CB + C_FOHI, (uint32_t)(fo >> 32));
-                                cset(C_SOWNER, (uint32_t)j);
-                                cset(C_SBLO, (uint32_t)sb);
-                                cset(C_SBHI, (uint32_t)(sb >> 32));
+                                if constexpr (SIDE) {
+                                    cset(CB + C_ND, ndj);
+                                    cset(CB + C_CONS, consD);
+                                } else {
+                                    cset(C_SBLO, (uint32_t)sb);
+                                    cset(C_SBHI, (uint32_t)(sb >> 32));
+                                }
                                 if (cget(C_FOWNER) == (uint32_t)j) cset(C_FOWNER, 0u);
                                 ++s_docs_blocks;
                                 s_bytes += 4 + consD;
@@ -661,16 +738,31 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             if (ballot(m0) | ballot(m1)) { // members take list j's term score at once
                                 if (cget(C_FOWNER) != (uint32_t)j) {
                                     const uint8_t* pf = arena + (((unsigned long long)cget(CB + C_FOHI) << 32) | cget(CB + C_FOLO));
-                                    const uint8_t* sbase = (const uint8_t*)(uintptr_t)(((unsigned long long)cget(C_SBHI) << 32) | cget(C_SBLO));
-                                    Window wf{sbase, STAGE_DW * 4u, L.stb};
-                                    if (cget(C_SOWNER) != (uint32_t)j || !wf.covers(pf, 64)) {
-                                        wf.load(pf, 256u);
-                                        LC(PH_C_BFREQS, 1);
-                                        LC(PH_PROBE, lines_of(pf + 4u * lane, true, 4u));
-                                        cset(C_SOWNER, 0u); // (the window no longer starts at the block)
+                                    uint32_t v0, v1, consF2;
+                                    if constexpr (SIDE) {
+                                        const uint32_t szj = cget(CB + C_SZ);
+                                        if (__builtin_expect(szj == 128u, 1)) {
+                                            const uint32_t skip_dw = cget(CB + C_CONS) >> 2;
+                                            if (cget(C_SOWNER) != (uint32_t)j) { // (3+ lists: another list's block took the window since)
+                                                rs_stage_block((const uint32_t*)(pf - 4u * skip_dw), rs_args()->xslots + (size_t)XSLOT_DW * (tj->blk_base + curj), L.stb, L.xsb);
+                                                LC(PH_C_BFREQS, 1);
+                                                cset(C_SOWNER, (uint32_t)j);
+                                            }
+                                            consF2 = optpfor_decode_side(L.stb + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, L.xsb, pf, rs_args()->xovf, 1u, cget(CB + C_ND), v0, v1);
+                                        } else {
+                                            consF2 = rs_tail(rs_args()->tails, tj->aux1, szj, 1u, v0, v1);
+                                        }
+                                    } else {
+                                        const uint8_t* sbase = (const uint8_t*)(uintptr_t)(((unsigned long long)cget(C_SBHI) << 32) | cget(C_SBLO));
+                                        Window wf{sbase, STAGE_DW * 4u, L.stb};
+                                        if (cget(C_SOWNER) != (uint32_t)j || !wf.covers(pf, 64)) {
+                                            wf.load(pf, 256u);
+                                            LC(PH_C_BFREQS, 1);
+                                            LC(PH_PROBE, lines_of(pf + 4u * lane, true, 4u));
+                                            cset(C_SOWNER, 0u); // (the window no longer starts at the block)
+                                        }
+                                        consF2 = decode_block<CODEC>(CODEC, wf, pf, 0xFFFFFFFFu, cget(CB + C_SZ), L.fj, L.exc, v0, v1);
                                     }
-                                    uint32_t v0, v1;
-                                    const uint32_t consF2 = decode_block<CODEC>(CODEC, wf, pf, 0xFFFFFFFFu, cget(CB + C_SZ), L.fj, L.exc, v0, v1);
                                     L.fj[lane] = v0 + 1u;
                                     L.fj[lane + 64] = v1 + 1u;
                                     wave_sync();
@@ -714,6 +806,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             dB1 = dA1;
             consB = consA;
             szB = szA;
+            ndB = ndA;
             if (haveB) {
                 // one byte per candidate from list 1's table (the other lists' bytes are fetched in stage B for the candidates inside
                 // list 1's ranges only: a gather is one cache-line request per lane, and most candidates die at list 1)

@@ -215,7 +215,12 @@ public:
             });
         for (auto& t : pool) t.join();
         for (auto const& e : errors) if (!e.empty()) throw std::runtime_error(e);
+        static std::atomic<uint64_t> generation(0);
+        m_id = ++generation;
     }
+    // identity of this set among all sets the process ever built: what a query operator keys its per-replica pipelines on
+    // (the address of a set can be reused by a later one)
+    uint64_t id() const { return m_id; }
     size_t replicas() const { return m_replicas.size(); }
     gpu_index const& replica(size_t i) const { return *m_replicas[i]; }
     size_t size() const { return m_replicas[0]->size(); }
@@ -231,6 +236,7 @@ public:
 
 private:
     std::vector<std::unique_ptr<gpu_index>> m_replicas;
+    uint64_t m_id = 0;
 };
 
 // the query-operator concept over a replica set: same calls, same answers as gpu_query_op over one index.
@@ -260,10 +266,10 @@ public:
             m_stats = m_ops[0].stats();
             return m_counts;
         }
-        if (m_pipes.size() != parts || m_pipes_of != &set) {
+        if (m_pipes.size() != parts || m_pipes_of != set.id()) {
             m_pipes.clear();
             for (size_t r = 0; r < parts; ++r) m_pipes.emplace_back(new gpu_pipeline(set.replica(r), 2));
-            m_pipes_of = &set;
+            m_pipes_of = set.id();
         }
         m_counts.assign(n, 0);
         m_topk.assign(n, std::vector<float>());
@@ -305,7 +311,16 @@ public:
         for (size_t r = 1; r < parts; ++r) pool.emplace_back(worker, r);
         worker(0);
         for (auto& t : pool) t.join();
-        for (auto const& e : errors) if (!e.empty()) throw std::runtime_error(e);
+        for (auto const& e : errors)
+            if (!e.empty()) {
+                // a failed ticket leaves its replica's other tickets submitted and un-waited: the cached pipelines would answer
+                // the next batch with DS2I_EBUSY. Drop them (destroying a pipeline waits for what it has in flight) and the
+                // half-filled answers; the next call starts from fresh pipelines.
+                release();
+                m_counts.clear();
+                m_topk.clear();
+                throw std::runtime_error(e);
+            }
         for (size_t r = 0; r < parts; ++r) {
             m_stats.kernel_ms = std::max(m_stats.kernel_ms, stats[r].kernel_ms);
             m_stats.docs_blocks_decoded += stats[r].docs_blocks_decoded;
@@ -325,6 +340,12 @@ public:
     std::vector<std::vector<float>> const& topk_batch() const { return m_topk; } // one entry per query (empty for and / or)
     ds2i_hip_stats const& stats() const { return m_stats; } // kernel_ms = busiest replica (sum of its tickets' windows), counters summed
     void collect_counters(bool on) { m_counters = on; }
+    // drops the per-replica pipelines (they hold device buffers of the set's indexes): call it before the set is destroyed if
+    // the operator is to outlive it; the next batch creates new ones
+    void release() {
+        m_pipes.clear();
+        m_pipes_of = 0;
+    }
     static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
     // queries per ticket: about eight tickets per replica, never fewer than 64 queries (a ticket is a kernel launch)
     static size_t ticket_size(size_t n, size_t parts) { return std::max<size_t>(64, (n + parts * 8 - 1) / (parts * 8)); }
@@ -334,7 +355,7 @@ private:
     bool m_counters = false;
     std::vector<gpu_query_op<OP>> m_ops;
     std::vector<std::unique_ptr<gpu_pipeline>> m_pipes;
-    gpu_index_set const* m_pipes_of = nullptr;
+    uint64_t m_pipes_of = 0; // gpu_index_set::id() the pipelines belong to (0 = none)
     std::vector<uint64_t> m_counts;
     std::vector<std::vector<float>> m_topk;
     ds2i_hip_stats m_stats{};

@@ -6,6 +6,9 @@
 //   enumerate <index_type> <index_file> <term> next
 //   enumerate <index_type> <index_file> <term> next_geq <lower_bound>...
 //   enumerate <index_type> <index_file> <term> move <position>...
+//   enumerate <index_type> <index_file> <replicas> set_recovery   (self-check of set_query<> over N replicas on device 0: a batch
+//                                                                  holding an out-of-range term fails, the next batch on the
+//                                                                  SAME operator object is answered, equal to one replica's answer)
 #include <cstdlib>
 
 #include "../include/ds2i_hip.hpp"
@@ -23,6 +26,22 @@ int main(int argc, const char** argv) {
     }
     try {
         tool::mapped_file m(argv[2]);
+        if (std::string(argv[4]) == "set_recovery") {
+            const size_t parts = std::max<size_t>(1, std::strtoull(argv[3], nullptr, 10));
+            ds2i_hip::gpu_index_set set(kind, m.data, m.size, nullptr, 0, std::vector<int>(parts, 0));
+            std::vector<ds2i_hip::term_id_vec> good;
+            for (uint32_t q = 0; q < 1200; ++q) good.push_back({q % (uint32_t)set.size(), (q * 7 + 3) % (uint32_t)set.size()});
+            std::vector<ds2i_hip::term_id_vec> bad = good;
+            bad[bad.size() / 2].push_back((uint32_t)set.size() + 5); // term id out of range: DS2I_ETERM for its ticket
+            ds2i_hip::set_query<DS2I_OP_AND> op;
+            bool threw = false;
+            try { op(set, bad); } catch (std::exception const&) { threw = true; }
+            const std::vector<uint64_t> got = op(set, good); // (poisoned pipelines would say DS2I_EBUSY here)
+            ds2i_hip::gpu_query_op<DS2I_OP_AND> one;
+            const std::vector<uint64_t> want = one(set.replica(0), good);
+            std::printf("threw %d equal %d n %zu\n", threw ? 1 : 0, got == want ? 1 : 0, got.size());
+            return (threw && got == want) ? 0 : 3;
+        }
         ds2i_hip::gpu_index index(kind, m.data, m.size);
         auto e = index[(size_t)std::strtoull(argv[3], nullptr, 10)];
         const std::string mode = argv[4];

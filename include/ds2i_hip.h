@@ -127,6 +127,10 @@ typedef struct ds2i_hip_index_info {
     int has_bitmaps;
     int has_membership_hints;    /* one more byte per level-1 range-table entry (block_optpfor indexes): see ds2i_hip_list_range_table */
     int range_table_entries_per_posting; /* DS2I_RMW_G in effect */
+    uint64_t side_table_bytes;   /* block_optpfor: exception side slots (256 B per block: the OptPFor exceptions of a block as position
+                                  * masks + values, so that a decode never parses the Simple16 streams), their overflow area, and the
+                                  * lists' partial last blocks in plain form; 0 = not built (DS2I_NO_XSLOTS, other index kinds, no room) */
+    int has_side_tables;
 } ds2i_hip_index_info;
 int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out);
 /* document_enumerator::size() of index[term] (block_posting_list.hpp:178-181) */

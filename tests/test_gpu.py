@@ -856,6 +856,22 @@ def test_cpp_adaptor_document_enumerator(coll, images, tmp_path):
             assert got[-1, 0] == docs[0] and got[-1, 1] == 0  # reset()
 
 
+def test_cpp_set_query_recovers_after_a_failed_batch(images, tmp_path):
+    """gpu_set_query_op caches one pipeline per replica. A batch in which one ticket fails (out-of-range term id)
+    used to leave that replica's other tickets submitted and un-waited, and the next batch on the same operator object
+    answered DS2I_EBUSY. The `enumerate ... set_recovery` self-check runs exactly that sequence over 3 replicas on this
+    device: the bad batch throws, the good batch that follows equals one replica's answer."""
+    import os
+    import subprocess
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ds2i_amd", "tools")
+    subprocess.check_call(["make", "-C", tools, "-s"])
+    path = tmp_path / "idx_block_optpfor"
+    path.write_bytes(images[0]["block_optpfor"])
+    out = subprocess.run([os.path.join(tools, "enumerate"), "block_optpfor", str(path), "3", "set_recovery"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.strip() == "threw 1 equal 1 n 1200"
+
+
 def test_block_profile_and_hybrid_optimiser(coll, queries, images):
     """GPU block-access profile (ds2i_hip_batch_block_profile) -> block_mixed optimiser (ds2i_hybrid_*) -> the
     optimised index answers every operator like the oracle, and its profile-weighted model time is lower than the
