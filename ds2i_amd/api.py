@@ -463,7 +463,7 @@ class Batch:
 
     def phase_cycles(self, cls):
         names = ("total", "docs", "freqs", "find", "member", "score", "topk", "prolog", "probe", "insert", "stream", "prefetch", "floor", "unit",
-                 "n_visit", "n_surv1", "n_surv2", "n_bdocs", "n_bfreqs", "n_heap", "n_liverounds")
+                 "n_visit", "n_surv1", "n_surv2", "n_bdocs", "n_bfreqs", "n_heap", "n_liverounds", "n_alive", "n_gblocks")
         out = np.zeros(len(names), dtype=np.uint64)
         _check(lib().ds2i_hip_batch_phase_cycles(self._h, cls, _ptr(out), len(names)))
         return dict(zip(names, out.tolist()))

@@ -32,7 +32,7 @@ struct QTerm {
 static_assert(sizeof(QTerm) == 80, "QTerm is an 80-byte device record");
 
 enum { PH_TOTAL = 0, PH_DOCS, PH_FREQS, PH_FIND, PH_MEMBER, PH_SCORE, PH_TOPK, PH_PROLOG, PH_PROBE, PH_INSERT, PH_STREAM, PH_PREFETCH, PH_FLOOR, PH_UNIT,
-       PH_C_VISIT, PH_C_SURV1, PH_C_SURV2, PH_C_BDOCS, PH_C_BFREQS, PH_C_HEAP, PH_C_LIVEROUNDS, /* event counts of the diagnostic build */ PH_COUNT };
+       PH_C_VISIT, PH_C_SURV1, PH_C_SURV2, PH_C_BDOCS, PH_C_BFREQS, PH_C_HEAP, PH_C_LIVEROUNDS, PH_C_ALIVE, PH_C_GBLOCKS, /* event counts of the diagnostic build */ PH_COUNT };
 struct Stats {
     unsigned long long docs_blocks, freqs_blocks, block_max_examined, algorithmic_bytes, postings_scored, rounds;
     unsigned long long phase_cycles[PH_COUNT]; // summed over waves; only filled with -DDS2I_PHASE_TIMING

@@ -206,9 +206,10 @@ template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)"
 // block_mixed: any block -> gaps or freqs-1 in (v0, v1), value i in lane i & 63, slot i >> 6, through the general decoders;
 // made opaque, so that no output of this function is ever "pending on vmcnt" for the compiler: the caller's prefetches and
 // gathers stay in flight across it.
+// (st holds the 512 bytes from `wbase` rounded down to a dword on; p = the part to decode, inside or beyond them)
 template <int CODEC>
-DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out, uint32_t* exc, uint32_t& v0, uint32_t& v1) {
-    Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, st};
+DS2I_DEV uint32_t rs_decode(uint32_t* st, const uint8_t* wbase, const uint8_t* p, uint32_t sum, uint32_t n, uint32_t* out, uint32_t* exc, uint32_t& v0, uint32_t& v1) {
+    Window w{(const uint8_t*)((uintptr_t)wbase & ~(uintptr_t)3), STAGE_DW * 4u, st};
     uint32_t a0, a1;
     const uint32_t consumed = uniform(decode_block<CODEC>(CODEC, w, p, sum, n, out, exc, a0, a1));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
@@ -256,6 +257,15 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
     typename std::conditional<STATS, unsigned long long, NullCounter>::type s_bytes;
     s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
     s_bytes = 0;
+#ifdef DS2I_RS_PHASE
+    // diagnostic build (-DDS2I_RS_PHASE, instrumented runs): shader cycles of a wave by where it spends them, reported through
+    // Stats::phase_cycles (profiles/probes/rs_phase_probe.py). PT(slot) closes the interval since the previous PT and books it.
+    unsigned long long pt[PH_COUNT] = {};
+    unsigned long long pt_prev = __builtin_readcyclecounter();
+#define PT(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); pt[slot] += t_ - pt_prev; pt_prev = t_; } while (0)
+#else
+#define PT(slot) ((void)0)
+#endif
 #ifdef DS2I_LINE_COUNT
     // diagnostic build: distinct 128-byte lines requested by the hand-placed gathers, by purpose (reported through Stats::phase_cycles)
     unsigned long long lc[PH_COUNT] = {};
@@ -310,6 +320,14 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             rsc[j] = qt[j].rmw_scale;
         };
         rs_for<1, NT>(bind_one);
+        // what lists 1.. can add to any document at most (their list maxima), and the collection's shortest document: a posting of
+        // list 0 with freq f scores at most qw0 * doc_term_weight(f, min_nl) there (doc_term_weight falls with norm_len)
+        float rest_all = 0.f;
+        {
+            auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest_all = rest_all + rsc[j] * 255.0f; };
+            rs_for_down<NT, 1>(add_max);
+        }
+        const float min_nl = a->min_norm_len;
         const long long hdelta = a->rmh ? (long long)(a->rmh - a->rmw) : 0ll; // hint of an entry = the byte at the same offset of the parallel buffer
         // Three and four lists: the byte fetched ahead for every candidate is list 1's HINT, not its weight. A weight byte lets a
         // candidate through whenever its range holds any posting (one candidate in 4..6, each then costing a line per further
@@ -426,6 +444,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         uint32_t gB0[NT] = {}, gB1[NT] = {};                                                    // range-table bytes of lists 1..
         uint32_t consA = 0, consB = 0, szA = 0, szB = 0; // bytes of the docs part, postings of the block
         uint32_t ndA = 0, ndB = 0;                       // (side slots) exceptions of the docs part
+        uint32_t fA0 = 1, fA1 = 1, fB0 = 1, fB1 = 1;     // freqs of the block's postings
+        float boA0 = 0.f, boA1 = 0.f, boB0 = 0.f, boB1 = 0.f; // freq-only bound of their list-0 term score
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]);
         uint32_t xs_base = 0;
@@ -441,6 +461,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         bool finished = false;
         haveA = select(u.blk_begin, A);
         if (haveA) prefetch(A, bufA);
+        PT(PH_UNIT);
         while (haveA || haveB) {
             Blk N{};
             bool haveN = false;
@@ -448,9 +469,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // ---------------- stage A: the bytes of the block after A requested, A's docs decoded
                 ++s_rounds;
                 if (shared_floor && (floor_tick++ & (DS2I_RS_FLOOR_EVERY - 1)) == 0) adopt_floor();
+                PT(PH_FLOOR);
                 haveN = select(A.blk + 1, N); // as things stand now: the heap may still rule it out before its turn
+                PT(PH_STREAM);
                 // A's bytes were requested an iteration ago; the only loads issued after them are B's two gathers
                 if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                PT(PH_PREFETCH);
                 if (haveN) prefetch(N, bufN);
                 if (haveN) LC(PH_STREAM, lines_of((const uint8_t*)((uintptr_t)(data0 + N.ep) & ~(uintptr_t)3) + 8u * lane, true, 8u));
                 szA = ((A.blk + 1) * 128u <= n0) ? 128u : (n0 & 127u);
@@ -459,7 +483,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     if (__builtin_expect(szA == 128u, 1)) consA = optpfor_decode_side(L.stage[bufA], STAGE_DW, L.xs[bufA], data0 + A.ep, rs_args()->xovf, 0u, 0u, v0, v1, &ndA);
                     else consA = rs_tail(rs_args()->tails, qt[0].aux1, szA, 0u, v0, v1);
                 } else {
-                    consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
+                    consA = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, data0 + A.ep, A.bmax - A.base - (szA - 1), szA, L.out, L.exc, v0, v1);
                 }
                 const uint32_t g0 = (lane < szA) ? v0 + 1u : 0u, g1 = (lane + 64 < szA) ? v1 + 1u : 0u;
                 const uint32_t i0 = wave_incl_scan(g0);
@@ -469,14 +493,42 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 ++s_docs_blocks;
                 s_bm_examined += 1;
                 s_bytes += 8 + consA; // block_max + endpoint + docs part
+                PT(PH_DOCS);
+                // The block's freqs right away (its bytes are staged, the side slot holds its exceptions): every posting gets a bound
+                // of its OWN list-0 term score from its freq alone. Only the candidates that could enter the heap with that bound +
+                // the other lists' maxima ask list 1's table at all -- a gather is a cache line per candidate, and with the heap
+                // warm nine candidates in ten fall here -- and the tests of stage B use the candidate's own bound where they used
+                // the block's weight.
+                uint32_t fv0, fv1, consF;
+                if constexpr (SIDE) {
+                    if (__builtin_expect(szA == 128u, 1)) {
+                        const uint32_t skip_dw = consA >> 2;
+                        consF = optpfor_decode_side(L.stage[bufA] + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, L.xs[bufA], data0 + A.ep + consA,
+                                                    rs_args()->xovf, 1u, ndA, fv0, fv1);
+                    } else {
+                        consF = rs_tail(rs_args()->tails, qt[0].aux1, szA, 1u, fv0, fv1);
+                    }
+                } else {
+                    consF = rs_decode<CODEC>(L.stage[bufA], data0 + A.ep, data0 + A.ep + consA, 0xFFFFFFFFu, szA, L.out, L.exc, fv0, fv1);
+                }
+                ++s_freqs_blocks;
+                s_bytes += consF;
+                fA0 = fv0 + 1u;
+                fA1 = fv1 + 1u;
+                boA0 = qw0 * doc_term_weight(fA0, min_nl);
+                boA1 = qw0 * doc_term_weight(fA1, min_nl);
+                PT(PH_FREQS);
             }
             if (haveB) {
                 // ---------------- stage B: the gathers of block B, issued before stage A ran; the only loads issued after them are
                 // those of the prefetch above
                 if (haveA && haveN) rs_wait_vm<PF_LOADS>(); else rs_wait_vm<0>();
+                PT(PH_TOPK);
                 gB0[1] = L.gb[0][lane];
                 gB1[1] = L.gb[1][lane];
-                bool ok0 = (dB0 != 0xFFFFFFFFu) & (gB0[1] != 0u), ok1 = (dB1 != 0xFFFFFFFFu) & (gB1[1] != 0u);
+                // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
+                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (gB0[1] != 0u);
+                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (gB1[1] != 0u);
                 if (hint_first) {
                     ok0 = ok0 & ((gB0[1] == 255u) | (gB0[1] == rmh_code(dB0, rsh[1])));
                     ok1 = ok1 & ((gB1[1] == 255u) | (gB1[1] == rmh_code(dB1, rsh[1])));
@@ -514,8 +566,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     float rest = 0.f;
                     auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest = rest + rsc[j] * 255.0f; };
                     rs_for_down<NT, 2>(add_max);
-                    ok0 = ok0 & enters((B.wq + (rest + rsc[1] * (float)gB0[1])) * BOUND_SLACK);
-                    ok1 = ok1 & enters((B.wq + (rest + rsc[1] * (float)gB1[1])) * BOUND_SLACK);
+                    ok0 = ok0 & enters((boB0 + (rest + rsc[1] * (float)gB0[1])) * BOUND_SLACK);
+                    ok1 = ok1 & enters((boB1 + (rest + rsc[1] * (float)gB1[1])) * BOUND_SLACK);
                     if (ballot(ok0) | ballot(ok1)) {
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
@@ -550,8 +602,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     return r;
                 };
                 float r0 = rest_of(gB0, 0), r1 = rest_of(gB1, 0);
-                ok0 = ok0 & enters((B.wq + r0) * BOUND_SLACK);
-                ok1 = ok1 & enters((B.wq + r1) * BOUND_SLACK);
+                ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
+                ok1 = ok1 & enters((boB1 + r1) * BOUND_SLACK);
                 LC(PH_C_VISIT, __builtin_popcountll(ballot(dB0 != 0xFFFFFFFFu)) + __builtin_popcountll(ballot(dB1 != 0xFFFFFFFFu)));
                 if (!hint_first) LC(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 if (!hint_first && hdelta && (ballot(ok0) | ballot(ok1))) {
@@ -570,40 +622,14 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     rs_for<1, NT>(hint_one);
                 }
                 LC(PH_C_SURV2, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
+                PT(PH_MEMBER);
                 if (__builtin_expect((ballot(ok0) | ballot(ok1)) != 0, 0)) {
                     LC(PH_C_LIVEROUNDS, 1);
                     // ---------------- stage C: somebody of block B may enter the heap
-                    // freqs of the block (its bytes are still staged), freq-only bound (doc_term_weight falls with norm_len, so the
-                    // collection's shortest document bounds the term score from the freq alone), norm_len, exact list-0 score
-                    const float min_nl = rs_args()->min_norm_len;
+                    // norm_len, exact list-0 score (the freqs were decoded in stage A)
                     const float* const norm_lens = rs_args()->norm_lens;
                     const uint8_t* const arena = rs_args()->arena;
-                    uint32_t fv0, fv1, consF;
-                    if constexpr (SIDE) {
-                        if (__builtin_expect(szB == 128u, 1)) {
-                            const uint32_t skip_dw = consB >> 2; // (the bytes of the whole block are still staged)
-                            consF = optpfor_decode_side(L.stage[bufB] + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, L.xs[bufB], data0 + B.ep + consB,
-                                                        rs_args()->xovf, 1u, ndB, fv0, fv1);
-                        } else {
-                            consF = rs_tail(rs_args()->tails, qt[0].aux1, szB, 1u, fv0, fv1);
-                        }
-                    } else {
-                        const uint8_t* p = data0 + B.ep;
-                        uint32_t* const stB = L.stage[bufB];
-                        Window w{(const uint8_t*)((uintptr_t)p & ~(uintptr_t)3), STAGE_DW * 4u, stB};
-                        uint32_t a0, a1;
-                        consF = uniform(decode_block<CODEC>(CODEC, w, p + consB, 0xFFFFFFFFu, szB, L.out, L.exc, a0, a1));
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1)::"memory");
-                        fv0 = a0;
-                        fv1 = a1;
-                    }
-                    ++s_freqs_blocks;
-                    s_bytes += consF;
-                    const uint32_t f0 = fv0 + 1u, f1 = fv1 + 1u;
-#ifndef DS2I_RS_NO_FREQ_BOUND
-                    ok0 = ok0 & enters((qw0 * doc_term_weight(f0, min_nl) + r0) * BOUND_SLACK);
-                    ok1 = ok1 & enters((qw0 * doc_term_weight(f1, min_nl) + r1) * BOUND_SLACK);
-#endif
+                    const uint32_t f0 = fB0, f1 = fB1;
                     const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
                     LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
                     float pa0 = qw0 * doc_term_weight(f0, nl0), pa1 = qw0 * doc_term_weight(f1, nl1);
@@ -797,6 +823,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     }
                 }
             }
+            PT(PH_SCORE);
             if (__builtin_expect(finished, 0)) break;
             // ---------------- rotate: A becomes B (its gathers are issued now and consumed an iteration later, behind the next
             // block's decode), the block whose bytes were requested becomes A
@@ -807,20 +834,30 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             consB = consA;
             szB = szA;
             ndB = ndA;
+            fB0 = fA0;
+            fB1 = fA1;
+            boB0 = boA0;
+            boB1 = boA1;
+            // only the candidates whose own bound + the other lists' maxima can still enter the heap ask list 1's table (the others
+            // read entry 0: one shared line); a block without any such candidate is done
+            const bool al0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK), al1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK);
+            haveB = haveB && (ballot(al0) | ballot(al1)) != 0;
+            if (haveB) { LC(PH_C_ALIVE, __builtin_popcountll(ballot(al0)) + __builtin_popcountll(ballot(al1))); LC(PH_C_GBLOCKS, 1); }
             if (haveB) {
                 // one byte per candidate from list 1's table (the other lists' bytes are fetched in stage B for the candidates inside
                 // list 1's ranges only: a gather is one cache-line request per lane, and most candidates die at list 1)
-                rs_gather_u8(gt1, (dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1], gb_base);
-                rs_gather_u8(gt1, (dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1], gb_base + 256u);
-                LC(PH_TOPK, lines_of(gt1 + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u));
+                rs_gather_u8(gt1, (al0 ? dB0 : 0u) >> rsh[1], gb_base);
+                rs_gather_u8(gt1, (al1 ? dB1 : 0u) >> rsh[1], gb_base + 256u);
+                LC(PH_TOPK, lines_of(gt1 + ((al0 ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((al1 ? dB1 : 0u) >> rsh[1]), true, 1u));
 #ifdef DS2I_LINE_COUNT
                 {   // the same lines by the width of list 1's ranges (shift 0 = one doc-id per byte: the densest lists)
-                    const uint32_t nl = lines_of(gt1 + ((dB0 != 0xFFFFFFFFu ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((dB1 != 0xFFFFFFFFu ? dB1 : 0u) >> rsh[1]), true, 1u);
+                    const uint32_t nl = lines_of(gt1 + ((al0 ? dB0 : 0u) >> rsh[1]), true, 1u) + lines_of(gt1 + ((al1 ? dB1 : 0u) >> rsh[1]), true, 1u);
                     const uint32_t shv = rsh[1];
                     if (shv == 0) lc[PH_TOTAL] += nl; else if (shv == 1) lc[PH_INSERT] += nl; else if (shv == 2) lc[PH_PREFETCH] += nl; else if (shv <= 4) lc[PH_FLOOR] += nl; else lc[PH_UNIT] += nl;
                 }
 #endif
             }
+            PT(PH_PROBE);
             A = N;
             haveA = haveN;
             const uint32_t t = bufB;
@@ -828,6 +865,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             bufA = bufN;
             bufN = t;
         }
+        PT(PH_TOTAL);
         rs_wait_vm<0>(); // (a unit left early -- list exhausted -- may still have a prefetch or gathers in flight)
 #undef cget
 #undef cset
@@ -855,8 +893,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 #ifdef DS2I_LINE_COUNT
         for (int i = 0; i < PH_COUNT; ++i) if (lc[i]) atomicAdd(&stats->phase_cycles[i], lc[i]);
 #endif
+#ifdef DS2I_RS_PHASE
+        for (int i = 0; i < PH_COUNT; ++i) if (pt[i]) atomicAdd(&stats->phase_cycles[i], pt[i]);
+#endif
     }
 #undef LC
+#undef PT
 }
 
 } // namespace

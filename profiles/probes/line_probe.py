@@ -24,5 +24,6 @@ for nt, c in ((2, 0), (3, 1), (4, 1)):
         print("   %-55s %10.2f M lines  %5.1f %%" % (label, ph[k] / 1e6, 100.0 * ph[k] / tot))
     print("   %-55s %10.2f M lines  %5.1f %%  (%d searches x 6)" % ("block searches in lists 1..", 6 * ph["find"] / 1e6, 600.0 * ph["find"] / tot, ph["find"]))
     print("   list-1 lines by range width: 1 doc-id per byte %.2f M, 2: %.2f M, 4: %.2f M, 8-16: %.2f M, wider: %.2f M" % tuple(ph[k] / 1e6 for k in ("total", "insert", "prefetch", "floor", "unit")))
+    print("   candidates alive at the gather (own freq bound + other lists' maxima can enter) %d in %d blocks that gathered" % (ph["n_alive"], ph["n_gblocks"]))
     print("   candidates %d, after the table bytes %d, after the hints %d, blocks with a stage C %d, list-j blocks decoded %d, freqs windows %d, heap offers %d"
           % (ph["n_visit"], ph["n_surv1"], ph["n_surv2"], ph["n_liverounds"], ph["n_bdocs"], ph["n_bfreqs"], ph["n_heap"]))
