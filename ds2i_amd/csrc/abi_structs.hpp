@@ -174,7 +174,10 @@ struct BmwArgs {
 };
 
 // exception side slot of one block (device_codecs.hpp, optpfor_decode_side): dwords, first add, adds held in-slot, overflow word
-static constexpr uint32_t XSLOT_DW = 64, XSLOT_ADDS = 8, XSLOT_CAP = 55, XSLOT_OVF = 63;
+// dword 8 / 9: copies of the docs / freqs part's header; dword 10 (XSLOT_FLAG): 0 = the common case -- neither part raw (b < 32),
+// both inside the 512 bytes a wave stages from the block's start, every add in the slot -- else bit 31 + (1 + dword offset of
+// the block's adds in the overflow area, or 0 when they are in the slot); dwords 11 .. 63: the adds, docs part first
+static constexpr uint32_t XSLOT_DW = 64, XSLOT_HDR = 8, XSLOT_FLAG = 10, XSLOT_ADDS = 11, XSLOT_CAP = 53, XSLOT_SLOW = 0x80000000u;
 
 // upload-time pass filling the exception side slots and the tail table (k_build_side_tables): items as in BmwArgs
 struct SideArgs {

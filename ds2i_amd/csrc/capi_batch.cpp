@@ -33,6 +33,7 @@ using ds2i_dev::Unit;
 extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
+hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
                                  const unsigned long long* seed_count, float* out_topk, uint32_t* out_len,
@@ -930,7 +931,8 @@ int launch_batch(ds2i_hip_batch* b) {
             }
             hipStream_t sg = (gi > 0 && nspare) ? spare[next_spare++ % nspare] : s;
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
-            if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw) HIP_OK(ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
+            if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
+                HIP_OK(idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
             else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, sg));
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));
             if (sg != s) HIP_OK(hipStreamWaitEvent(sm, b->ev_g[c][2 * gi + 1], 0));

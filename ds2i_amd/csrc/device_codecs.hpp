@@ -552,24 +552,15 @@ DS2I_DEV bool optpfor_decode_lds(const uint32_t* blk, uint32_t avail_dw, uint32_
 // full block of the index gets one 64-dword slot that holds the same information in the form a wave wants:
 //   dwords 0..3   docs part:  128-bit mask of the positions that carry an exception (bit i = value i)
 //   dwords 4..7   freqs part: the same
-//   dwords 8..62  the "adds" = (high part + 1) << b of every exception, docs part first (in position order), then freqs part
-//   dword  63     0, or 1 + dword offset of the block's adds in the overflow area when they do not fit (> 55: a few blocks in 10^5)
-// so that value i = low bits | (mask bit i ? adds[first + popcount(mask below i)] : 0): two LDS reads, no Simple16.
-// (XSLOT_* constants: abi_structs.hpp)
+//   dword  8, 9   copies of the two parts' header dwords (b << 26 | exceptions << 16 | Simple16 words)
+//   dword  10     0 in the common case (see XSLOT_FLAG), else XSLOT_SLOW | (1 + offset of the block's adds in the overflow area)
+//   dwords 11..63 the "adds" = (high part + 1) << b of every exception, docs part first (in position order), then freqs part
+// so that value i = low bits | (mask bit i ? adds[first + popcount(mask below i)] : 0). Everything a decode branches or
+// computes addresses on sits at fixed places of the slot: a wave reads it in ONE LDS round trip, the packed low bits and the
+// adds of BOTH parts in a second one, and the common case has no branch at all.
 
-// the b-bit low parts of a full block (header dword hdr at dword 0 of the part; RD(i) = dword i of the part)
-template <class RD>
-DS2I_DEV void optpfor_low_bits(RD rd, uint32_t hdr, uint32_t& v0, uint32_t& v1) {
-    const uint32_t lane = lane_id();
-    const uint32_t b = hdr >> 26, ew = hdr & 0xFFFFu;
-    const uint32_t mask = (1u << b) - 1u; // b == 0: mask 0, every value 0 (b < 32 here)
-    const uint32_t bit0 = lane * b, bit1 = bit0 + 64u * b;
-    const uint32_t i0 = 1u + ew + (bit0 >> 5), i1 = 1u + ew + (bit1 >> 5);
-    v0 = __builtin_amdgcn_alignbit(rd(i0 + 1), rd(i0), bit0 & 31u) & mask;
-    v1 = __builtin_amdgcn_alignbit(rd(i1 + 1), rd(i1), bit1 & 31u) & mask;
-}
-// the exceptions of one part: m = its mask (the same four dwords in every lane), XRD(i) = add i of the block, first = index
-// of the part's first add
+// the exceptions of one part: m = its mask (the same four dwords in every lane), XRD(i) = add i, first = index of the part's
+// first add
 template <class XRD>
 DS2I_DEV void optpfor_apply_adds(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t first, XRD xrd, uint32_t& v0, uint32_t& v1) {
     const uint32_t lane = lane_id();
@@ -581,22 +572,53 @@ DS2I_DEV void optpfor_apply_adds(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t
     v0 |= has0 ? a0 : 0u;
     v1 |= has1 ? a1 : 0u;
 }
+// the b-bit low parts of a full block (header dword hdr at dword 0 of the part; RD(i) = dword i of the part)
+template <class RD>
+DS2I_DEV void optpfor_low_bits(RD rd, uint32_t hdr, uint32_t& v0, uint32_t& v1) {
+    const uint32_t lane = lane_id();
+    const uint32_t b = hdr >> 26, ew = hdr & 0xFFFFu;
+    const uint32_t mask = (1u << b) - 1u; // b == 0: mask 0, every value 0 (b < 32 here)
+    const uint32_t bit0 = lane * b, bit1 = bit0 + 64u * b;
+    const uint32_t i0 = 1u + ew + (bit0 >> 5), i1 = 1u + ew + (bit1 >> 5);
+    v0 = __builtin_amdgcn_alignbit(rd(i0 + 1), rd(i0), bit0 & 31u) & mask;
+    v1 = __builtin_amdgcn_alignbit(rd(i1 + 1), rd(i1), bit1 & 31u) & mask;
+}
 
-// One part (docs: part = 0, freqs: part = 1) of a full OptPFor block whose bytes are staged in LDS from `blk` on
-// (avail_dw dwords; blk -> the part's header) and whose side slot is staged at `slot`. `gpart` = the part's address in
-// the arena and `xovf` = the overflow area, touched only by the cases the staging does not cover (a part beyond the staged
+// The head of a staged slot: the two headers and the flag word, wave-uniform
+struct SlotHead { uint32_t hd, hf, flag; };
+DS2I_DEV SlotHead optpfor_slot_head(const uint32_t* slot) {
+    const uint4 h = *(const uint4*)(slot + XSLOT_HDR);
+    return SlotHead{uniform(h.x), uniform(h.y), uniform(h.z)};
+}
+// BOTH parts of a full block in the common case (h.flag == 0): st = the block's bytes (staged from its first dword on), slot = its
+// staged side slot. No branch, no global memory; gaps-1 in (d0, d1), freqs-1 in (f0, f1), value i in lane i & 63, slot i >> 6.
+// cons_d / cons_f = bytes of the two parts.
+DS2I_DEV void optpfor_decode_pair(const uint32_t* st, const uint32_t* slot, const SlotHead& h, uint32_t& d0, uint32_t& d1, uint32_t& f0, uint32_t& f1,
+                                  uint32_t& cons_d, uint32_t& cons_f) {
+    const uint32_t nd = (h.hd >> 16) & 0x3FFu;
+    const uint32_t tot_d = 1u + (h.hd & 0xFFFFu) + 4u * (h.hd >> 26);
+    cons_d = 4u * tot_d;
+    cons_f = 4u * (1u + (h.hf & 0xFFFFu) + 4u * (h.hf >> 26));
+    const uint4 md = *(const uint4*)(slot), mf = *(const uint4*)(slot + 4);
+    optpfor_low_bits([&](uint32_t i) { return st[i]; }, h.hd, d0, d1);
+    const uint32_t* const sf = st + tot_d;
+    optpfor_low_bits([&](uint32_t i) { return sf[i]; }, h.hf, f0, f1);
+    // (a part without exceptions has an all-zero mask: its lanes read add `first` and discard it)
+    optpfor_apply_adds(md.x, md.y, md.z, md.w, XSLOT_ADDS, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, d0, d1);
+    optpfor_apply_adds(mf.x, mf.y, mf.z, mf.w, XSLOT_ADDS + nd, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, f0, f1);
+}
+
+// One part (docs: part = 0, freqs: part = 1) of a full OptPFor block in EVERY case: its bytes staged in LDS from `blk` on
+// (avail_dw dwords, 0 = not staged; blk -> the part's header) and its side slot staged at `slot`. `gpart` = the part's address
+// in the arena and `xovf` = the overflow area, touched only by what the staging does not cover (a part beyond the staged
 // bytes, a raw b = 32 block, adds in the overflow area); their loads are waited for before the function returns, so that
 // nothing of it is "pending" for the compiler where the caller's paths join. nd = exceptions of the docs part (where the
-// freqs part's adds start; ignored for part 0). Returns the bytes of the part; values in v0 / v1 (value i in lane i & 63,
-// slot i >> 6).
+// freqs part's adds start; ignored for part 0). Returns the bytes of the part.
 DS2I_DEV uint32_t optpfor_decode_side(const uint32_t* blk, uint32_t avail_dw, const uint32_t* slot, const uint8_t* gpart, const uint32_t* xovf,
                                       uint32_t part, uint32_t nd, uint32_t& v0, uint32_t& v1, uint32_t* nexc_out = nullptr) {
     const uint32_t lane = lane_id();
     const uint32_t* const g = (const uint32_t*)gpart;
-    const bool staged = avail_dw != 0u;
-    uint32_t hdr;
-    if (__builtin_expect(staged, 1)) hdr = uniform(blk[0]);
-    else hdr = uniform(g[0]);
+    const uint32_t hdr = uniform(slot[XSLOT_HDR + part]);
     const uint32_t b = hdr >> 26, nexc = (hdr >> 16) & 0x3FFu, ew = hdr & 0xFFFFu;
     if (nexc_out) *nexc_out = nexc;
     if (__builtin_expect(b >= 32u, 0)) { // raw block: 128 dwords behind the header
@@ -607,7 +629,7 @@ DS2I_DEV uint32_t optpfor_decode_side(const uint32_t* blk, uint32_t avail_dw, co
         return 4u * 129u;
     }
     const uint32_t total_dw = 1u + ew + 4u * b;
-    if (__builtin_expect(staged && total_dw + 1u <= avail_dw, 1)) {
+    if (__builtin_expect(total_dw + 1u <= avail_dw, 1)) {
         optpfor_low_bits([&](uint32_t i) { return blk[i]; }, hdr, v0, v1);
     } else {
         uint32_t a0, a1;
@@ -618,10 +640,10 @@ DS2I_DEV uint32_t optpfor_decode_side(const uint32_t* blk, uint32_t avail_dw, co
     }
     if (nexc) {
         const uint4 m = *(const uint4*)(slot + 4u * part);
-        const uint32_t ovf = uniform(slot[XSLOT_OVF]);
+        const uint32_t ovf = uniform(slot[XSLOT_FLAG]) & ~XSLOT_SLOW;
         const uint32_t first = part ? nd : 0u;
         if (__builtin_expect(ovf == 0u, 1)) {
-            optpfor_apply_adds(m.x, m.y, m.z, m.w, XSLOT_ADDS + first, [&](uint32_t i) { return slot[i]; }, v0, v1);
+            optpfor_apply_adds(m.x, m.y, m.z, m.w, XSLOT_ADDS + first, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, v0, v1);
         } else {
             const uint32_t* const xo = xovf + (ovf - 1u);
             uint32_t a0 = 0, a1 = 0;

@@ -2457,10 +2457,16 @@ __global__ void __launch_bounds__(64) k_decode_list_side(DecodeArgs a) {
             st[lane + 64] = g[lane + 64];
             xs[lane] = gx[lane];
             wave_sync();
-            uint32_t nd = 0;
-            const uint32_t cons = optpfor_decode_side(st, STAGE_DW, xs, data + ep, a.xovf, 0u, 0u, v0, v1, &nd);
-            const uint32_t skip_dw = cons >> 2;
-            optpfor_decode_side(st + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, xs, data + ep + cons, a.xovf, 1u, nd, f0, f1);
+            const SlotHead h = optpfor_slot_head(xs);
+            if (h.flag == 0u) {
+                uint32_t cd, cf;
+                optpfor_decode_pair(st, xs, h, v0, v1, f0, f1, cd, cf);
+            } else {
+                uint32_t nd = 0;
+                const uint32_t cons = optpfor_decode_side(st, STAGE_DW, xs, data + ep, a.xovf, 0u, 0u, v0, v1, &nd);
+                const uint32_t skip_dw = cons >> 2;
+                optpfor_decode_side(st + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, xs, data + ep + cons, a.xovf, 1u, nd, f0, f1);
+            }
         } else {
             const uint32_t* const tl = a.tails + t.aux1;
             v0 = lane < sz ? tl[lane] : 0u;
@@ -2660,6 +2666,10 @@ __global__ void __launch_bounds__(64) k_build_side_tables(SideArgs a) {
             uint32_t* dst = slot + XSLOT_ADDS;
             uint32_t ovf = 0;
             bool ok = true;
+            // the common case a wave decodes without a branch: neither part raw, both (and the dword a lane may read past the freqs
+            // part) inside the 128 dwords staged from the block's start, every add in the slot
+            const uint32_t tot_d = 1u + (hd & 0xFFFFu) + 4u * bd, tot_f = 1u + (hf & 0xFFFFu) + 4u * bf;
+            const bool common = bd < 32u && bf < 32u && tot_d + tot_f + 1u <= STAGE_DW && nd + nf <= XSLOT_CAP;
             if (nd + nf > XSLOT_CAP) {
                 unsigned long long off = 0;
                 if (lane == 0) off = atomicAdd(a.xovf_cursor, (unsigned long long)(nd + nf));
@@ -2673,8 +2683,8 @@ __global__ void __launch_bounds__(64) k_build_side_tables(SideArgs a) {
             uint32_t mine = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) mine = lane == (uint32_t)i ? words[i] : mine;
-            if (lane < 8u) slot[lane] = mine;
-            if (lane == XSLOT_OVF) slot[lane] = ok ? ovf : 0u;
+            mine = lane == XSLOT_HDR ? hd : lane == XSLOT_HDR + 1 ? hf : lane == XSLOT_FLAG ? (common ? 0u : (XSLOT_SLOW | (ok ? ovf : 0u))) : mine;
+            if (lane <= XSLOT_FLAG) slot[lane] = mine;
             if (ok) {
                 const uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(md0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md0, 0u));
                 const uint32_t r1 = (uint32_t)__builtin_popcountll(md0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(md1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)md1, 0u));
