@@ -50,6 +50,14 @@ struct Unit {
     uint32_t nparts;    // number of units of query q (1 -> the unit writes the final outputs itself)
 };
 
+// k_ranked_stream: everything the start of a unit needs in ONE 32-byte record per ticket of the launch (the unit, its query's
+// first term in qterms and its score histogram) -- order[tkt] -> units[uid] -> q_off[q] / q_hist_slot[q] were three dependent
+// round trips of a unit that lives for a few dozen blocks
+struct UnitRec {
+    uint32_t uid, q, blk_begin, blk_end, nparts, qt_off, hist_slot, pad;
+};
+static_assert(sizeof(UnitRec) == 32, "UnitRec is a 32-byte device record");
+
 struct BatchArgs {
     const uint8_t* arena;     // block indexes: list bytes ; opt index: chunk directory
     const uint8_t* bits0;     // opt index: docs bit vector words
@@ -60,6 +68,7 @@ struct BatchArgs {
     const uint32_t* q_off;    // nq+1 offsets into qterms
     const Unit* units;        // all units, grouped by query
     const uint32_t* order;    // nslice unit ids, scheduling order (costliest first)
+    const UnitRec* urec;      // the same order, one record per ticket (ranked conjunctive classes 0 / 1), or null
     uint32_t nslice;
     uint32_t num_docs;
     uint32_t k;

@@ -137,7 +137,7 @@ struct ds2i_hip_batch {
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
     size_t o_vinfo = 0;
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {},
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {},
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -690,6 +690,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     for (uint32_t i = 0; i < b->nsplit; ++i) b->hist_slot[b->split_queries[i]] = i;
     b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
+    for (int c = 0; c < 2; ++c) b->o_urec[c] = place(b->order[c].size() * sizeof(ds2i_dev::UnitRec)); // (classes of k_ranked_stream)
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
     b->up_bytes = o + 16;
     const size_t nq1 = nq ? nq : 1, nu1 = b->nunits ? b->nunits : 1;
@@ -787,6 +788,14 @@ int upload_batch(ds2i_hip_batch* b) {
     put(b->o_single, b->single_queries.data(), b->single_queries.size() * 4);
     put(b->o_hslot, b->hist_slot.data(), b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) put(b->o_order[c], b->order[c].data(), b->order[c].size() * 4);
+    for (int c = 0; c < 2 && !b->union_stream; ++c) { // one record per ticket: what k_ranked_stream reads where a unit starts (conjunctive batches)
+        ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
+        for (size_t i = 0; i < b->order[c].size(); ++i) {
+            const uint32_t uid = b->order[c][i];
+            const Unit& u = b->units[uid];
+            r[i] = ds2i_dev::UnitRec{uid, u.q, u.blk_begin, u.blk_end, u.nparts, b->qoff[u.q], b->hist_slot[u.q], 0u};
+        }
+    }
     if (b->want_matches) put(b->o_match_off, b->match_off.data(), b->match_off.size() * 8);
     HIP_OK(hipMemcpyAsync(b->d_up.p, b->h_up.p, b->up_bytes, hipMemcpyHostToDevice, idx->s_up));
     HIP_OK(hipEventRecord(b->ev_up, idx->s_up));
@@ -878,6 +887,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
+        a.urec = c < 2 ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
         a.nslice = b->ncls[c];
         a.dyn_lists = 0;
         a.num_docs = (uint32_t)idx->num_docs;
@@ -917,8 +927,10 @@ int launch_batch(ds2i_hip_batch* b) {
         a.long_stride = (uint32_t)((size_t)b->long_terms * (256 + ds2i_meta_words() + 2) + 16);
         a.stats = b->instrument ? b->d_stats.at<Stats>(0) + c : nullptr;
         const uint32_t* order_base = a.order;
+        const ds2i_dev::UnitRec* urec_base = a.urec;
         for (const auto& sl : b->sub[c]) { // one launch per group of the class (a single group for everything but the union kernels)
             a.order = order_base + sl.begin;
+            a.urec = urec_base ? urec_base + sl.begin : nullptr;
             a.nslice = sl.end - sl.begin;
             a.dyn_lists = sl.lists;
             // (the groups of a class run back to back on its stream: launching them beside each other on further streams

@@ -48,7 +48,7 @@ static_assert(DS2I_RS_FLOOR_EVERY > 0 && (DS2I_RS_FLOOR_EVERY & (DS2I_RS_FLOOR_E
 #define DS2I_RS_OCC2 6
 #endif
 #ifndef DS2I_RS_OCC4
-#define DS2I_RS_OCC4 5
+#define DS2I_RS_OCC4 6 // (round 5, on the leaner kernel: 5 -> 6 waves per SIMD for 3 / 4 lists +3.5 % end to end; 6 -> 7 / 8 for 2 lists: nothing)
 #endif
 #define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : DS2I_RS_OCC4)
 
@@ -238,6 +238,14 @@ DS2I_DEV void rs_decode_full(const uint32_t* st, const uint32_t* slot, const uin
     }
 }
 
+// an UPPER bound of bm25 doc_term_weight(f, nl) = f / (f + k1 (1 - b + b nl)) (device_enum.hpp) for the pruning tests: the
+// quotient through v_rcp_f32 (1 ulp) instead of the IEEE division sequence (11 instructions), widened by 2^-20 -- far more than
+// the reciprocal's and the product's rounding can lose. Scores themselves are always computed with the exact division.
+DS2I_DEV float rs_dtw_bound(uint32_t freq, float norm_len) {
+    const float f = (float)freq;
+    return f * __builtin_amdgcn_rcpf(f + 1.2f * (0.5f + 0.5f * norm_len)) * (1.0f + 1.0f / 1048576.0f);
+}
+
 #ifndef RS_HINT_FIRST
 #define RS_HINT_FIRST(nt) ((nt) > 2)
 #endif
@@ -284,15 +292,15 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
     const uint32_t nslice = rs_args()->nslice;
     for (uint32_t tkt = blockIdx.x; tkt < nslice; tkt += gridDim.x) {
         KArgs a = rs_args(); // (fields read below stay live for the unit; the cold ones are re-read at their use site)
-        const uint32_t uid = uniform(a->order[tkt]);
-        const Unit u = a->units[uid];
+        const UnitRec u = a->urec[tkt]; // (one 32-byte record: the unit, its query's terms, its histogram)
+        const uint32_t uid = uniform(u.uid);
         if constexpr (STATS) { // diagnostic (DS2I_UNIT_CLOCK=1): when the unit started / ended
             unsigned long long* const clk = a->unit_clock;
             if (clk && lane == 0) clk[2ull * uid] = wall_clock64();
         }
         const uint32_t q = uniform(u.q), blk_begin = uniform(u.blk_begin), blk_end = uniform(u.blk_end);
         const bool whole = uniform(u.nparts) == 1u;
-        const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(a->q_off[q])); // exactly NT terms (the planner's launch groups)
+        const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(u.qt_off)); // exactly NT terms (the planner's launch groups)
         TopK tk;
         tk.init(a->k);
         // ---- list 0: the stream
@@ -339,7 +347,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         unsigned int* const q_hist = a->q_hist;
         const bool shared_floor = !whole && q_hist;
         ScoreHist sh;
-        sh.init(shared_floor ? q_hist : nullptr, shared_floor ? uniform(a->q_hist_slot[q]) : 0u, shared_floor ? rs_uniformf(qt[0].max_bmw + qt[0].suf_bmw) : 0.f,
+        sh.init(shared_floor ? q_hist : nullptr, shared_floor ? uniform(u.hist_slot) : 0u, shared_floor ? rs_uniformf(qt[0].max_bmw + qt[0].suf_bmw) : 0.f,
                 1.0f - 1.0f / 1048576.0f);
         // can a score enter the heap: s >= floor && (heap not full || s > k-th score) (TopK::would_enter), branch-free on two
         // wave-uniform values that are refreshed whenever the heap or the floor changes
@@ -469,8 +477,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 dA1 = (lane + 64 < szA) ? A.base + i1 - 1u : 0xFFFFFFFFu;
                 fA0 = fv0 + 1u;
                 fA1 = fv1 + 1u;
-                boA0 = qw0 * doc_term_weight(fA0, min_nl);
-                boA1 = qw0 * doc_term_weight(fA1, min_nl);
+                boA0 = qw0 * rs_dtw_bound(fA0, min_nl);
+                boA1 = qw0 * rs_dtw_bound(fA1, min_nl);
                 ++s_docs_blocks;
                 ++s_freqs_blocks;
                 s_bm_examined += 1;

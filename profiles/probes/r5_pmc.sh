@@ -3,7 +3,7 @@
 # Utilisation MEASURED, not derived: issue-busy cycles of the vector / scalar / LDS / VMEM pipes, what waves
 # wait for, and how much of the L2's fabric traffic is DRAM. One rocprofv3 --pmc pass per group (own runs, --kernel-trace only).
 set -u
-TAG=${1:-r05}; OP=${2:-ranked_and}; shift 2 || true
+TAG=${1:-r05}; OP=${2:-ranked_and}; shift; if [ $# -gt 0 ]; then shift; fi
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
