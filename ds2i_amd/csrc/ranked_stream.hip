@@ -67,7 +67,16 @@ struct LdsRS {
 // ({block_max, end offset} per block), wtab = its block weights. 64 rows per probe: the 64 after `from`, then a 64-ary
 // search (the reference scans block_max linearly, block_posting_list.hpp:134-137).
 struct Found { uint32_t blk, bmax, base, ep; float w; };
-DS2I_DEV bool find_block_rows(const uint2* tab, const float* wtab, uint32_t nb, uint32_t from, uint32_t lb, Found& o) {
+// the first probe's rows (from-1 .. from+62; lane 0 = the block before `from`, never a candidate itself): they do not depend on
+// the doc-id searched for, so stage C requests them together with the candidates' norm_lens, one round trip earlier
+struct Rows { uint2 e; float w; };
+DS2I_DEV Rows rows_load(const uint2* tab, const float* wtab, uint32_t nb, uint32_t from) {
+    const uint32_t idx = (from ? from - 1 : 0) + lane_id();
+    Rows r{make_uint2(0xFFFFFFFFu, 0u), 0.f};
+    if (idx < nb) { r.e = tab[idx]; r.w = wtab[idx]; }
+    return r;
+}
+DS2I_DEV bool find_block_rows(const uint2* tab, const float* wtab, uint32_t nb, uint32_t from, uint32_t lb, Found& o, const Rows& first_rows) {
     const uint32_t lane = lane_id();
     if (from >= nb) return false;
     float wv = 0.f;
@@ -81,11 +90,11 @@ DS2I_DEV bool find_block_rows(const uint2* tab, const float* wtab, uint32_t nb, 
         o.base = o.blk ? pmax + 1u : 0u;
         o.ep = o.blk ? pend : 0u;
     };
-    {   // rows from-1 .. from+62 (lane 0 = the block before `from`, never a candidate itself)
+    {
         const uint32_t first = from ? from - 1 : 0;
         const uint32_t idx = first + lane;
-        uint2 e = make_uint2(0xFFFFFFFFu, 0u);
-        if (idx < nb) { e = tab[idx]; wv = wtab[idx]; }
+        const uint2 e = first_rows.e;
+        wv = first_rows.w;
         const uint64_t hit = ballot(idx >= from && idx < nb && e.x >= lb);
         if (hit) { finish(e, first, hit); return true; }
         if (first + 64 >= nb) return false;
@@ -339,10 +348,27 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         const uint8_t* const gt1 = hint_first ? rt[1] + hdelta : rt[1];
         // block of list j whose doc-ids and freqs are in L.dj[j-1] / L.fj[j-1] (cur = ~0: none) and its block_max. Only stage C
         // touches them: they live in the lanes of one VGPR (v_readlane / v_writelane at a constant lane).
+        // Together with the list's geometry (postings, first row in the per-block tables, arena offset, query weight): read once
+        // per unit, here, so that stage C starts with its first memory request instead of a dependent read of the QTerm.
         uint32_t cold = 0xFFFFFFFFu;
-        enum { C_CUR = 0, C_BMAX = 1, C_PER = 2 };
+        enum { C_CUR = 0, C_BMAX = 1, C_N = 2, C_BB = 3, C_LOLO = 4, C_LOHI = 5, C_QW = 6, C_TLLO = 7, C_TLHI = 8, C_PER = 9 };
 #define cget(l) ((uint32_t)__builtin_amdgcn_readlane((int)cold, (l)))
 #define cset(l, v) rs_writelane<(l)>(cold, (v))
+        {
+            auto park = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int CB = (j - 1) * C_PER;
+                const unsigned long long lo = qt[j].list_off, tl = qt[j].aux1;
+                cset(CB + C_N, qt[j].n);
+                cset(CB + C_BB, qt[j].blk_base);
+                cset(CB + C_LOLO, (uint32_t)lo);
+                cset(CB + C_LOHI, (uint32_t)(lo >> 32));
+                cset(CB + C_QW, __float_as_uint(qt[j].q_weight));
+                cset(CB + C_TLLO, (uint32_t)tl);
+                cset(CB + C_TLHI, (uint32_t)(tl >> 32));
+            };
+            rs_for<1, NT>(park);
+        }
         // ---- pruning state: the parts of a split query share a score histogram (device_score.hpp)
         unsigned int* const q_hist = a->q_hist;
         const bool shared_floor = !whole && q_hist;
@@ -431,9 +457,11 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         Blk A{}, B{};            // A: decoded this iteration; B: its gathers are consumed this iteration, then stage C if needed
         uint32_t haveA = 0, haveB = 0, finished = 0, from = blk_begin;
         uint32_t dA0 = 0xFFFFFFFFu, dA1 = 0xFFFFFFFFu, dB0 = 0xFFFFFFFFu, dB1 = 0xFFFFFFFFu; // doc-ids (value lane, lane + 64)
-        uint32_t fA0 = 1, fA1 = 1, fB0 = 1, fB1 = 1;                                          // freqs
+        // (a block's freqs are needed once more only if stage C scores it: they wait in the block's staging buffer, whose bytes
+        // are dead once decoded, instead of in four registers)
         float boA0 = 0.f, boA1 = 0.f, boB0 = 0.f, boB1 = 0.f;                                  // freq-only bound of the list-0 term score
-        uint32_t gB0[NT] = {}, gB1[NT] = {};                                                    // range-table bytes of lists 1..
+        // range-table weight bytes of a lane's two candidates, packed: byte j - 1 = list j (v_cvt_f32_ubyteN unpacks for free)
+        auto gbyte = [](uint32_t g, int j) __attribute__((always_inline)) -> uint32_t { return (g >> (8 * (j - 1))) & 255u; };
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]), xs_base = rs_lds_offset(&L.xs[0][0]);
         const uint32_t voff = lane * 4u;
@@ -475,10 +503,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
                 dA0 = (lane < szA) ? A.base + i0 - 1u : 0xFFFFFFFFu;
                 dA1 = (lane + 64 < szA) ? A.base + i1 - 1u : 0xFFFFFFFFu;
-                fA0 = fv0 + 1u;
-                fA1 = fv1 + 1u;
-                boA0 = qw0 * rs_dtw_bound(fA0, min_nl);
-                boA1 = qw0 * rs_dtw_bound(fA1, min_nl);
+                boA0 = qw0 * rs_dtw_bound(fv0 + 1u, min_nl);
+                boA1 = qw0 * rs_dtw_bound(fv1 + 1u, min_nl);
+                L.stage[bufA][lane] = fv0 + 1u; // (same lanes write and read: no fence needed before stage C's read an iteration later)
+                L.stage[bufA][lane + 64] = fv1 + 1u;
                 ++s_docs_blocks;
                 ++s_freqs_blocks;
                 s_bm_examined += 1;
@@ -490,14 +518,15 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // those of the prefetch above
                 if (haveN) rs_wait_vm<PF_LOADS>(); else rs_wait_vm<0>();
                 PT(PH_TOPK);
-                gB0[1] = L.gb[0][lane];
-                gB1[1] = L.gb[1][lane];
+                const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane]; // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists)
+                uint32_t gP0 = x0, gP1 = x1;
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
-                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (gB0[1] != 0u);
-                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (gB1[1] != 0u);
+                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (x0 != 0u);
+                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (x1 != 0u);
                 if (hint_first) {
-                    ok0 = ok0 & ((gB0[1] == 255u) | (gB0[1] == rmh_code(dB0, rsh[1])));
-                    ok1 = ok1 & ((gB1[1] == 255u) | (gB1[1] == rmh_code(dB1, rsh[1])));
+                    ok0 = ok0 & ((x0 == 255u) | (x0 == rmh_code(dB0, rsh[1])));
+                    ok1 = ok1 & ((x1 == 255u) | (x1 == rmh_code(dB1, rsh[1])));
+                    gP0 = gP1 = 0u;
                     LC(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                     if constexpr (NT > 2) {
                         if (ballot(ok0) | ballot(ok1)) { // the further lists' hints, all requested before any is tested
@@ -521,8 +550,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     if (ballot(ok0) | ballot(ok1)) { // every list's weight byte for what is left
                         auto wload = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            gB0[j] = ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u;
-                            gB1[j] = ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u;
+                            gP0 |= (ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u) << (8 * (j - 1));
+                            gP1 |= (ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u) << (8 * (j - 1));
                             LC(PH_FREQS, lines_of(rt[j] + (dB0 >> rsh[j]), ok0, 1u) + lines_of(rt[j] + (dB1 >> rsh[j]), ok1, 1u));
                         };
                         rs_for<1, NT>(wload);
@@ -532,35 +561,35 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     float rest = 0.f;
                     auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest = rest + rsc[j] * 255.0f; };
                     rs_for_down<NT, 2>(add_max);
-                    ok0 = ok0 & enters((boB0 + (rest + rsc[1] * (float)gB0[1])) * BOUND_SLACK);
-                    ok1 = ok1 & enters((boB1 + (rest + rsc[1] * (float)gB1[1])) * BOUND_SLACK);
+                    ok0 = ok0 & enters((boB0 + (rest + rsc[1] * (float)x0)) * BOUND_SLACK);
+                    ok1 = ok1 & enters((boB1 + (rest + rsc[1] * (float)x1)) * BOUND_SLACK);
                     if (ballot(ok0) | ballot(ok1)) {
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            gB0[j] = (uint32_t)rt[j][(ok0 ? dB0 : 0u) >> rsh[j]];
-                            gB1[j] = (uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]];
+                            gP0 |= (uint32_t)rt[j][(ok0 ? dB0 : 0u) >> rsh[j]] << (8 * (j - 1));
+                            gP1 |= (uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]] << (8 * (j - 1));
                         };
                         rs_for<2, NT>(load_one);
                         auto test_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            ok0 = ok0 & (gB0[j] != 0u);
-                            ok1 = ok1 & (gB1[j] != 0u);
+                            ok0 = ok0 & (gbyte(gP0, j) != 0u);
+                            ok1 = ok1 & (gbyte(gP1, j) != 0u);
                         };
                         rs_for<2, NT>(test_one);
                     }
                 }
                 // what the lists after list `after` can add to this lane's two candidates, from their own bytes (summed from the
                 // last list down, so that the value for `after` is a prefix of the same chain whatever `after` is)
-                auto rest_of = [&](const uint32_t (&g)[NT], int after) __attribute__((always_inline)) -> float {
+                auto rest_of = [&](uint32_t g, int after) __attribute__((always_inline)) -> float {
                     float r = 0.f;
                     auto add_one = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
-                        if (j > after) r = r + rsc[j] * (float)g[j];
+                        if (j > after) r = r + rsc[j] * (float)gbyte(g, j);
                     };
                     rs_for_down<NT, 1>(add_one);
                     return r;
                 };
-                float r0 = rest_of(gB0, 0), r1 = rest_of(gB1, 0);
+                float r0 = rest_of(gP0, 0), r1 = rest_of(gP1, 0);
                 ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
                 ok1 = ok1 & enters((boB1 + r1) * BOUND_SLACK);
                 LC(PH_C_VISIT, __builtin_popcountll(ballot(dB0 != 0xFFFFFFFFu)) + __builtin_popcountll(ballot(dB1 != 0xFFFFFFFFu)));
@@ -587,8 +616,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     // ---------------- stage C: somebody of block B may enter the heap: norm_len, exact list-0 score
                     const float* const norm_lens = rs_args()->norm_lens;
                     const uint8_t* const arena = rs_args()->arena;
+                    // (list 1's rows after its current block go out together with the norm_lens: the search they serve comes first
+                    // in the probe below and does not depend on which candidate it is for)
+                    const Rows rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
                     const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
                     LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
+                    const uint32_t fB0 = L.stage[bufB][lane], fB1 = L.stage[bufB][lane + 64];
                     float pa0 = qw0 * doc_term_weight(fB0, nl0), pa1 = qw0 * doc_term_weight(fB1, nl1);
                     {
                         const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
@@ -604,15 +637,15 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         constexpr int CB = (j - 1) * C_PER; // this list's lanes of `cold`
                         uint64_t todo0 = ballot(ok0), todo1 = ballot(ok1);
                         if (!(todo0 | todo1)) return;
-                        const QTerm* const tj = qt + j;
-                        const uint32_t nj = uniform(tj->n), nbj = (nj + 127u) >> 7, bbj = uniform(tj->blk_base);
+                        const uint32_t nj = cget(CB + C_N), nbj = (nj + 127u) >> 7, bbj = cget(CB + C_BB);
                         const uint32_t vlj = 1u + (nj >= (1u << 7)) + (nj >= (1u << 14)) + (nj >= (1u << 21)) + (nj >= (1u << 28));
-                        const uint8_t* const dataj = arena + rs_uniform64(tj->list_off) + vlj + 4ull * nbj + 4ull * (nbj - 1);
+                        const uint8_t* const dataj = arena + (((unsigned long long)cget(CB + C_LOHI) << 32) | cget(CB + C_LOLO)) + vlj + 4ull * nbj + 4ull * (nbj - 1);
                         const uint2* const tabj = (const uint2*)rs_args()->skip + bbj;
                         const float* const wtabj = rs_args()->bmw + bbj;
-                        const float qwj = rs_uniformf(tj->q_weight);
-                        const float rj0 = rest_of(gB0, j), rj1 = rest_of(gB1, j); // the lists after j
-                        const float bj0 = rsc[j] * (float)gB0[j], bj1 = rsc[j] * (float)gB1[j];
+                        const float qwj = __uint_as_float(cget(CB + C_QW));
+                        bool rows_fresh = j == 1; // (rows1 was loaded for from = list 1's current block + 1)
+                        const float rj0 = rest_of(gP0, j), rj1 = rest_of(gP1, j); // the lists after j
+                        const float bj0 = rsc[j] * (float)gbyte(gP0, j), bj1 = rsc[j] * (float)gbyte(gP1, j);
                         uint32_t* const dj = L.dj[j - 1];
                         uint32_t* const fj = L.fj[j - 1];
                         bool mem0 = false, mem1 = false;
@@ -621,7 +654,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             const uint32_t amin = todo0 ? bcast(dB0, (uint32_t)__builtin_ctzll(todo0)) : bcast(dB1, (uint32_t)__builtin_ctzll(todo1));
                             if (curj == 0xFFFFFFFFu || amin > bmj) {
                                 Found fb;
-                                const bool found = find_block_rows(tabj, wtabj, nbj, curj + 1u, amin, fb);
+                                const bool found = find_block_rows(tabj, wtabj, nbj, curj + 1u, amin, fb, rows_fresh ? rows1 : rows_load(tabj, wtabj, nbj, curj + 1u));
                                 LC(PH_FIND, 1);
                                 if (!found) { // list j has nothing >= amin: no later document of list 0 can be a result either
                                     s_bm_examined += 1;
@@ -640,8 +673,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 if (!(ballot(can0) | ballot(can1))) { // nobody inside the block can enter: it is not decoded
                                     todo0 &= ~ballot(in0);
                                     todo1 &= ~ballot(in1);
-                                    continue; // (the list stays where it was: the next search restarts there)
+                                    continue; // (the list stays where it was: the next search restarts there, with the same rows)
                                 }
+                                rows_fresh = false;
                                 const uint8_t* pb = dataj + fb.ep;
                                 LC(PH_C_BDOCS, 1);
                                 LC(PH_DOCS, lines_of(pb + 8u * lane, true, 8u));
@@ -651,7 +685,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                     rs_stage_block((const uint32_t*)pb, rs_args()->xslots + (size_t)XSLOT_DW * (bbj + fb.blk), L.stb, L.xsb);
                                     rs_decode_full(L.stb, L.xsb, pb, rs_args()->xovf, v0, v1, w0, w1, consD, consF2);
                                 } else {
-                                    rs_tail(rs_args()->tails, rs_uniform64(tj->aux1), szb, v0, v1, w0, w1, consD, consF2);
+                                    rs_tail(rs_args()->tails, ((unsigned long long)cget(CB + C_TLHI) << 32) | cget(CB + C_TLLO), szb, v0, v1, w0, w1, consD, consF2);
                                 }
                                 const uint32_t g0 = (lane < szb) ? v0 + 1u : 0u, g1 = (lane + 64 < szb) ? v1 + 1u : 0u;
                                 const uint32_t i0 = wave_incl_scan(g0);
@@ -734,8 +768,6 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             haveB = haveA;
             dB0 = dA0;
             dB1 = dA1;
-            fB0 = fA0;
-            fB1 = fA1;
             boB0 = boA0;
             boB1 = boA1;
             if (haveB) {
