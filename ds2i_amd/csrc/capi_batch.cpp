@@ -142,7 +142,7 @@ struct ds2i_hip_batch {
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
     // ---- device-only scratch: per-unit partial results of split queries + the shared floors
-    size_t o_unit_count = 0, o_unit_topk = 0, o_unit_topk_len = 0, o_unit_freq_sum = 0, o_qfloor = 0, scr_bytes = 0;
+    size_t o_unit_count = 0, o_unit_topk = 0, o_unit_topk_len = 0, o_unit_freq_sum = 0, o_qfloor = 0, o_qfloorw = 0, scr_bytes = 0;
     DevBuf d_up, d_out, d_scr, d_matches, d_prof, d_stats, d_long, d_clk;
     // union kernels (k_disjunctive) keep their decoded blocks in dynamic LDS sized per launch: a class's units are grouped
     // by the list count of their query and every group is launched with just that many list slots
@@ -709,6 +709,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     const bool disj_ranked = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
     const bool hist = !(op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_ranked);
     b->o_qfloor = place(hist ? 1024 * (size_t)b->nsplit : 16);
+    b->o_qfloorw = place(hist ? 4 * (size_t)b->nsplit : 16); // k_ranked_stream: the floor the histogram implies, one word per split query
     b->scr_bytes = o;
 
     b->use_seed = seeded;
@@ -907,7 +908,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.seed_topk = b->use_seed ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
         a.seed_len = b->use_seed ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
         const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-        a.q_floor = nullptr;
+        a.q_floor = base_op == DS2I_OP_RANKED_AND ? b->d_scr.at<unsigned int>(b->o_qfloorw) : nullptr;
         a.q_hist = (!(b->op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_topk))
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
         a.q_hist_slot = b->d_up.at<uint32_t>(b->o_hslot);

@@ -61,6 +61,7 @@ struct LdsRS {
     uint32_t xsb[XSLOT_DW];      // its side slot
     uint32_t dj[NT - 1][128];    // lists 1 .. NT-1: doc-ids of their current block
     uint32_t fj[NT - 1][128];    // and its freqs
+    uint32_t fw[64];             // the query's shared floor word, as fetched an iteration ago (LDS-DMA: one copy per lane)
 };
 
 // first block >= from of a list whose block_max >= lb, with its table words; rows = the list's interleaved skip table
@@ -190,6 +191,12 @@ DS2I_DEV void rs_prefetch_blk(const uint8_t* g, uint32_t lds, const uint32_t* gx
                  : "=&s"(keep) : "v"(voff), "s"(g), "s"(uniform(lds)), "s"(gx), "s"(uniform(lds_x)) : "memory");
 }
 static constexpr int PF_LOADS = 3; // hand-issued loads of one block prefetch
+// (i') one dword at g, read past this CU's L1 (sc1: other CUs update it with atomics) -> the 64 dwords at LDS byte offset lds
+DS2I_DEV void rs_fetch_word(const unsigned int* g, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(0u), "s"(g), "s"(uniform(lds)) : "memory");
+}
 // (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
 // lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
 // destination is written when the statement ends, and under register pressure it did copy the still-pending register
@@ -380,13 +387,16 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         float e_floor = tk.floor, e_gt = -__builtin_inff();
         auto refresh = [&]() __attribute__((always_inline)) { e_floor = tk.floor; e_gt = tk.n < tk.k ? -__builtin_inff() : tk.thr; };
         auto enters = [&](float s) __attribute__((always_inline)) -> bool { return (s >= e_floor) & (s > e_gt); };
-        auto adopt_floor = [&]() __attribute__((always_inline)) {
-            const float f = sh.floor(tk.k);
-            if (f > tk.floor) tk.floor = f;
-            refresh();
+        // The floor the histogram implies is published in one word per split query (BatchArgs::q_floor, float bits: scores are
+        // >= 0, so the bit patterns order like the values): whoever puts a score into its heap re-reads the histogram -- the only
+        // moment the floor can have moved -- and raises the word; everybody else gets the word with every block, fetched an
+        // iteration ahead by LDS-DMA, instead of a 256-counter scan every fourth block on the critical path.
+        unsigned int* const fwp = shared_floor ? (unsigned int*)rs_uniform_ptr(a->q_floor + uniform(u.hist_slot)) : nullptr;
+        auto adopt_word = [&](uint32_t bits) __attribute__((always_inline)) {
+            const float f = __uint_as_float(bits);
+            if (bits != 0u && f > tk.floor) { tk.floor = f; refresh(); }
         };
-        if (shared_floor) adopt_floor();
-        uint32_t floor_tick = 1;
+        if (shared_floor) adopt_word(uniform(__hip_atomic_load(fwp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         // ---- the 64-row window of list 0's table (lane j: row s_first + j; lane 0 is the row before the first block the window
         // can serve, unless that is block 0) and, per row, what a document of that block can score at most: block weight + for
         // each other list the largest range-table entry over the block's own doc-id span (read from the level whose entries are
@@ -464,29 +474,31 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         auto gbyte = [](uint32_t g, int j) __attribute__((always_inline)) -> uint32_t { return (g >> (8 * (j - 1))) & 255u; };
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]), xs_base = rs_lds_offset(&L.xs[0][0]);
+        const uint32_t fw_base = rs_lds_offset(&L.fw[0]);
         const uint32_t voff = lane * 4u;
         uint32_t bufB = 0, bufA = 1, bufN = 2;
         PT(PH_UNIT);
         for (;;) {
             // ---------------- stage N: the next block worth a visit as things stand now (the heap may still rule it out before its
             // turn), its bytes and side slot requested
+            // A's bytes (and the floor word) were requested an iteration ago; the only loads issued after them are B's two gathers
             if (haveA) {
                 ++s_rounds;
-                if (shared_floor && (floor_tick++ & (DS2I_RS_FLOOR_EVERY - 1)) == 0) adopt_floor();
+                if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                PT(PH_PREFETCH);
+                if (shared_floor) adopt_word(uniform(L.fw[0]));
             }
             PT(PH_FLOOR);
             Blk N{};
             const uint32_t haveN = select(from, N);
             if (!haveN) from = blk_end; // (the threshold only rises: what is not worth a visit now never will be)
             PT(PH_STREAM);
-            // A's bytes were requested an iteration ago; the only loads issued after them are B's two gathers
-            if (haveA) { if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>(); }
-            PT(PH_PREFETCH);
             if (haveN) {
                 from = N.blk + 1u;
                 const uint8_t* const g = rs_uniform_ptr(data0 + N.ep); // (full blocks of a block_optpfor list are dword aligned; a partial last block is not read from here)
                 rs_prefetch_blk((const uint8_t*)((uintptr_t)g & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), rs_uniform_ptr(xs0 + (size_t)XSLOT_DW * N.blk),
                                 xs_base + bufN * (XSLOT_DW * 4u), voff);
+                if (shared_floor) rs_fetch_word(fwp, fw_base);
                 LC(PH_STREAM, lines_of((const uint8_t*)((uintptr_t)g & ~(uintptr_t)3) + 8u * lane, true, 8u));
             }
             if (haveA) {
@@ -516,7 +528,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             if (haveB) {
                 // ---------------- stage B: the gathers of block B, issued before stage A ran; the only loads issued after them are
                 // those of the prefetch above
-                if (haveN) rs_wait_vm<PF_LOADS>(); else rs_wait_vm<0>();
+                if (haveN) { if (shared_floor) rs_wait_vm<PF_LOADS + 1>(); else rs_wait_vm<PF_LOADS>(); } else rs_wait_vm<0>();
                 PT(PH_TOPK);
                 const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane]; // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists)
                 uint32_t gP0 = x0, gP1 = x1;
@@ -744,6 +756,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     };
                     rs_for<1, NT>(probe);
                     // pa0 / pa1 are complete scores of documents of the intersection now
+                    uint32_t inserted = 0;
                     for (int half = 0; half < 2; ++half) {
                         const float sc = half ? pa1 : pa0;
                         uint64_t todo = ballot((half ? ok1 : ok0) & enters(sc));
@@ -754,8 +767,16 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             LC(PH_C_HEAP, 1);
                             if (tk.insert(v)) {
                                 refresh();
+                                inserted = 1;
                                 if (shared_floor && lane == 0) sh.add(v);
                             }
+                        }
+                    }
+                    if (shared_floor && inserted) { // the histogram moved: what floor does it imply now
+                        const float f = sh.floor(tk.k);
+                        if (f > 0.f) {
+                            if (lane == 0) __hip_atomic_fetch_max(fwp, __float_as_uint(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (f > tk.floor) { tk.floor = f; refresh(); }
                         }
                     }
                 }
