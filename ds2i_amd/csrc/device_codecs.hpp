@@ -593,19 +593,26 @@ DS2I_DEV SlotHead optpfor_slot_head(const uint32_t* slot) {
 // BOTH parts of a full block in the common case (h.flag == 0): st = the block's bytes (staged from its first dword on), slot = its
 // staged side slot. No branch, no global memory; gaps-1 in (d0, d1), freqs-1 in (f0, f1), value i in lane i & 63, slot i >> 6.
 // cons_d / cons_f = bytes of the two parts.
+// (DOCS / FREQS: which parts the caller wants; the other one's outputs are left untouched)
+template <bool DOCS = true, bool FREQS = true>
 DS2I_DEV void optpfor_decode_pair(const uint32_t* st, const uint32_t* slot, const SlotHead& h, uint32_t& d0, uint32_t& d1, uint32_t& f0, uint32_t& f1,
                                   uint32_t& cons_d, uint32_t& cons_f) {
     const uint32_t nd = (h.hd >> 16) & 0x3FFu;
     const uint32_t tot_d = 1u + (h.hd & 0xFFFFu) + 4u * (h.hd >> 26);
     cons_d = 4u * tot_d;
     cons_f = 4u * (1u + (h.hf & 0xFFFFu) + 4u * (h.hf >> 26));
-    const uint4 md = *(const uint4*)(slot), mf = *(const uint4*)(slot + 4);
-    optpfor_low_bits([&](uint32_t i) { return st[i]; }, h.hd, d0, d1);
-    const uint32_t* const sf = st + tot_d;
-    optpfor_low_bits([&](uint32_t i) { return sf[i]; }, h.hf, f0, f1);
     // (a part without exceptions has an all-zero mask: its lanes read add `first` and discard it)
-    optpfor_apply_adds(md.x, md.y, md.z, md.w, XSLOT_ADDS, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, d0, d1);
-    optpfor_apply_adds(mf.x, mf.y, mf.z, mf.w, XSLOT_ADDS + nd, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, f0, f1);
+    if constexpr (DOCS) {
+        const uint4 md = *(const uint4*)(slot);
+        optpfor_low_bits([&](uint32_t i) { return st[i]; }, h.hd, d0, d1);
+        optpfor_apply_adds(md.x, md.y, md.z, md.w, XSLOT_ADDS, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, d0, d1);
+    }
+    if constexpr (FREQS) {
+        const uint4 mf = *(const uint4*)(slot + 4);
+        const uint32_t* const sf = st + tot_d;
+        optpfor_low_bits([&](uint32_t i) { return sf[i]; }, h.hf, f0, f1);
+        optpfor_apply_adds(mf.x, mf.y, mf.z, mf.w, XSLOT_ADDS + nd, [&](uint32_t i) { return slot[i & (XSLOT_DW - 1u)]; }, f0, f1);
+    }
 }
 
 // One part (docs: part = 0, freqs: part = 1) of a full OptPFor block in EVERY case: its bytes staged in LDS from `blk` on

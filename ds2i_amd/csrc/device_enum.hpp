@@ -64,7 +64,10 @@ struct MetaReg {
     uint32_t pf_blk[NPF], pf_tab[NPF], pf_w0[NPF], pf_w1[NPF];
     uint32_t v[TMAX * M_WORDS];
     DS2I_DEV uint32_t get(uint32_t s, int f) const { return v[s * M_WORDS + f]; }
-    DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = x; }
+    // (through v_readfirstlane: a word the compiler takes for divergent -- assigned under a branch it could not prove uniform --
+    // would live in a VGPR, and a few dozen of those push the unrolled kernels into hundreds of scratch spills; as scalars
+    // the same words spill, if they must, into the lanes of a VGPR)
+    DS2I_DEV void set(uint32_t s, int f, uint32_t x) { v[s * M_WORDS + f] = uniform(x); }
 };
 
 // a counter that compiles to nothing (uninstrumented kernels)
@@ -93,6 +96,31 @@ struct CtxT {
     uint32_t num_docs;
     unsigned int* block_profile; // 2 counters per block (docs, freqs decodes) or null; instrumented kernels only
     const uint2* skip;           // block indexes: {block_max[b], end offset of block b} per block of the index, or null
+    // CODEC_T == CODEC_OPTPFOR = block_optpfor WITH the upload-time side tables (BatchArgs::xslots / tails; an upload without
+    // them runs the runtime-codec instantiation): a full block is decoded through its exception side slot (device_codecs.hpp,
+    // optpfor_decode_pair / optpfor_decode_side), a list's partial last block comes from the tail table -- these kernels carry
+    // no Simple16 parser and no interpolative walk. The slot of the block decoded last waits in exc[0 .. 63] (slot_blk = its
+    // index-wide block number, ~0 = none). want_freqs: decode_docs() delivers the freqs with the doc-ids (one pass over the
+    // staged bytes) instead of leaving them to a later decode_freqs().
+    const uint32_t* xslots = nullptr;
+    const uint32_t* xovf = nullptr;
+    const uint32_t* tails = nullptr;
+    uint32_t slot_blk = 0xFFFFFFFFu;
+    bool want_freqs = false;
+    static constexpr bool SIDE = CODEC_T == CODEC_OPTPFOR;
+    DS2I_DEV bool side() const { return SIDE; }
+    DS2I_DEV const uint32_t* tail_of(uint32_t s) const { return tails + (((uint64_t)m(s, M_DBIT_HI) << 32) | m(s, M_DBIT_LO)); }
+    // the slot of block gb -> exc[0 .. 63]; `have` = its dword of this lane, loaded ahead by the caller (with the block's bytes)
+    // (gb, like everything that steers control flow here, is made wave-uniform explicitly: a value the compiler takes for
+    // divergent turns the branch into a masked region and every enumerator word assigned under it into a VGPR)
+    DS2I_DEV void stage_slot(uint32_t gb, const uint32_t* have = nullptr) {
+        gb = uniform(gb);
+        if (slot_blk == gb) return;
+        const uint32_t v = have ? *have : xslots[(size_t)XSLOT_DW * gb + lane_id()];
+        exc[lane_id()] = v;
+        slot_blk = gb;
+        wave_sync();
+    }
     DS2I_DEV bool is_pef() const { return CODEC_T == CODEC_PEF || (CODEC_T < 0 && codec == CODEC_PEF); }
     // per-wave statistics (wave-uniform). Like the reference's block_profiler they are a compile-time option
     // (block_posting_list.hpp:316-318 `if (Profile)`): the counters live in SGPRs, and the <=2-list kernel at
@@ -214,10 +242,18 @@ struct CtxT {
         const uint8_t* data = endpoints + 4ull * (nb - 1);
         const uint8_t* lend = ptr(s, M_END_LO);
         const uint32_t cur = m(s, M_CUR);
-        const uint32_t sz = ((b + 1) * 128u <= n) ? 128u : (n & 127u);
+        const uint32_t sz = SIDE ? uniform(((b + 1) * 128u <= n) ? 128u : (n & 127u)) : (((b + 1) * 128u <= n) ? 128u : (n & 127u));
         uint32_t ep = 0, bmax = 0, base = 0, next_ep = 0;
         const uint8_t* p = nullptr;
         bool have = false;
+        // (side slots: the block's slot is requested here, together with the table words / block bytes below)
+        const uint32_t gblk = SIDE ? uniform(m(s, M_PBASE) + b) : 0u;
+        bool fetch_slot = false;
+        uint32_t slot_dw = 0;
+        if constexpr (SIDE) {
+            fetch_slot = sz == 128u && slot_blk != gblk;
+            if (fetch_slot) slot_dw = xslots[(size_t)XSLOT_DW * gblk + lane];
+        }
         if constexpr (META::NPF > 0) {
             if (s < (uint32_t)META::NPF && cur != 0xFFFFFFFFu && meta.pf_blk[s < (uint32_t)META::NPF ? s : 0] == b) { // the bytes are already in registers
                 have = true;
@@ -239,8 +275,8 @@ struct CtxT {
             bmax = pre->bmax;
             base = pre->base;
             next_ep = pre->next_ep;
-            uint32_t hint = next_ep - ep;
-            if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+            uint32_t hint = next_ep - ep + 8u; // (+ the dword a lane may read past the last value)
+            if (hint == 8u || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
             p = data + ep;
             if (!staged) win.load(p, hint);
         }
@@ -273,8 +309,8 @@ struct CtxT {
             bmax = bcast(hv, 1);
             base = bcast(hv, 2);
             next_ep = bcast(hv, 3);
-            uint32_t hint = next_ep - ep; // docs+freqs bytes of this block when endpoints are monotone
-            if (hint == 0 || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
+            uint32_t hint = next_ep - ep + 8u; // docs+freqs bytes of this block when endpoints are monotone (+ the dword a lane may read past the last value)
+            if (hint == 8u || hint > STAGE_DW * 4 - 4) hint = STAGE_DW * 4 - 4;
             p = data + ep;
             win.load(p, hint);
         }
@@ -283,7 +319,51 @@ struct CtxT {
         if (blk_bytes > STAGE_DW * 4) blk_bytes = STAGE_DW * 4;
         uint32_t v0, v1;
         uint32_t* dst = D(s);
-        uint32_t consumed = decode_block<CODEC_T>(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
+        uint32_t consumed;
+        const bool freqs_too = SIDE && want_freqs;
+        if constexpr (SIDE) {
+            uint32_t f0 = 0, f1 = 0, cf = 0;
+            if (__builtin_expect(sz == 128u, 1)) { // (full blocks of a block_optpfor list are dword aligned in the arena)
+                stage_slot(gblk, fetch_slot ? &slot_dw : nullptr);
+                const SlotHead h = optpfor_slot_head(exc);
+                const uint32_t off = uniform((uint32_t)(p - win.gbase));
+                const uint32_t need = 4u * (2u + (h.hd & 0xFFFFu) + 4u * (h.hd >> 26) + 1u + (h.hf & 0xFFFFu) + 4u * (h.hf >> 26));
+                const uint32_t in_win = uniform((p >= win.gbase && off < win.nbytes) ? 1u : 0u);
+                const uint32_t fast = uniform((h.flag == 0u && in_win && off + need <= win.nbytes) ? 1u : 0u);
+                if (__builtin_expect(fast != 0u, 1)) {
+                    if (want_freqs) optpfor_decode_pair<true, true>(win.st + (off >> 2), exc, h, v0, v1, f0, f1, consumed, cf);
+                    else optpfor_decode_pair<true, false>(win.st + (off >> 2), exc, h, v0, v1, f0, f1, consumed, cf);
+                } else {
+                    uint32_t nd = 0;
+                    consumed = optpfor_decode_side(win.st + (in_win ? off >> 2 : 0u), in_win ? (win.nbytes - off) >> 2 : 0u, exc, p, xovf, 0u, 0u, v0, v1, &nd);
+                    if (want_freqs) {
+                        const uint32_t offf = off + consumed;
+                        const uint32_t in_winf = uniform((in_win && offf < win.nbytes) ? 1u : 0u);
+                        cf = optpfor_decode_side(win.st + (in_winf ? offf >> 2 : 0u), in_winf ? (win.nbytes - offf) >> 2 : 0u, exc, p + consumed, xovf, 1u, nd, f0, f1);
+                    }
+                }
+            } else { // the list's partial last block: plain values in the tail table (entry: sz gaps-1, sz freqs-1, bytes of the two parts)
+                const uint32_t* const t = tail_of(s);
+                v0 = lane < sz ? t[lane] : 0u;
+                v1 = lane + 64 < sz ? t[lane + 64] : 0u;
+                consumed = t[2u * sz];
+                if (want_freqs) {
+                    f0 = lane < sz ? t[sz + lane] : 0u;
+                    f1 = lane + 64 < sz ? t[sz + lane + 64] : 0u;
+                    cf = t[2u * sz + 1u];
+                }
+            }
+            consumed = uniform(consumed);
+            if (freqs_too) {
+                uint32_t* fd = F(s);
+                fd[lane] = f0 + 1u;
+                fd[lane + 64] = f1 + 1u;
+                ++s_freqs_blocks;
+                s_bytes += uniform(cf);
+            }
+        } else {
+            consumed = decode_block<CODEC_T>(codec, win, p, bmax - base - (sz - 1), sz, dst, exc, v0, v1);
+        }
         uint32_t g0 = (lane < sz) ? v0 + 1u : 0u;
         uint32_t g1 = (lane + 64 < sz) ? v1 + 1u : 0u;
         uint32_t i0 = wave_incl_scan(g0);
@@ -301,7 +381,8 @@ struct CtxT {
         setm(s, M_DOCID, first < num_docs ? first : num_docs); // num_docs doubles as the unit's doc-id limit
         setm(s, M_FREQ_LO, (uint32_t)fo);
         setm(s, M_FREQ_HI, (uint32_t)(fo >> 32));
-        setm(s, M_FDEC, 0);
+        setm(s, M_FDEC, freqs_too ? 1u : 0u);
+        if (SHARE_F && s && freqs_too) fowner = s;
         setm(s, M_DDEC, 1);
         setm(s, M_GPOS, b * 128u);
         setm(s, M_NEXTEP, next_ep);
@@ -347,7 +428,23 @@ struct CtxT {
         }
         uint32_t v0, v1;
         uint32_t* dst = F(s);
-        uint32_t consumed = decode_block<CODEC_T>(codec, win, p, 0xFFFFFFFFu, sz, dst, exc, v0, v1);
+        uint32_t consumed;
+        if constexpr (SIDE) {
+            if (__builtin_expect(uniform(sz) == 128u, 1)) {
+                stage_slot(m(s, M_PBASE) + m(s, M_CUR));
+                const uint32_t off = uniform((uint32_t)(p - win.gbase));
+                const uint32_t in_win = uniform((p >= win.gbase && off < win.nbytes) ? 1u : 0u);
+                consumed = optpfor_decode_side(win.st + (in_win ? off >> 2 : 0u), in_win ? (win.nbytes - off) >> 2 : 0u, exc, p, xovf, 1u, (uniform(exc[XSLOT_HDR]) >> 16) & 0x3FFu, v0, v1);
+            } else {
+                const uint32_t* const t = tail_of(s);
+                v0 = lane < sz ? t[sz + lane] : 0u;
+                v1 = lane + 64 < sz ? t[sz + lane + 64] : 0u;
+                consumed = t[2u * sz + 1u];
+            }
+            consumed = uniform(consumed);
+        } else {
+            consumed = decode_block<CODEC_T>(codec, win, p, 0xFFFFFFFFu, sz, dst, exc, v0, v1);
+        }
         dst[lane] = v0 + 1u;
         dst[lane + 64] = v1 + 1u;
         setm(s, M_FDEC, 1);
@@ -410,6 +507,10 @@ struct CtxT {
         setm(s, M_RBASE, t.rmw_off64);
         setm(s, M_RSHIFT, t.rmw_shift);
         setm(s, M_RSCALE, __float_as_uint(t.rmw_scale));
+        if constexpr (SIDE) { // (block indexes do not use the freq_index bit offsets: the list's entry of the tail table rides there)
+            setm(s, M_DBIT_LO, (uint32_t)t.aux1);
+            setm(s, M_DBIT_HI, (uint32_t)(t.aux1 >> 32));
+        }
         if constexpr (META::NPF > 0) { if (s < (uint32_t)META::NPF) meta.pf_blk[s] = 0xFFFFFFFFu; }
         wave_sync();
         s_bytes += vl + 8; // vbyte(n) + list offset

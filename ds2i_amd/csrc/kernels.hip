@@ -52,7 +52,7 @@ DS2I_DEV CtxT<CODEC_T, META, STATS, SHARE_F> make_ctx(LDS& L, const BatchArgs& a
     c.freqs = freqs;
     bind_meta(c.meta, &L.meta[0][0]);
     c.exc = L.exc;
-    if constexpr (CODEC_T != CODEC_PEF) s16_table_init(L.exc);
+    if constexpr (CODEC_T != CODEC_PEF && CODEC_T != CODEC_OPTPFOR) s16_table_init(L.exc); // (block_optpfor kernels decode through the side slots)
     c.win.st = L.st;
     c.win.gbase = a.arena;
     c.win.nbytes = 0;
@@ -63,6 +63,9 @@ DS2I_DEV CtxT<CODEC_T, META, STATS, SHARE_F> make_ctx(LDS& L, const BatchArgs& a
     c.num_docs = a.num_docs;
     c.block_profile = a.block_profile;
     c.skip = (const uint2*)a.skip;
+    c.xslots = a.xslots;
+    c.xovf = a.xovf;
+    c.tails = a.tails;
     c.init_stats();
     return c;
 }
@@ -162,11 +165,12 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
     // and lives in registers (MetaReg); 8/16 lists keep it in LDS (code size)
     constexpr bool REG = TMAX <= 4;
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
-    __shared__ LdsConj<TMAX, !REG, RANKED, CODEC_T != CODEC_PEF> L;
+    __shared__ LdsConj<TMAX, !REG, RANKED, CODEC_T != CODEC_PEF && CODEC_T != CODEC_OPTPFOR> L; // (no Simple16 field table for the Elias-Fano layouts and for block_optpfor through its side slots)
     const uint32_t lane = lane_id();
     // ranked_and with 3+ lists: one freqs buffer for list 0, one shared by the others (each is used where it is decoded)
     constexpr bool SHARE_F = RANKED && TMAX > 2;
     CtxT<CODEC_T, META, STATS, SHARE_F> cx = make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a);
+    cx.want_freqs = WITH_FREQS && !RANKED; // and_freq reads the freq of every match: both parts of a block in one pass (side slots)
     // ranked_and only: per-block max doc_term_weight table (null = no pruning). Three levels, all exact (the bounds
     // are true upper bounds of the float32 score and topk_queue::insert is strict, queries.hpp:157-172):
     //   * blocks of list 0 whose bound cannot enter the heap are skipped without being decoded (skip_list0);
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
         const uint32_t* const cmax0 = pstream ? (const uint32_t*)cx.ptr(0, M_MAXS_LO) : nullptr;
         const uint32_t* const ent0 = pstream ? (const uint32_t*)cx.ptr(0, M_END_LO) : nullptr;
         const uint8_t* data0 = nullptr;
-        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
+        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0, pf_x = 0;
         uint2 s_e = make_uint2(0xFFFFFFFFu, 0u);
         float s_w = 0.f, s_rb = 0.f;
         bool s_none = false; // some other list has no posting at all inside the block's doc-id span: nothing to intersect
@@ -481,6 +485,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                     cx.win.nbytes = 512;
                     cx.win.st[lane] = pf_d0;
                     cx.win.st[lane + 64] = pf_d1;
+                    if (cx.side()) { cx.exc[lane] = pf_x; cx.slot_blk = cx.m(0, M_PBASE) + blk2; } // (its side slot came with them)
                     wave_sync();
                 }
                 PT_END(cx, PH_STREAM);
@@ -504,6 +509,7 @@ __global__ void __launch_bounds__(64, CONJ_WAVES_R(RANKED, TMAX)) k_conjunctive(
                             const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e.y, fn - 1)) & ~(uintptr_t)3);
                             pf_d0 = g[lane];
                             pf_d1 = g[lane + 64];
+                            if (cx.side()) pf_x = cx.xslots[(size_t)XSLOT_DW * (cx.m(0, M_PBASE) + s_first + fn) + lane];
                         }
                         pf_blk = s_first + fn;
                     }
@@ -1787,7 +1793,7 @@ template <int TMAX, int CODEC_T, bool STATS = true>
 __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) {
     constexpr bool REG = TMAX <= 4;
     typedef typename std::conditional<REG, MetaReg<TMAX>, MetaLds>::type META;
-    __shared__ LdsUnionTopk<TMAX, !REG, CODEC_T != CODEC_PEF> L;
+    __shared__ LdsUnionTopk<TMAX, !REG, CODEC_T != CODEC_PEF && CODEC_T != CODEC_OPTPFOR> L;
     const uint32_t lane = lane_id();
     constexpr bool SHARE_F = TMAX > 2; // one freqs buffer for the driver, one shared by the lists that are looked up
     CtxT<CODEC_T, META, STATS, SHARE_F> cx = make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a);
@@ -1876,7 +1882,7 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
             const uint32_t nb0 = cx.m(0, M_NB);
             data0 = cx.ptr(0, M_MAXS_LO) + 4ull * nb0 + 4ull * (nb0 - 1);
         }
-        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0;
+        uint32_t s_first = 0, pf_blk = 0xFFFFFFFFu, pf_d0 = 0, pf_d1 = 0, pf_x = 0;
         uint2 s_e2 = make_uint2(0xFFFFFFFFu, 0u);
         float s_w = 0.f, s_rb = 0.f;
         auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
@@ -1967,6 +1973,7 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                     cx.win.nbytes = 512;
                     cx.win.st[lane] = pf_d0;
                     cx.win.st[lane + 64] = pf_d1;
+                    if (cx.side()) { cx.exc[lane] = pf_x; cx.slot_blk = cx.m(0, M_PBASE) + blk; } // (its side slot came with them)
                     wave_sync();
                 }
                 cx.decode_docs(0, blk, &bi, staged);
@@ -1984,6 +1991,7 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                         const uint32_t* g = (const uint32_t*)((uintptr_t)(data0 + bcast(s_e2.y, fn - 1)) & ~(uintptr_t)3);
                         pf_d0 = g[lane];
                         pf_d1 = g[lane + 64];
+                        if (cx.side()) pf_x = cx.xslots[(size_t)XSLOT_DW * (cx.m(0, M_PBASE) + s_first + fn) + lane];
                     }
                     pf_blk = s_first + fn;
                 }
@@ -2217,6 +2225,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
     __shared__ LdsUnion L;
     const uint32_t lane = lane_id();
     CtxT<CODEC_T, MetaReg<1>, STATS> cx = make_ctx<CODEC_T, MetaReg<1>, STATS>(L, a);
+    cx.want_freqs = WITH_FREQS; // or_freq reads every freq it passes
     for (uint32_t tkt = blockIdx.x; tkt < a.nslice; tkt += gridDim.x) {
         const uint32_t uid = a.order[tkt];
         const unsigned long long t_unit = (STATS && a.unit_clock) ? wall_clock64() : 0ull;
@@ -2295,7 +2304,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                     const bool tabbed = !cx.is_pef() && cx.skip;
                     const uint2* const tab = tabbed ? cx.skip + cx.m(0, M_PBASE) : nullptr;
                     const uint8_t* const data = tabbed ? cx.ptr(0, M_MAXS_LO) + 4ull * nb + 4ull * (nb - 1) : nullptr;
-                    uint32_t wfirst = 0, pf_blk = 0xFFFFFFFFu, pf0 = 0, pf1 = 0;
+                    uint32_t wfirst = 0, pf_blk = 0xFFFFFFFFu, pf0 = 0, pf1 = 0, pfx = 0; // (pfx: the block's exception side slot, with its bytes)
                     uint2 we = make_uint2(0xFFFFFFFFu, 0u);
                     auto wfill = [&](uint32_t first) __attribute__((always_inline)) {
                         wfirst = first;
@@ -2321,6 +2330,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                                 cx.win.nbytes = 512;
                                 cx.win.st[lane] = pf0;
                                 cx.win.st[lane + 64] = pf1;
+                                if (cx.side()) { cx.exc[lane] = pfx; cx.slot_blk = cx.m(0, M_PBASE) + b; }
                                 wave_sync();
                             }
                             if constexpr (WITH_FREQS && CODEC_T == CODEC_OPTPFOR)
@@ -2351,6 +2361,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                                 const uint32_t* g = (const uint32_t*)((uintptr_t)(data + bi.next_ep) & ~(uintptr_t)3);
                                 pf0 = g[lane];
                                 pf1 = g[lane + 64];
+                                if (cx.side()) pfx = cx.xslots[(size_t)XSLOT_DW * (cx.m(0, M_PBASE) + b + 1u) + lane];
                                 pf_blk = b + 1;
                             }
                         } else {
@@ -2370,7 +2381,7 @@ __global__ void __launch_bounds__(64, 5) k_union(BatchArgs a) {
                             }
                             if constexpr (WITH_FREQS) { // or_query<true> reads the freq of every posting it passes (queries.hpp:118-120)
                                 if (ballot(in0) | ballot(in1)) {
-                                    cx.decode_freqs(0);
+                                    if (!cx.m(0, M_FDEC)) cx.decode_freqs(0); // (side slots: decode_docs delivered them already)
                                     unsigned long long fs = (unsigned long long)(in0 ? L.freqs[0][lane] : 0u) + (in1 ? L.freqs[0][lane + 64] : 0u);
                                     for (int o = 32; o; o >>= 1) fs += __shfl_xor(fs, o);
                                     fsum += fs;
@@ -2619,7 +2630,7 @@ __global__ void __launch_bounds__(64) k_build_side_tables(SideArgs a) {
     ba.codec = CODEC_OPTPFOR;
     ba.num_docs = a.num_docs;
     ba.skip = a.skip;
-    auto cx = make_ctx<CODEC_OPTPFOR, MetaLds>(L, ba);
+    Ctx cx = make_ctx<-1, MetaLds>(L, ba); // (the general decoders: CODEC_OPTPFOR as a template argument means "through the side tables")
     const uint32_t lane = lane_id();
     uint32_t bad = 0;
     for (uint32_t item = blockIdx.x; item < a.nitems; item += gridDim.x) {
@@ -2769,6 +2780,10 @@ __global__ void __launch_bounds__(64) k_calib_read(const uint32_t* base, unsigne
 } // namespace
 
 // ------------------------------------------------------------------ launchers (called from capi.cpp)
+// the block_optpfor specialisations decode through the upload-time side tables; an index uploaded without them runs the
+// runtime-codec instantiations
+static inline bool optpfor_side(const BatchArgs& a) { return a.codec == CODEC_OPTPFOR && a.xslots != nullptr && a.tails != nullptr; }
+
 namespace ds2i_launch {
 
 struct Batch {
@@ -2822,25 +2837,25 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
     // block_mixed (configs[4]; its three block types stay a run-time switch, QMX drops out); block_varint /
     // block_interpolative / block_qmx go through the runtime-dispatch instantiation (CODEC_T = -1)
     case OP_AND:
-        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        if (optpfor_side(a) && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
-        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (optpfor_side(a)) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, false, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_AND_FREQ:
-        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        if (optpfor_side(a) && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
-        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (optpfor_side(a)) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<false, true, TMAX, -1>), g, b, 0, s, a);
         break;
     case OP_RANKED_AND:
-        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+        if (optpfor_side(a) && !a.stats) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF && !a.stats) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF, false>), g, b, 0, s, a);
-        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+        else if (optpfor_side(a)) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_PEF>), g, b, 0, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, CODEC_MIXED>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_conjunctive<true, true, TMAX, -1>), g, b, 0, s, a);
@@ -2856,14 +2871,14 @@ hipError_t launch_t(int op, const BatchArgs& a, unsigned grid, hipStream_t s)
     case OP_MAXSCORE:
     case OP_RANKED_OR:
         if (a.vq_info) { // the streaming form (units = (query, driving list, block range)); needs the range tables
-            if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
-            else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
+            if (optpfor_side(a) && !a.stats) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR, false>), g, b, 0, s, a);
+            else if (optpfor_side(a)) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_OPTPFOR>), g, b, 0, s, a);
             else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_union_topk<TMAX, CODEC_PEF>), g, b, 0, s, a);
             else hipLaunchKernelGGL((k_union_topk<TMAX, -1>), g, b, 0, s, a);
             break;
         }
-        if (a.codec == CODEC_OPTPFOR && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, dyn, s, a);
-        else if (a.codec == CODEC_OPTPFOR) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, dyn, s, a);
+        if (optpfor_side(a) && !a.stats) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR, false>), g, b, dyn, s, a);
+        else if (optpfor_side(a)) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_OPTPFOR>), g, b, dyn, s, a);
         else if (a.codec == CODEC_PEF) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_PEF>), g, b, dyn, s, a);
         else if (a.codec == CODEC_MIXED) hipLaunchKernelGGL((k_disjunctive<TMAX, CODEC_MIXED>), g, b, dyn, s, a);
         else hipLaunchKernelGGL((k_disjunctive<TMAX, -1>), g, b, dyn, s, a);
@@ -2901,10 +2916,10 @@ hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned 
     if ((op == OP_OR || op == OP_OR_FREQ) && a.dyn_lists == 0xFFFFFFFFu) { // or_query as a stream: one kernel for every list count
         const dim3 g(grid), b(64);
         const bool f = op == OP_OR_FREQ;
-        if (a.codec == CODEC_OPTPFOR && !a.stats) {
+        if (optpfor_side(a) && !a.stats) {
             if (f) hipLaunchKernelGGL((k_union<true, CODEC_OPTPFOR, false>), g, b, 0, s, a);
             else hipLaunchKernelGGL((k_union<false, CODEC_OPTPFOR, false>), g, b, 0, s, a);
-        } else if (a.codec == CODEC_OPTPFOR) {
+        } else if (optpfor_side(a)) {
             if (f) hipLaunchKernelGGL((k_union<true, CODEC_OPTPFOR>), g, b, 0, s, a);
             else hipLaunchKernelGGL((k_union<false, CODEC_OPTPFOR>), g, b, 0, s, a);
         } else {
