@@ -423,7 +423,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     // 4 with the many-list classes cut 4x finer: 430-457 k, 2: 251 k)
     const bool rmw_units = ranked && conj && idx->d_rmw; // (and / and_freq verify every candidate the tables let through: their cost
                                                          // stays with the blocks of all lists, and they are throughput-, not tail-bound: measured)
-    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? 4.0 : 16.0;
+    // (a small batch -- the per-GPU share of a batch sharded over several GPUs -- is cut coarser still: at 512 queries factor 2
+    // measured 391 k queries/s against 321-328 k with 4; at 4096 it is the other way round)
+    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? (nq < 1536 ? 2.0 : 4.0) : 16.0;
     // wand / maxscore / ranked_or: the streaming form (kernels.hip, k_union_topk) needs the range tables and the block weights;
     // queries beyond 16 terms and k > 64 keep the one-document-per-step kernel, and the whole batch keeps the windowed
     // kernel when any query does (one operator = one kernel family per batch)
@@ -461,8 +463,15 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         // per launch for 18 queries, the longest kernel of the step) -- cut them DS2I_UNIT_DIV_MANY (4) times finer still
         static const char* udm = std::getenv("DS2I_UNIT_DIV_MANY");
         static const double unit_div_many = udm && std::atof(udm) > 0 ? std::atof(udm) : 4.0;
-        const double target = std::max(48.0, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
-                                                 (c == 3 && rmw_cost ? unit_div_many : 1.0));
+        // a unit pays for itself (a dozen dependent round trips before its first block, its own heap to warm up): below a few
+        // dozen blocks that is most of its time. The floor only binds for small batches -- the per-GPU share of a batch
+        // sharded over 8 GPUs: at 512 queries the 3-4-term class was cut into 39 k units of 4 blocks (DS2I_UNIT_FLOOR; 48 = round 4:
+        // 227 k queries/s at batch 512, 192: 300-330 k)
+        static const char* ufl = std::getenv("DS2I_UNIT_FLOOR");
+        static const double unit_floor = ufl && std::atof(ufl) > 0 ? std::atof(ufl) : 0.0;
+        const double floor_cost = unit_floor > 0 ? unit_floor : (rmw_cost && c <= 2) ? 256.0 : 48.0;
+        const double target = std::max(floor_cost, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
+                                                       (c == 3 && rmw_cost ? unit_div_many : 1.0));
         ++b->nqcls[c];
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);

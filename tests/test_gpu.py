@@ -1114,3 +1114,6 @@ def test_clueweb_scale_block_mixed_configs4(built_lib):
     gidx = d.Index("block_mixed", img, wand)
     oidx = o.Index("block_mixed", img, wand)
     _scale_properties(gidx, oidx, queries, nsample=32)
+    # every query of the batch against the threaded oracle at this scale too -- ranked_and top-k, `and` counts
+    # and doc-id lists (checksums) of all 4096, wand / maxscore on the first 256
+    _full_batch_equals_oracle(gidx, oidx, queries, union_n=256)
