@@ -204,6 +204,18 @@ struct SideArgs {
     unsigned int* bad;         // out: blocks whose header disagrees with their decoded values (corrupt image)
 };
 
+// or_query<with_freqs>: the freqs of every posting of every query term, streamed on their own (freq_stream.hip)
+struct FreqArgs {
+    const uint8_t* arena;
+    const void* skip;
+    const uint32_t* xslots;
+    const uint32_t* xovf;
+    const uint32_t* tails;
+    const QTerm* qterms;        // the terms of all queries of the batch
+    const uint32_t* qterm_q;    // the query each of them belongs to
+    unsigned long long* out_freq_sum; // per query: the sum is ADDED (after the union kernels and the merge have written theirs)
+};
+
 struct MergeArgs {
     const uint32_t* split_queries; // ids of queries with nparts > 1
     uint32_t nsplit;

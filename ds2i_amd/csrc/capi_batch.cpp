@@ -33,6 +33,7 @@ using ds2i_dev::Unit;
 extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
+hipError_t ds2i_launch_freq_stream(const void* args, unsigned longest, unsigned nqterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
@@ -132,12 +133,15 @@ struct ds2i_hip_batch {
     std::vector<QTerm> vterms;
     std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
     bool union_stream = false;
+    // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
+    // depend on the union -- by a stream of their own after the merge (freq_stream.hip)
+    bool freq_stream = false;
     uint32_t ncls[NCLS] = {};  // units per kernel class
     uint32_t nqcls[NCLS] = {}; // queries per kernel class
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
     size_t o_vinfo = 0;
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {},
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {}, o_qterm_q = 0,
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -434,6 +438,9 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     static const bool tables_off = std::getenv("DS2I_NO_BMW_PRUNE") || std::getenv("DS2I_NO_RMW_USE"); // (A/B knobs of launch_batch)
     b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
                       !b->long_terms && !no_topk_stream && !tables_off;
+    static const bool no_freq_stream = std::getenv("DS2I_NO_FREQ_STREAM") != nullptr;
+    b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
+                     idx->d_skip && !no_freq_stream && !std::getenv("DS2I_NO_UNION_STREAM");
     b->vterms.clear();
     b->voff.assign(1, 0);
     b->vinfo.clear();
@@ -700,6 +707,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
     for (int c = 0; c < 2; ++c) b->o_urec[c] = place(b->order[c].size() * sizeof(ds2i_dev::UnitRec)); // (classes of k_ranked_stream)
+    b->o_qterm_q = place(b->freq_stream ? qterms.size() * 4 : 0);
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
     b->up_bytes = o + 16;
     const size_t nq1 = nq ? nq : 1, nu1 = b->nunits ? b->nunits : 1;
@@ -798,6 +806,11 @@ int upload_batch(ds2i_hip_batch* b) {
     put(b->o_single, b->single_queries.data(), b->single_queries.size() * 4);
     put(b->o_hslot, b->hist_slot.data(), b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) put(b->o_order[c], b->order[c].data(), b->order[c].size() * 4);
+    if (b->freq_stream) { // or_freq: the query of every term (k_freq_stream adds a term's freqs to its query's checksum)
+        uint32_t* qq = (uint32_t*)(h + b->o_qterm_q);
+        for (uint32_t q = 0; q < b->nq; ++q)
+            for (uint32_t i = b->qoff[q]; i < b->qoff[q + 1]; ++i) qq[i] = q;
+    }
     for (int c = 0; c < 2 && !b->union_stream; ++c) { // one record per ticket: what k_ranked_stream reads where a unit starts (conjunctive batches)
         ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
         for (size_t i = 0; i < b->order[c].size(); ++i) {
@@ -865,6 +878,34 @@ int launch_batch(ds2i_hip_batch* b) {
     }
     HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
     if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
+    if (b->freq_stream && !b->qterms.empty()) {
+        // beside the union kernels, on the stream of the >16-term class when the batch has no such query (else on the merge
+        // stream, ahead of the merge): nobody else writes the checksums (the union kernels and k_merge get no pointer to them)
+        const bool own = b->ncls[CLS_LONG] == 0;
+        hipStream_t sf = own ? idx->stream[CLS_LONG] : sm;
+        if (own) HIP_OK(hipStreamWaitEvent(sf, b->ev_clear, 0));
+        ds2i_dev::FreqArgs f{};
+        f.arena = idx->d_arena;
+        f.skip = idx->d_skip;
+        f.xslots = idx->d_xslots;
+        f.xovf = idx->d_xovf;
+        f.tails = idx->d_tails;
+        f.qterms = b->d_up.at<QTerm>(b->o_qterms);
+        f.qterm_q = b->d_up.at<uint32_t>(b->o_qterm_q);
+        f.out_freq_sum = b->d_out.at<unsigned long long>(b->o_freq_sum);
+        uint32_t longest = 1; // (the grid has one row per term, as wide as the longest list needs)
+        for (const QTerm& t : b->qterms) longest = std::max(longest, t.nblocks);
+        for (size_t t0 = 0; t0 < b->qterms.size(); t0 += 32768) { // (grid.y is limited to 65535)
+            ds2i_dev::FreqArgs g = f;
+            g.qterms += t0;
+            g.qterm_q += t0;
+            HIP_OK(ds2i_launch_freq_stream(&g, longest, (unsigned)std::min<size_t>(32768, b->qterms.size() - t0), sf));
+        }
+        if (own) {
+            HIP_OK(hipEventRecord(b->ev_c1[CLS_LONG], sf));
+            HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[CLS_LONG], 0));
+        }
+    }
     // DS2I_GROUP_SPREAD=1: the second and later launch groups of a class go to the streams of classes this batch has no
     // queries in (no further hardware queues are opened), so that a class stream is not held by its short groups
     static const char* e_spread = std::getenv("DS2I_GROUP_SPREAD");
@@ -907,7 +948,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.out_count = b->d_out.at<unsigned long long>(b->o_count);
         a.out_topk = b->d_out.at<float>(b->o_topk);
         a.out_topk_len = b->d_out.at<uint32_t>(b->o_topk_len);
-        a.out_freq_sum = b->d_out.at<unsigned long long>(b->o_freq_sum);
+        a.out_freq_sum = b->freq_stream ? nullptr : b->d_out.at<unsigned long long>(b->o_freq_sum);
         a.out_matches = b->want_matches ? (uint32_t*)b->d_matches.p : nullptr;
         a.match_off = b->want_matches ? b->d_up.at<unsigned long long>(b->o_match_off) : nullptr;
         a.unit_count = b->d_scr.at<unsigned long long>(b->o_unit_count);
@@ -955,7 +996,7 @@ int launch_batch(ds2i_hip_batch* b) {
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
                 HIP_OK(idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
-            else HIP_OK(ds2i_launch_batch(b->op & (0xFF | DS2I_OP_REFERENCE_ORDER), c, &a, a.nslice, sg));
+            else HIP_OK(ds2i_launch_batch(b->freq_stream ? (int)DS2I_OP_OR : (b->op & (0xFF | DS2I_OP_REFERENCE_ORDER)), c, &a, a.nslice, sg));
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));
             if (sg != s) HIP_OK(hipStreamWaitEvent(sm, b->ev_g[c][2 * gi + 1], 0));
         }
@@ -976,7 +1017,7 @@ int launch_batch(ds2i_hip_batch* b) {
         m.out_count = b->d_out.at<unsigned long long>(b->o_count);
         m.out_topk = b->d_out.at<float>(b->o_topk);
         m.out_topk_len = b->d_out.at<uint32_t>(b->o_topk_len);
-        m.out_freq_sum = b->d_out.at<unsigned long long>(b->o_freq_sum);
+        m.out_freq_sum = b->freq_stream ? nullptr : b->d_out.at<unsigned long long>(b->o_freq_sum);
         HIP_OK(ds2i_launch_merge(&m, std::min<unsigned>(b->nsplit, 4096u), sm));
     }
     if (b->use_seed && b->nsingle)
