@@ -83,6 +83,7 @@ def lib():
         for f in ("ds2i_hip_index_size", "ds2i_hip_index_num_docs", "ds2i_hip_index_device_bytes"):
             getattr(L, f).argtypes = [vp]
             getattr(L, f).restype = C.c_uint64
+        L.ds2i_hip_index_get_info.argtypes = [vp, vp]
         L.ds2i_hip_list_size.argtypes = [vp, C.c_uint32, u64p]
         L.ds2i_hip_decode_list.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, u64p]
         L.ds2i_hip_query_batch.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(Stats)]
@@ -556,6 +557,14 @@ def flatten_queries(queries):
     return _flatten(queries)
 
 
+class IndexInfo(C.Structure):
+    """ds2i_hip_index_info (include/ds2i_hip.h)"""
+    _fields_ = [("index_bytes", C.c_uint64), ("skip_table_bytes", C.c_uint64), ("block_weight_bytes", C.c_uint64), ("range_table_bytes", C.c_uint64),
+                ("norm_len_bytes", C.c_uint64), ("total_blocks", C.c_uint64), ("total_postings", C.c_uint64), ("has_block_weights", C.c_int),
+                ("has_range_tables", C.c_int), ("has_bitmaps", C.c_int), ("has_membership_hints", C.c_int), ("range_table_entries_per_posting", C.c_int),
+                ("side_table_bytes", C.c_uint64), ("has_side_tables", C.c_int)]
+
+
 class Index:
     """block_freq_index resident in one GPU's HBM (Index concept: size(), num_docs(), operator[])."""
 
@@ -574,6 +583,12 @@ class Index:
 
     def device_bytes(self):
         return lib().ds2i_hip_index_device_bytes(self._h)
+
+    def info(self):
+        """what the upload put into HBM beside the index image (ds2i_hip_index_get_info), as a dict"""
+        i = IndexInfo()
+        _check(lib().ds2i_hip_index_get_info(self._h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in IndexInfo._fields_}
 
     def list_size(self, term):
         n = C.c_uint64()

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "../../include/ds2i_build.h"
 #include "host_index.hpp"
 #include "host_pef.hpp"
 #include <atomic>
@@ -367,8 +368,80 @@ int ds2i_hip_device_count(void) {
     return n;
 }
 
+static int index_open_impl(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, bool bare,
+                           ds2i_hip_index** out);
+
+// block_mixed, the default upload: the image is TRANSCODED to the block codec this device decodes fastest. The mixed
+// image is uploaded bare (no tables), every list decoded by the mixed-block kernels (mixed_block.hpp:198-217: OptPFor /
+// VarInt-G8IU / interpolative by type byte), the postings re-encoded by the GPU index encoder as block_optpfor
+// (encode_kernels.hip, byte-identical to the host builder), and THAT image is what the query kernels see -- with its skip
+// table, block weights, range tables and exception side slots. The answers are those of the mixed index (same postings); what
+// changes is that a query never waits for the lane-0 interpolative walk (12 % of the fixed policy's blocks at 11 x the cost
+// of an OptPFor block) or the descriptor-driven VarInt-G8IU gather. DS2I_MIXED_NATIVE=1 keeps the image as it is and runs the
+// mixed-codec kernels (k_ranked_stream_mixed, the CODEC_MIXED instantiations).
+static int index_open_transcoded(int device, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, ds2i_hip_index** out) {
+    ds2i_hip_index* raw = nullptr;
+    int rc = index_open_impl(device, DS2I_BLOCK_MIXED, index_image, index_bytes, nullptr, 0, true, &raw);
+    if (rc) return rc;
+    std::unique_ptr<ds2i_hip_index, void (*)(ds2i_hip_index*)> guard(raw, free_index);
+    const uint64_t V = raw->size;
+    std::vector<uint64_t> offs(V + 1, 0);
+    uint32_t longest = 1;
+    for (uint64_t t = 0; t < V; ++t) {
+        offs[t + 1] = offs[t] + raw->list_n[t];
+        longest = std::max(longest, raw->list_n[t]);
+    }
+    std::vector<uint32_t> docs, freqs;
+    try {
+        docs.resize(offs[V]);
+        freqs.resize(offs[V]);
+    } catch (std::bad_alloc const&) {
+        return ds2i_set_error(DS2I_ENOMEM, "out of host memory transcoding a block_mixed index (DS2I_MIXED_NATIVE=1 uploads it as it is)");
+    }
+    {
+        DevTemps tmp;
+        uint32_t *d_docs = nullptr, *d_freqs = nullptr;
+        HIP_OK(tmp.alloc(&d_docs, 4 * ((size_t)longest + 128)));
+        HIP_OK(tmp.alloc(&d_freqs, 4 * ((size_t)longest + 128)));
+        for (uint64_t t = 0; t < V; ++t) {
+            DecodeArgs a{};
+            a.arena = raw->d_arena;
+            a.term = ds2i_make_qterm(raw, (uint32_t)t);
+            a.codec = DS2I_BLOCK_MIXED;
+            a.num_docs = (uint32_t)raw->num_docs;
+            a.out_docs = d_docs;
+            a.out_freqs = d_freqs;
+            HIP_OK(ds2i_launch_decode_list(&a, (unsigned)std::min<uint64_t>(raw->list_nb[t], uint64_t(raw->num_cus) * 16), raw->stream[0]));
+            HIP_OK(hipMemcpyAsync(docs.data() + offs[t], d_docs, 4 * (size_t)raw->list_n[t], hipMemcpyDeviceToHost, raw->stream[0]));
+            HIP_OK(hipMemcpyAsync(freqs.data() + offs[t], d_freqs, 4 * (size_t)raw->list_n[t], hipMemcpyDeviceToHost, raw->stream[0]));
+            HIP_OK(hipStreamSynchronize(raw->stream[0])); // (the two device buffers are reused by the next list)
+        }
+    }
+    const uint64_t num_docs = raw->num_docs;
+    guard.reset(); // the mixed image leaves the device before the transcoded one arrives
+    ds2i_blob* img = nullptr;
+    rc = ds2i_hip_encode_index(device, DS2I_BLOCK_OPTPFOR, num_docs, V, offs.data(), docs.data(), freqs.data(), &img, nullptr);
+    if (rc) return rc;
+    std::vector<uint32_t>().swap(docs);
+    std::vector<uint32_t>().swap(freqs);
+    rc = index_open_impl(device, DS2I_BLOCK_OPTPFOR, ds2i_blob_data(img), ds2i_blob_size(img), wand_image, wand_bytes, false, out);
+    ds2i_blob_free(img);
+    if (rc == DS2I_OK) (*out)->kind_on_disk = DS2I_BLOCK_MIXED;
+    return rc;
+}
+
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
+    if (kind == DS2I_BLOCK_MIXED && out && index_image && !std::getenv("DS2I_MIXED_NATIVE")) {
+        const int ndev = ds2i_hip_device_count();
+        if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
+        return index_open_transcoded(device, index_image, index_bytes, wand_image, wand_bytes, out);
+    }
+    return index_open_impl(device, kind, index_image, index_bytes, wand_image, wand_bytes, false, out);
+}
+
+static int index_open_impl(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, bool bare,
+                           ds2i_hip_index** out) {
     if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
     if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_UNIFORM)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
@@ -566,11 +639,11 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));
-    if (x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {
+    if (!bare && x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;
     }
-    if (kind == DS2I_BLOCK_OPTPFOR) {
+    if (!bare && kind == DS2I_BLOCK_OPTPFOR) {
         int rc = build_side_tables(x.get());
         if (rc) return rc;
     }

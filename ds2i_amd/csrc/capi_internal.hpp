@@ -79,6 +79,7 @@ struct ds2i_hip_batch;
 
 struct ds2i_hip_index {
     int device = 0, kind = 0, num_cus = 256;
+    int kind_on_disk = -1;          // the index kind the caller uploaded when it differs from `kind` (block_mixed transcoded at upload), else -1
     uint64_t size = 0, num_docs = 0;
     uint8_t* d_arena = nullptr;
     uint64_t arena_bytes = 0;

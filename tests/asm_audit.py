@@ -14,7 +14,7 @@ def kernels(asm_text):
     out, cur, name = {}, None, None
     for line in asm_text.splitlines():
         m = re.match(r"^(_Z\w+):", line)
-        if m and "k_ranked_stream" in m.group(1):
+        if m and ("k_ranked_stream" in m.group(1) or "k_freq_stream" in m.group(1)):
             name, cur = m.group(1), []
             out[name] = cur
             continue

@@ -2,6 +2,8 @@
 
 Bit-exact for doc-id lists, counts and decoded postings; BM25 top-k within 1e-5 relative (north_star).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -91,6 +93,37 @@ def test_decode_every_list(coll, images, codec):
         dd, ff = idx[t]
         assert np.array_equal(dd, docs), (codec, t)
         assert np.array_equal(ff, freqs), (codec, t)
+
+
+@pytest.fixture
+def mixed_native(monkeypatch):
+    """block_mixed images are transcoded to block_optpfor at upload by default; DS2I_MIXED_NATIVE=1 (read by
+    ds2i_hip_index_open) keeps the image and runs the mixed-codec kernels."""
+    monkeypatch.setenv("DS2I_MIXED_NATIVE", "1")
+
+
+def test_block_mixed_native_decoders_and_kernels(coll, queries, images, mixed_native):
+    """The mixed-codec device path itself (mixed_block.hpp:198-217 by type byte; k_ranked_stream_mixed and the CODEC_MIXED
+    instantiations): every list decoded == the raw lists, every operator == the oracle. (Without the switch a block_mixed
+    upload is transcoded and these kernels only run inside the upload's decode pass.)"""
+    idx = d.Index("block_mixed", images[0]["block_mixed"], images[1])
+    for t, (docs, freqs) in enumerate(coll.lists):
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+    oidx = o.Index("block_mixed", images[0]["block_mixed"], images[1])
+    for op in ALL_OPS:
+        _check_against_oracle(idx, oidx, op, queries)
+
+
+def test_block_mixed_is_transcoded_at_upload(coll, images):
+    """the default upload of a block_mixed image: the device holds a block_optpfor index with its side tables (reported by
+    ds2i_hip_index_get_info), and every list it decodes is the mixed image's list"""
+    idx = d.Index("block_mixed", images[0]["block_mixed"], images[1])
+    info = idx.info()
+    assert info["has_side_tables"] and info["side_table_bytes"] > 0
+    for t, (docs, freqs) in enumerate(coll.lists):
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
 
 
 def _check_against_oracle(gidx, oidx, op, queries, k=10, reference_order=False):
@@ -1111,9 +1144,15 @@ def test_clueweb_scale_block_mixed_configs4(built_lib):
     assert nd > 20000 and all(c > 0.05 * nd for c in tc["docs"]), tc       # pfor, varint, interpolative: > 5 % each
     assert sum(c > 0.05 * nf for c in tc["freqs"]) >= 2, tc
     queries = d.synth_queries(0x51E21, p.num_terms, 4096)
-    gidx = d.Index("block_mixed", img, wand)
     oidx = o.Index("block_mixed", img, wand)
-    _scale_properties(gidx, oidx, queries, nsample=32)
+    os.environ["DS2I_MIXED_NATIVE"] = "1"  # the mixed-codec kernels on the image as it is: properties + a 32-query oracle sample
+    try:
+        gidx = d.Index("block_mixed", img, wand)
+        _scale_properties(gidx, oidx, queries, nsample=32)
+        gidx.close()
+    finally:
+        del os.environ["DS2I_MIXED_NATIVE"]
+    gidx = d.Index("block_mixed", img, wand)  # the default upload: transcoded to block_optpfor + side tables
     # every query of the batch against the threaded oracle at this scale too -- ranked_and top-k, `and` counts
     # and doc-id lists (checksums) of all 4096, wand / maxscore on the first 256
     _full_batch_equals_oracle(gidx, oidx, queries, union_n=256)
