@@ -1797,6 +1797,7 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
     const uint32_t lane = lane_id();
     constexpr bool SHARE_F = TMAX > 2; // one freqs buffer for the driver, one shared by the lists that are looked up
     CtxT<CODEC_T, META, STATS, SHARE_F> cx = make_ctx<CODEC_T, META, STATS, SHARE_F>(L, a);
+    cx.want_freqs = cx.side(); // (the driver's freqs with its doc-ids: every posting gets its own bound before any gather)
     const float* const bmw = a.bmw;
     const uint8_t* const rmw = a.rmw;
     constexpr int NW = (TMAX + 3) / 4; // a candidate's bytes, four lists to a dword (byte i = list slot i; slot 0 unused)
@@ -1872,6 +1873,11 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
             }
             return r;
         };
+        // what the optional lists can add to any document at most (their list maxima, summed like rest_of sums their bytes)
+        uint32_t pk_ff[NW];
+#pragma unroll
+        for (int k2 = 0; k2 < NW; ++k2) pk_ff[k2] = 0xFFFFFFFFu;
+        const float opt_all = rest_of(pk_ff, 0);
         // ---- the driver as a stream (see k_conjunctive): table window in registers, next block requested ahead
         const bool pstream = cx.is_pef();
         const uint2* const tab0 = pstream ? nullptr : cx.skip + cx.m(0, M_PBASE);
@@ -1998,6 +2004,20 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
             }
             const uint32_t c0 = L.docs[0][lane], c1 = L.docs[0][lane + 64];
             bool al0 = c0 != 0xFFFFFFFFu, al1 = c1 != 0xFFFFFFFFu;
+            // block_optpfor through the side slots: the block's freqs came with its doc-ids, so every posting has a bound of its
+            // OWN term score (doc_term_weight falls with norm_len: the collection's shortest document bounds it from the freq
+            // alone). Only the postings that could enter the heap with that bound + the optional lists' maxima ask the other
+            // lists' tables at all -- a gather is a cache line per posting and list, and this operator's were 56 GB per batch --
+            // and the tests below use the posting's own bound where they used the block's weight.
+            float wb0 = wblk, wb1 = wblk;
+            if (cx.side() && cx.m(0, M_FDEC)) {
+                const float o0 = qw0 * doc_term_weight(L.freqs[0][lane], a.min_norm_len), o1 = qw0 * doc_term_weight(L.freqs[0][lane + 64], a.min_norm_len);
+                wb0 = o0 < wblk ? o0 : wblk;
+                wb1 = o1 < wblk ? o1 : wblk;
+                al0 = al0 && tk.would_enter((wb0 + opt_all) * BOUND_SLACK);
+                al1 = al1 && tk.would_enter((wb1 + opt_all) * BOUND_SLACK);
+                if (!(ballot(al0) | ballot(al1))) continue;
+            }
             // ---- the candidates' bytes in every other list: one gather per list, all issued before the first is consumed
             uint32_t pk0[NW] = {}, pk1[NW] = {};
             {
@@ -2025,8 +2045,8 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                 };
                 static_list_loop<1, TMAX>(nt, load_first);
                 if (split + 1u < nt) {
-                    al0 = al0 && tk.would_enter((wblk + f0 + suf_split) * BOUND_SLACK);
-                    al1 = al1 && tk.would_enter((wblk + f1 + suf_split) * BOUND_SLACK);
+                    al0 = al0 && tk.would_enter((wb0 + f0 + suf_split) * BOUND_SLACK);
+                    al1 = al1 && tk.would_enter((wb1 + f1 + suf_split) * BOUND_SLACK);
                     auto load_rest = [&](auto ic) __attribute__((always_inline)) {
                         constexpr uint32_t i = decltype(ic)::value;
                         if (i <= split) return true;
@@ -2047,8 +2067,8 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                 static_list_loop<1, TMAX>(nt, pack_one);
             }
             float r0 = rest_of(pk0, 0), r1 = rest_of(pk1, 0);
-            al0 = al0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
-            al1 = al1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+            al0 = al0 && tk.would_enter((wb0 + r0) * BOUND_SLACK);
+            al1 = al1 && tk.would_enter((wb1 + r1) * BOUND_SLACK);
             if (!(ballot(al0) | ballot(al1))) continue; // nobody of this block can enter: its freqs stay undecoded
             if (a.rmh) {
                 // ---- membership hints (BatchArgs::rmh; block_optpfor indexes): a non-zero byte says SOME posting of list i lies in
@@ -2119,12 +2139,12 @@ __global__ void __launch_bounds__(64, UT_WAVES(TMAX)) k_union_topk(BatchArgs a) 
                 }
                 r0 = rest_of(pk0, 0);
                 r1 = rest_of(pk1, 0);
-                al0 = al0 && tk.would_enter((wblk + r0) * BOUND_SLACK);
-                al1 = al1 && tk.would_enter((wblk + r1) * BOUND_SLACK);
+                al0 = al0 && tk.would_enter((wb0 + r0) * BOUND_SLACK);
+                al1 = al1 && tk.would_enter((wb1 + r1) * BOUND_SLACK);
                 if (!(ballot(al0) | ballot(al1))) continue;
             }
             // ---- the driver's own term score: freq-only bound first, then the norm_len gather
-            cx.decode_freqs(0);
+            if (!cx.m(0, M_FDEC)) cx.decode_freqs(0);
             const uint32_t f0 = L.freqs[0][lane], f1 = L.freqs[0][lane + 64];
             al0 = al0 && tk.would_enter((qw0 * doc_term_weight(f0, a.min_norm_len) + r0) * BOUND_SLACK);
             al1 = al1 && tk.would_enter((qw0 * doc_term_weight(f1, a.min_norm_len) + r1) * BOUND_SLACK);
