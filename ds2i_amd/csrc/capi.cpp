@@ -351,13 +351,32 @@ const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
 // before the runtime initialises; an explicit setting of the user wins.
 __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
-bool g_ds2i_options_frozen = false; // set when the first batch is planned (capi_batch.cpp): the knobs are function-local statics
+// Two phases of the knobs: the ones an upload reads (tables to build, stream sets) are frozen by the first
+// ds2i_hip_index_open, the ones the planner / launcher read by the first batch (capi_batch.cpp). Both are function-local
+// statics or per-upload reads of the environment; setting one after its phase would be silently ignored, so it is refused.
+std::atomic<bool> g_ds2i_options_frozen{false};
+static std::atomic<bool> g_ds2i_upload_options_frozen{false};
+namespace {
+const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE",
+                                    "DS2I_STREAM_SETS", "DS2I_FLAT_PRIORITY"};
+const char* const kBatchKnobs[] = {"DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
+                                   "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
+                                   "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
+                                   "DS2I_SEED_STREAM", "DS2I_SEED_TERMS", "DS2I_UNIT_CAP", "DS2I_UNIT_CLOCK", "DS2I_UNIT_DIV", "DS2I_UNIT_DIV_MANY", "DS2I_UNIT_DIV_RMW",
+                                   "DS2I_UNIT_FACTOR", "DS2I_UNIT_FLOOR", "DS2I_UT_BLOCKS", "DS2I_UT_DIV_MANY", "DS2I_UT_FIRST"};
+}
 
 int ds2i_hip_set_option(const char* name, const char* value) {
     if (!name || std::strncmp(name, "DS2I_", 5) != 0 || std::strlen(name) > 48) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
     for (const char* c = name; *c; ++c)
         if (!((*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_')) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
-    if (g_ds2i_options_frozen) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first batch)");
+    bool upload = false, batch = false;
+    for (const char* k : kUploadKnobs) upload = upload || std::strcmp(k, name) == 0;
+    for (const char* k : kBatchKnobs) batch = batch || std::strcmp(k, name) == 0;
+    if (!upload && !batch) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: unknown knob (DESIGN.md 7c lists them)");
+    if (upload && g_ds2i_upload_options_frozen.load())
+        return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: an index has been uploaded already (this knob is read by ds2i_hip_index_open)");
+    if (g_ds2i_options_frozen.load()) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first batch)");
     if (value) setenv(name, value, 1); else unsetenv(name);
     return DS2I_OK;
 }
@@ -432,6 +451,7 @@ static int index_open_transcoded(int device, const void* index_image, size_t ind
 
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
+    g_ds2i_upload_options_frozen.store(true);
     if (kind == DS2I_BLOCK_MIXED && out && index_image && !std::getenv("DS2I_MIXED_NATIVE")) {
         const int ndev = ds2i_hip_device_count();
         if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");

@@ -6,6 +6,7 @@
 // blocks on the device -- the host plans batch i+1 while the kernels of batch i run.
 // There is NO CPU fallback: every query result comes from the HIP kernels or the call fails.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,7 +24,7 @@
 #include "capi_internal.hpp"
 #include "host_index.hpp"
 
-extern bool g_ds2i_options_frozen; // capi.cpp
+extern std::atomic<bool> g_ds2i_options_frozen; // capi.cpp
 using ds2i_dev::BatchArgs;
 using ds2i_dev::MergeArgs;
 using ds2i_dev::QTerm;
@@ -203,7 +204,7 @@ void order_by_cost(const std::vector<float>& cost, const std::vector<uint32_t>& 
 int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
                int want_matches) {
     ds2i_hip_index* idx = b->idx;
-    g_ds2i_options_frozen = true; // (ds2i_hip_set_option: the knobs below are read once)
+    g_ds2i_options_frozen.store(true); // (ds2i_hip_set_option: the knobs below are read once)
     const auto plan_t0 = std::chrono::steady_clock::now();
     if (!query_offsets || (!terms && nq && query_offsets[nq] > 0))
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
