@@ -216,6 +216,33 @@ struct FreqArgs {
     unsigned long long* out_freq_sum; // per query: the sum is ADDED (after the union kernels and the merge have written theirs)
 };
 
+// and_query / and_query<with_freqs> of queries whose lists are ALL dense enough to carry their exact bitmap (RmwLevels::has_bitmap):
+// every list that has to be read is streamed on its own (freq_stream.hip, k_and_stream), membership in the OTHER lists is one bit
+// gather per posting and list -- no list is searched, none is decoded for another list's sake
+struct StreamTerm {
+    uint64_t list_off;   // as QTerm
+    uint64_t tail;       // QTerm::aux1: the list's entry of the tail table
+    uint32_t n;
+    uint32_t blk_base;
+    uint32_t q;          // the query the sums belong to
+    uint32_t counts;     // 1: this list's matches are the query's result count (its shortest list), 0: freqs only
+    uint32_t nother;     // other lists of the query (1..3)
+    uint32_t pad;
+    uint64_t bm[3];      // byte offsets of their bitmaps from BatchArgs::rmw
+};
+static_assert(sizeof(StreamTerm) == 64, "StreamTerm is a 64-byte device record");
+struct AndStreamArgs {
+    const uint8_t* arena;
+    const void* skip;
+    const uint32_t* xslots;
+    const uint32_t* xovf;
+    const uint32_t* tails;
+    const uint8_t* rmw;
+    const StreamTerm* terms;
+    unsigned long long* out_count;
+    unsigned long long* out_freq_sum; // or null (and_query)
+};
+
 struct MergeArgs {
     const uint32_t* split_queries; // ids of queries with nparts > 1
     uint32_t nsplit;

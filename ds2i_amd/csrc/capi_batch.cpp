@@ -35,6 +35,7 @@ extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
 hipError_t ds2i_launch_freq_stream(const void* args, unsigned longest, unsigned nqterms, hipStream_t s); // freq_stream.hip
+hipError_t ds2i_launch_and_stream(const void* args, int with_freqs, unsigned longest, unsigned nterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
@@ -137,12 +138,16 @@ struct ds2i_hip_batch {
     // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
     // depend on the union -- by a stream of their own after the merge (freq_stream.hip)
     bool freq_stream = false;
+    // and / and_freq: the queries whose lists all carry their exact bitmap are answered by list streams (freq_stream.hip,
+    // k_and_stream) and get no work units; sterms = one record per list that has to be read
+    std::vector<ds2i_dev::StreamTerm> sterms;
+    uint32_t sterm_longest = 0;
     uint32_t ncls[NCLS] = {};  // units per kernel class
     uint32_t nqcls[NCLS] = {}; // queries per kernel class
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
     size_t o_vinfo = 0;
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {}, o_qterm_q = 0,
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {}, o_qterm_q = 0, o_sterms = 0,
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -439,6 +444,12 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     static const bool tables_off = std::getenv("DS2I_NO_BMW_PRUNE") || std::getenv("DS2I_NO_RMW_USE"); // (A/B knobs of launch_batch)
     b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
                       !b->long_terms && !no_topk_stream && !tables_off;
+    static const bool no_and_stream = std::getenv("DS2I_NO_AND_STREAM") != nullptr;
+    const bool and_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
+                            idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_rmw && idx->has_bitmaps && !no_and_stream &&
+                            !std::getenv("DS2I_NO_BITMAP_USE") && !std::getenv("DS2I_NO_RMW_USE");
+    b->sterms.clear();
+    b->sterm_longest = 0;
     static const bool no_freq_stream = std::getenv("DS2I_NO_FREQ_STREAM") != nullptr;
     b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
                      idx->d_skip && !no_freq_stream && !std::getenv("DS2I_NO_UNION_STREAM");
@@ -481,6 +492,38 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
         const double target = std::max(floor_cost, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
                                                        (c == 3 && rmw_cost ? unit_div_many : 1.0));
         ++b->nqcls[c];
+        if (and_stream && nt >= 2 && nt <= 4) {
+            // every list carries its exact bitmap: the query is a sum over the postings of its shortest list (and, with the freqs,
+            // over every list's own postings) of one bit test per other list -- list streams, no units (k_and_stream)
+            // (and_query reads only its shortest list: that one needs no bitmap of its own)
+            bool dense = true;
+            for (uint32_t i = qoff[q] + (base_op == DS2I_OP_AND ? 1u : 0u); i < qoff[q + 1]; ++i)
+                dense = dense && ds2i_dev::RmwLevels::has_bitmap(qterms[i].n, (uint32_t)idx->num_docs);
+            if (dense) {
+                const uint32_t lists = base_op == DS2I_OP_AND_FREQ ? nt : 1u;
+                for (uint32_t i = 0; i < lists; ++i) {
+                    const QTerm& t = qterms[qoff[q] + i];
+                    ds2i_dev::StreamTerm st{};
+                    st.list_off = t.list_off;
+                    st.tail = t.aux1;
+                    st.n = t.n;
+                    st.blk_base = t.blk_base;
+                    st.q = q;
+                    st.counts = i == 0 ? 1u : 0u;
+                    st.nother = nt - 1;
+                    uint32_t k2 = 0;
+                    for (uint32_t j = 0; j < nt; ++j) {
+                        if (j == i) continue;
+                        const QTerm& o = qterms[qoff[q] + j];
+                        st.bm[k2++] = 64ull * o.rmw_off64 + ds2i_dev::RmwLevels((uint32_t)idx->num_docs, o.rmw_shift).bytes();
+                    }
+                    b->sterms.push_back(st);
+                    b->sterm_longest = std::max(b->sterm_longest, t.nblocks);
+                }
+                b->q_unit_off[q + 1] = (uint32_t)b->units.size();
+                continue;
+            }
+        }
         if (seeded && nt == 1) { // one list: wand == maxscore == ranked_and, answered by the (block-synchronous) seed pass
             b->single_queries.push_back(q);
             b->q_unit_off[q + 1] = (uint32_t)b->units.size();
@@ -709,6 +752,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
     for (int c = 0; c < 2; ++c) b->o_urec[c] = place(b->order[c].size() * sizeof(ds2i_dev::UnitRec)); // (classes of k_ranked_stream)
     b->o_qterm_q = place(b->freq_stream ? qterms.size() * 4 : 0);
+    b->o_sterms = place(b->sterms.size() * sizeof(ds2i_dev::StreamTerm));
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
     b->up_bytes = o + 16;
     const size_t nq1 = nq ? nq : 1, nu1 = b->nunits ? b->nunits : 1;
@@ -807,6 +851,7 @@ int upload_batch(ds2i_hip_batch* b) {
     put(b->o_single, b->single_queries.data(), b->single_queries.size() * 4);
     put(b->o_hslot, b->hist_slot.data(), b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) put(b->o_order[c], b->order[c].data(), b->order[c].size() * 4);
+    put(b->o_sterms, b->sterms.data(), b->sterms.size() * sizeof(ds2i_dev::StreamTerm));
     if (b->freq_stream) { // or_freq: the query of every term (k_freq_stream adds a term's freqs to its query's checksum)
         uint32_t* qq = (uint32_t*)(h + b->o_qterm_q);
         for (uint32_t q = 0; q < b->nq; ++q)
@@ -879,6 +924,28 @@ int launch_batch(ds2i_hip_batch* b) {
     }
     HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
     if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
+    if (!b->sterms.empty()) { // and / and_freq of the all-dense queries: list streams beside the class kernels (nobody else writes these queries' results)
+        ds2i_dev::AndStreamArgs g{};
+        g.arena = idx->d_arena;
+        g.skip = idx->d_skip;
+        g.xslots = idx->d_xslots;
+        g.xovf = idx->d_xovf;
+        g.tails = idx->d_tails;
+        g.rmw = idx->d_rmw;
+        g.out_count = b->d_out.at<unsigned long long>(b->o_count);
+        g.out_freq_sum = base_op == DS2I_OP_AND_FREQ ? b->d_out.at<unsigned long long>(b->o_freq_sum) : nullptr;
+        const bool own = b->ncls[CLS_LONG] == 0;
+        hipStream_t sf = own ? idx->stream[CLS_LONG] : sm;
+        if (own) HIP_OK(hipStreamWaitEvent(sf, b->ev_clear, 0));
+        for (size_t t0 = 0; t0 < b->sterms.size(); t0 += 32768) { // (grid.y is limited to 65535)
+            g.terms = b->d_up.at<ds2i_dev::StreamTerm>(b->o_sterms) + t0;
+            HIP_OK(ds2i_launch_and_stream(&g, base_op == DS2I_OP_AND_FREQ ? 1 : 0, b->sterm_longest, (unsigned)std::min<size_t>(32768, b->sterms.size() - t0), sf));
+        }
+        if (own) {
+            HIP_OK(hipEventRecord(b->ev_c1[CLS_LONG], sf));
+            HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[CLS_LONG], 0));
+        }
+    }
     if (b->freq_stream && !b->qterms.empty()) {
         // beside the union kernels, on the stream of the >16-term class when the batch has no such query (else on the merge
         // stream, ahead of the merge): nobody else writes the checksums (the union kernels and k_merge get no pointer to them)

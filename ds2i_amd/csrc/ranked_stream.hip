@@ -40,10 +40,6 @@ using namespace ds2i_dev;
 
 namespace {
 
-#ifndef DS2I_RS_FLOOR_EVERY
-#define DS2I_RS_FLOOR_EVERY 4 // power of two: the shared histogram is consulted every n-th visited block
-#endif
-static_assert(DS2I_RS_FLOOR_EVERY > 0 && (DS2I_RS_FLOOR_EVERY & (DS2I_RS_FLOOR_EVERY - 1)) == 0, "DS2I_RS_FLOOR_EVERY is used as a mask: power of two");
 #ifndef DS2I_RS_OCC2
 #define DS2I_RS_OCC2 6
 #endif
