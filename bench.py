@@ -285,6 +285,11 @@ def main():
         "config": {"workload": "%s, %s, %s, batch=%d" % (W["label"], args.codec, args.op, args.batch), "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
                    "batch_per_gpu": per_rank_q, "k": 10, "parallelism": "query-batch sharding x%d (%s), index replicated" % (world, args.scaling)},
     }
+    info = idx.info()
+    out["config"]["device_bytes"] = int(idx.device_bytes())
+    if info["transcoded_from"] >= 0:  # block_mixed / opt / ef / single / uniform: decoded once at upload, queried as block_optpfor + side tables
+        out["config"]["upload"] = ("%s image transcoded to block_optpfor at upload (DS2I_MIXED_NATIVE=1 / DS2I_PEF_NATIVE=1 "
+                                   "query the image as it is)" % args.codec)
 
     # ---------------------------------------------------------------- oracle legs (rank 0 only; the only place this file touches oracle/)
     cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3 if n <= 16 else 4
@@ -470,7 +475,8 @@ def main():
     traffic = None
     traffic_src = None
     traffic_step = None
-    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r04_traffic_%s_%s.json" % (wl, args.op))
+    tjson = {}
+    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r05_traffic_%s_%s.json" % (wl, args.op))
     if os.path.exists(tj) and args.codec == "block_optpfor":
         tjson = json.load(open(tj))
         name = dom_k["kernel"] if dom_k else kernel_name(dom)
@@ -488,6 +494,9 @@ def main():
         ms_alone, n_timed, nq_dom, kname_dom = res_ms[dom] / args.steps, cls_ms[dom][1], cls_stats[dom][1], kernel_name(dom)
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_per_step": traffic_step, "traffic_source": traffic_src,
+                       #  what of that traffic reached HBM: the L2's fabric-side counters cannot tell an Infinity-Cache hit from
+                       # a DRAM access (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ for these kernels), so the same figure is an UPPER bound
+                       "hbm_bytes_per_step": traffic_step, "hbm_bytes_source": (tjson.get("l2_fabric_note") if traffic_step else None),
                        "kernel": kname_dom, "kernel_ms": dom_ms, "kernel_ms_alone": ms_alone,
                        "kernel_ms_all_launches": ms_all, "launches_all": n_all,
                        "launches_timed": n_timed, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,

@@ -357,8 +357,8 @@ __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU
 std::atomic<bool> g_ds2i_options_frozen{false};
 static std::atomic<bool> g_ds2i_upload_options_frozen{false};
 namespace {
-const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE",
-                                    "DS2I_STREAM_SETS", "DS2I_FLAT_PRIORITY"};
+const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE",
+                                    "DS2I_STREAM_SETS", "DS2I_CLASS_PRIORITY"};
 const char* const kBatchKnobs[] = {"DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
                                    "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
                                    "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
@@ -398,9 +398,15 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
 // changes is that a query never waits for the lane-0 interpolative walk (12 % of the fixed policy's blocks at 11 x the cost
 // of an OptPFor block) or the descriptor-driven VarInt-G8IU gather. DS2I_MIXED_NATIVE=1 keeps the image as it is and runs the
 // mixed-codec kernels (k_ranked_stream_mixed, the CODEC_MIXED instantiations).
-static int index_open_transcoded(int device, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, ds2i_hip_index** out) {
+// The freq_index layouts (opt / ef / single / uniform) take the same way: partitioned Elias-Fano is the space-optimal form for
+// disk and for a CPU's caches; on a device with 288 GB behind 8 TB/s the form to query is the one whose block is one wave's
+// worth of work with its skip entry, block weight, range-table bytes and side slot beside it. Their chunk directory is built
+// (it is what the decode pass walks), every list decoded by the partitioned-sequence kernels (partitioned_sequence.hpp:198-326,
+// compact_elias_fano.hpp:184-214, compact_ranked_bitvector.hpp, positive / strict sequences), and the postings re-encoded as
+// above. DS2I_PEF_NATIVE=1 keeps the bit vectors and runs the CODEC_PEF kernels over the chunk directory.
+static int index_open_transcoded(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, ds2i_hip_index** out) {
     ds2i_hip_index* raw = nullptr;
-    int rc = index_open_impl(device, DS2I_BLOCK_MIXED, index_image, index_bytes, nullptr, 0, true, &raw);
+    int rc = index_open_impl(device, kind, index_image, index_bytes, nullptr, 0, true, &raw);
     if (rc) return rc;
     std::unique_ptr<ds2i_hip_index, void (*)(ds2i_hip_index*)> guard(raw, free_index);
     const uint64_t V = raw->size;
@@ -415,7 +421,7 @@ static int index_open_transcoded(int device, const void* index_image, size_t ind
         docs.resize(offs[V]);
         freqs.resize(offs[V]);
     } catch (std::bad_alloc const&) {
-        return ds2i_set_error(DS2I_ENOMEM, "out of host memory transcoding a block_mixed index (DS2I_MIXED_NATIVE=1 uploads it as it is)");
+        return ds2i_set_error(DS2I_ENOMEM, "out of host memory transcoding the index to block_optpfor (DS2I_MIXED_NATIVE=1 / DS2I_PEF_NATIVE=1 upload it as it is)");
     }
     {
         DevTemps tmp;
@@ -425,8 +431,11 @@ static int index_open_transcoded(int device, const void* index_image, size_t ind
         for (uint64_t t = 0; t < V; ++t) {
             DecodeArgs a{};
             a.arena = raw->d_arena;
+            a.bits0 = raw->d_bits0;
+            a.bits1 = raw->d_bits1;
+            a.skip = raw->d_skip;
             a.term = ds2i_make_qterm(raw, (uint32_t)t);
-            a.codec = DS2I_BLOCK_MIXED;
+            a.codec = kind >= DS2I_OPT ? (int)DS2I_OPT : kind; // (every freq_index layout decodes through the chunk directory)
             a.num_docs = (uint32_t)raw->num_docs;
             a.out_docs = d_docs;
             a.out_freqs = d_freqs;
@@ -445,17 +454,19 @@ static int index_open_transcoded(int device, const void* index_image, size_t ind
     std::vector<uint32_t>().swap(freqs);
     rc = index_open_impl(device, DS2I_BLOCK_OPTPFOR, ds2i_blob_data(img), ds2i_blob_size(img), wand_image, wand_bytes, false, out);
     ds2i_blob_free(img);
-    if (rc == DS2I_OK) (*out)->kind_on_disk = DS2I_BLOCK_MIXED;
+    if (rc == DS2I_OK) (*out)->kind_on_disk = kind;
     return rc;
 }
 
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
     g_ds2i_upload_options_frozen.store(true);
-    if (kind == DS2I_BLOCK_MIXED && out && index_image && !std::getenv("DS2I_MIXED_NATIVE")) {
+    const bool transcode = (kind == DS2I_BLOCK_MIXED && !std::getenv("DS2I_MIXED_NATIVE")) ||
+                           (kind >= DS2I_OPT && kind <= DS2I_UNIFORM && !std::getenv("DS2I_PEF_NATIVE"));
+    if (transcode && out && index_image) {
         const int ndev = ds2i_hip_device_count();
         if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
-        return index_open_transcoded(device, index_image, index_bytes, wand_image, wand_bytes, out);
+        return index_open_transcoded(device, kind, index_image, index_bytes, wand_image, wand_bytes, out);
     }
     return index_open_impl(device, kind, index_image, index_bytes, wand_image, wand_bytes, false, out);
 }
@@ -641,15 +652,20 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
     }
     HIP_OK(hipMalloc((void**)&x->d_ticket, 64 * sizeof(unsigned int)));
     {
-        // The many-list classes are few, LDS-hungry workgroups with long dependent chains; the <=2-list class is a
-        // flood of small ones. With equal priorities the flood starves the chains (class 2 alone: 4 ms, next to class
-        // 0: 21 ms), so the chain classes get the higher queue priority and finish inside the shadow of the flood.
+        // One stream per class, all of ONE priority. Rounds 2-4 gave the many-list classes (few, LDS-hungry workgroups with long
+        // dependent chains) a higher queue priority than the <=2-list flood, which starved them at the time (class 2 alone:
+        // 4 ms, next to class 0: 21 ms). With the stream kernels the <=2-list class IS the critical path of a step, and what the
+        // priorities do turned out to depend on the history of the process: the first index a process uploads ran at 990 k
+        // queries/s either way, but an index uploaded after another one had been closed -- every transcoding upload -- got
+        // hardware queues on which the priorities bite (class 0: 3.5 -> 4.4 ms per launch, the others faster, the step 18 %
+        // longer). Equal priorities: 990 k-1 000 k in every order of uploads (profiles/probes/r5_prio.sh). DS2I_CLASS_PRIORITY=1
+        // restores the old scheme.
         int lo_pri = 0, hi_pri = 0; // numerically lower = higher priority
         HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-        static const bool flat = std::getenv("DS2I_FLAT_PRIORITY") != nullptr;
+        static const bool by_class = std::getenv("DS2I_CLASS_PRIORITY") != nullptr;
         for (int c = 0; c < NCLS; ++c) {
-            int pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
-            if (flat) pri = (lo_pri + hi_pri) / 2;
+            int pri = (lo_pri + hi_pri) / 2;
+            if (by_class) pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
             HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, pri));
             // (the second set exists only when asked for: every stream is a hardware queue, and two replicas on one device --
             // or anything else that shares the GPU -- push the total past what the queues serve without time-slicing)
@@ -703,6 +719,7 @@ int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out)
     out->has_range_tables = idx->d_rmw != nullptr;
     out->has_bitmaps = idx->d_rmw != nullptr && idx->has_bitmaps;
     out->range_table_entries_per_posting = idx->d_rmw ? idx->rmw_g : 0;
+    out->transcoded_from = idx->kind_on_disk;
     return DS2I_OK;
 }
 

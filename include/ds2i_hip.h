@@ -131,6 +131,8 @@ typedef struct ds2i_hip_index_info {
                                   * masks + values, so that a decode never parses the Simple16 streams), their overflow area, and the
                                   * lists' partial last blocks in plain form; 0 = not built (DS2I_NO_XSLOTS, other index kinds, no room) */
     int has_side_tables;
+    int transcoded_from;         /* the DS2I_* kind of the image the caller handed over when the upload transcoded it to block_optpfor
+                                  * (block_mixed, opt / ef / single / uniform by default: DS2I_MIXED_NATIVE / DS2I_PEF_NATIVE), else -1 */
 } ds2i_hip_index_info;
 int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out);
 /* document_enumerator::size() of index[term] (block_posting_list.hpp:178-181) */

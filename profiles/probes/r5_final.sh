@@ -10,7 +10,7 @@ import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r=d.get("roofline",{})
-    print(sys.argv[2], round(d["value"]), "q/s", round(d["ms_per_step"],3), "ms/step", "frac", r.get("frac"), "step_frac", r.get("step_frac"), "cpu", d.get("cpu_baseline",{}).get("value"))
+    print(sys.argv[2], round(d["value"]), "q/s", round(d["ms_per_step"],3), "ms/step", "frac", r.get("frac"), "step_frac", r.get("step_frac"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
@@ -32,6 +32,13 @@ if [ $PART = ops ]; then
   for op in wand maxscore ranked_or and and_freq or or_freq; do bench gov2_$op --workload gov2 --op $op --steps 30 --warmup 3; done
   bench gov2c --workload gov2c --steps 30 --warmup 3
   bench gov2c_wand --workload gov2c --op wand --steps 30 --warmup 3
+fi
+if [ $PART = opt ]; then
+  # the freq_index layouts: default upload (transcoded to block_optpfor) and the partitioned-sequence kernels on the image as it is
+  bench gov2_opt --workload gov2 --codec opt --steps 30 --warmup 3
+  bench gov2_opt_wand --workload gov2 --codec opt --op wand --steps 30 --warmup 3 --no-cpu-baseline
+  DS2I_PEF_NATIVE=1 python bench.py --workload gov2 --codec opt --steps 30 --warmup 3 --no-cpu-baseline > $OUT/bench_gov2_opt_native.json 2> $OUT/bench_gov2_opt_native.err; line $OUT/bench_gov2_opt_native.json gov2_opt_native
+  DS2I_PEF_NATIVE=1 python bench.py --workload gov2 --codec opt --op wand --steps 30 --warmup 3 --no-cpu-baseline > $OUT/bench_gov2_opt_wand_native.json 2> $OUT/bench_gov2_opt_wand_native.err; line $OUT/bench_gov2_opt_wand_native.json gov2_opt_wand_native
 fi
 if [ $PART = scale ]; then
   bench gov2_b512 --batch 512 --depth 8 --steps 160 --warmup 80 --no-cpu-baseline

@@ -95,6 +95,33 @@ def test_decode_every_list(coll, images, codec):
         assert np.array_equal(ff, freqs), (codec, t)
 
 
+@pytest.fixture(autouse=True)
+def _freq_layouts_native(monkeypatch):
+    """opt / ef / single / uniform images are transcoded to block_optpfor at upload by default (like block_mixed). The tests
+    of this module are about the partitioned-sequence kernels themselves, so they keep the image (DS2I_PEF_NATIVE=1, read by
+    ds2i_hip_index_open); test_freq_layouts_are_transcoded_at_upload and the 25 M-doc configs[2] test drop the switch."""
+    monkeypatch.setenv("DS2I_PEF_NATIVE", "1")
+
+
+@pytest.mark.parametrize("kind", list(d.FREQ_INDEX_KINDS))
+def test_freq_layouts_are_transcoded_at_upload(coll, queries, images, kind, monkeypatch):
+    """the default upload of an opt / ef / single / uniform image: its lists are decoded by the partitioned-sequence kernels
+    once, the device holds a block_optpfor index with side tables (ds2i_hip_index_get_info says so), every list it
+    decodes is the image's list and every operator answers like the oracle reading the ORIGINAL image"""
+    monkeypatch.delenv("DS2I_PEF_NATIVE")
+    idx = d.Index(kind, images[0][kind], images[1])
+    info = idx.info()
+    assert info["transcoded_from"] == d.CODECS[kind] and info["has_side_tables"] and info["has_range_tables"]
+    for t, (docs, freqs) in enumerate(coll.lists):
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+    oidx = o.Index(kind, images[0][kind], images[1])
+    for op in ALL_OPS:
+        _check_against_oracle(idx, oidx, op, queries)
+    monkeypatch.setenv("DS2I_PEF_NATIVE", "1")
+    assert d.Index(kind, images[0][kind], images[1]).info()["transcoded_from"] == -1
+
+
 @pytest.fixture
 def mixed_native(monkeypatch):
     """block_mixed images are transcoded to block_optpfor at upload by default; DS2I_MIXED_NATIVE=1 (read by
@@ -124,6 +151,36 @@ def test_block_mixed_is_transcoded_at_upload(coll, images):
     for t, (docs, freqs) in enumerate(coll.lists):
         dd, ff = idx[t]
         assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+
+
+def test_block_optpfor_without_side_tables(coll, queries, images, monkeypatch):
+    """DS2I_NO_XSLOTS=1 (read by ds2i_hip_index_open): no exception side slots, the kernels parse the on-disk OptPFor bytes
+    (Simple16 streams, interpolative tails: block_codecs.hpp:143-214, 46-79) -- the runtime-codec instantiations and
+    k_conjunctive instead of k_ranked_stream. Every list and every operator must still equal the oracle."""
+    monkeypatch.setenv("DS2I_NO_XSLOTS", "1")
+    idx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    monkeypatch.delenv("DS2I_NO_XSLOTS")
+    info = idx.info()
+    assert not info["has_side_tables"] and info["side_table_bytes"] == 0
+    for t, (docs, freqs) in enumerate(coll.lists):
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+    oidx = o.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    for op in ALL_OPS:
+        _check_against_oracle(idx, oidx, op, queries)
+
+
+def test_decode_list_through_both_decoders(coll, images, monkeypatch):
+    """ds2i_hip_decode_list on an index WITH side slots: the slot decoder (default) and, with DS2I_DECODE_GENERAL=1, the
+    decoder of the on-disk bytes -- the same postings both ways"""
+    idx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
+    assert idx.info()["has_side_tables"]
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("DS2I_DECODE_GENERAL", "1")
+        for t, (docs, freqs) in enumerate(coll.lists):
+            dd, ff = idx[t]
+            assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), (general, t)
 
 
 def _check_against_oracle(gidx, oidx, op, queries, k=10, reference_order=False):
@@ -184,34 +241,39 @@ def _full_batch_equals_oracle(gidx, oidx, queries, k=10, union_n=1024, chunk=512
     (oracle.Index.query_batch_mt: one query_ctx per thread over the immutable index, profile_queries.cpp:21-39 style).
     ranked_and: top-k of every query; and: counts and doc-id LISTS of every query (bit-exact, compared through an
     order-sensitive 64-bit checksum per query -- the lists of a 4096-query batch at 25 M docs are gigabytes);
-    wand / maxscore: the first union_n queries."""
-    rc, rtopk, rlen, _ = gidx.query_batch("ranked_and", queries, k=k)
+    wand / maxscore: the first union_n queries. gidx: one device index or several uploads of the same image (the oracle
+    answers once)."""
+    gidxs = gidx if isinstance(gidx, (list, tuple)) else [gidx]
     oc, otk, otl, _, _ = oidx.query_batch_mt("ranked_and", queries, k=k)
-    assert np.array_equal(rlen, otl) and np.array_equal(rc, oc)
     f = np.isfinite(otk)
-    assert np.array_equal(np.isfinite(rtopk), f)
-    np.testing.assert_allclose(rtopk[f], otk[f], rtol=RTOL)
+    for g in gidxs:
+        rc, rtopk, rlen, _ = g.query_batch("ranked_and", queries, k=k)
+        assert np.array_equal(rlen, otl) and np.array_equal(rc, oc)
+        assert np.array_equal(np.isfinite(rtopk), f)
+        np.testing.assert_allclose(rtopk[f], otk[f], rtol=RTOL)
     oac, _, _, _, ohash = oidx.query_batch_mt("and", queries, match_hash=True)
-    for lo in range(0, len(queries), chunk):  # (the doc-id buffer of a batch is sized for the shortest lists' full lengths)
-        part = queries[lo:lo + chunk]
-        b = d.Batch(gidx, "and", part, want_matches=True)
-        b.run()
-        count = b.fetch()[0]
-        got = b.fetch_matches(count)
-        b.close()
-        assert np.array_equal(count, oac[lo:lo + chunk])
-        for i, m in enumerate(got):
-            m64 = m.astype(np.uint64)
-            h = (m64 * (2 * np.arange(len(m64), dtype=np.uint64) + 1)).sum(dtype=np.uint64)
-            assert h == ohash[lo + i], (lo + i, part[i])
+    for g in gidxs:
+        for lo in range(0, len(queries), chunk):  # (the doc-id buffer of a batch is sized for the shortest lists' full lengths)
+            part = queries[lo:lo + chunk]
+            b = d.Batch(g, "and", part, want_matches=True)
+            b.run()
+            count = b.fetch()[0]
+            got = b.fetch_matches(count)
+            b.close()
+            assert np.array_equal(count, oac[lo:lo + chunk])
+            for i, m in enumerate(got):
+                m64 = m.astype(np.uint64)
+                h = (m64 * (2 * np.arange(len(m64), dtype=np.uint64) + 1)).sum(dtype=np.uint64)
+                assert h == ohash[lo + i], (lo + i, part[i])
     for op in ("wand", "maxscore"):
         sub = queries[:union_n]
-        _, gt, gl, _ = gidx.query_batch(op, sub, k=k)
         _, ot, ol, _, _ = oidx.query_batch_mt(op, sub, k=k)
-        assert np.array_equal(gl, ol), op
         f = np.isfinite(ot)
-        assert np.array_equal(np.isfinite(gt), f), op
-        np.testing.assert_allclose(gt[f], ot[f], rtol=RTOL, err_msg=op)
+        for g in gidxs:
+            _, gt, gl, _ = g.query_batch(op, sub, k=k)
+            assert np.array_equal(gl, ol), op
+            assert np.array_equal(np.isfinite(gt), f), op
+            np.testing.assert_allclose(gt[f], ot[f], rtol=RTOL, err_msg=op)
 
 
 def _and_match_lists_equal_oracle(gidx, oidx, sample):
@@ -1114,7 +1176,12 @@ def test_gov2_scale_opt_index_configs2(built_lib):
     oidx = o.Index("opt", img, wand)
     rtopk, rlen = _scale_properties(gidx, oidx, queries)
     _union_topk_equals_oracle(gidx, oidx, queries, nsample=32)
-    _full_batch_equals_oracle(gidx, oidx, queries, union_n=512)  # every query of the batch, not a sample
+    del os.environ["DS2I_PEF_NATIVE"]  # (the module's fixture restores it) -- the default upload: transcoded to block_optpfor
+    tidx = d.Index("opt", img, wand)
+    assert tidx.info()["transcoded_from"] == d.CODECS["opt"] and gidx.info()["transcoded_from"] == -1
+    # every query of the batch, not a sample -- the partitioned-sequence kernels on the image as it is AND the default upload
+    _full_batch_equals_oracle([gidx, tidx], oidx, queries, union_n=512)
+    tidx.close()
     # wand == maxscore (test_ranked_queries.cpp:39-57) and they dominate ranked_and, on a slice of the batch
     sub = queries[:512]
     _, wt, wl, _ = gidx.query_batch("wand", sub, k=10)
