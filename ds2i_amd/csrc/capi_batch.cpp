@@ -7,6 +7,7 @@
 // There is NO CPU fallback: every query result comes from the HIP kernels or the call fails.
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -65,6 +66,7 @@ struct PlanPool {
     const std::function<void(unsigned)>* fn = nullptr;
     unsigned next = 0, total = 0, done = 0;
     uint64_t epoch = 0;
+    std::exception_ptr failed; // the first exception a piece threw (any thread); rethrown by run() once every piece is done
     void worker() {
         uint64_t seen = 0;
         for (;;) {
@@ -74,8 +76,10 @@ struct PlanPool {
                 const unsigned i = next++;
                 const std::function<void(unsigned)>* f = fn;
                 lk.unlock();
-                (*f)(i);
+                std::exception_ptr ex;
+                try { (*f)(i); } catch (...) { ex = std::current_exception(); } // (a throw on a detached thread would be std::terminate)
                 lk.lock();
+                if (ex && !failed) failed = ex;
                 if (++done == total) cv_done.notify_all();
             }
             seen = epoch;
@@ -90,21 +94,29 @@ struct PlanPool {
             next = 1; // (index 0 is the caller's)
             total = n;
             done = 1;
+            failed = nullptr;
             ++epoch;
         }
         cv_work.notify_all();
-        f(0);
+        std::exception_ptr ex;
+        try { f(0); } catch (...) { ex = std::current_exception(); }
+        // whatever happened to piece 0, the workers hold a pointer to f and to the caller's chunks: they are waited for
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return done == total; });
         total = 0;
+        fn = nullptr;
+        if (!ex) ex = failed;
+        failed = nullptr;
+        lk.unlock();
+        if (ex) std::rethrow_exception(ex);
     }
 };
 std::mutex g_plan_pool_user; // one batch at a time uses the pool (several pipelines / replicas may plan concurrently)
 void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
     static PlanPool* pool = new PlanPool; // (leaked on purpose: its detached threads may outlive static destruction)
     if (n > 1 && g_plan_pool_user.try_lock()) {
+        std::lock_guard<std::mutex> user(g_plan_pool_user, std::adopt_lock); // (released when run() throws, too)
         pool->run(n, f);
-        g_plan_pool_user.unlock();
     } else {
         for (unsigned i = 0; i < n; ++i) f(i); // the pool is busy with another batch: plan this one on the caller's thread
     }
@@ -206,8 +218,21 @@ void order_by_cost(const std::vector<float>& cost, const std::vector<uint32_t>& 
 }
 
 // ---------------------------------------------------------------- plan: host half of the query operators
+static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq, int want_matches);
+// (the plan's vectors grow with the batch: an allocation failure -- on the caller's thread or on a pool thread, see PlanPool -- is
+// an error code at the C boundary, not an exception crossing it)
 int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
                int want_matches) {
+    try {
+        return plan_batch_impl(b, op, k, terms, query_offsets, nq, want_matches);
+    } catch (std::bad_alloc const&) {
+        return ds2i_set_error(DS2I_ENOMEM, "out of host memory planning the batch");
+    } catch (std::exception const& e) {
+        return ds2i_set_error(DS2I_EINVAL, e.what());
+    }
+}
+static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
+                           int want_matches) {
     ds2i_hip_index* idx = b->idx;
     g_ds2i_options_frozen.store(true); // (ds2i_hip_set_option: the knobs below are read once)
     const auto plan_t0 = std::chrono::steady_clock::now();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box): bash profiles/probes/r5_defer.sh -- stage C deferred (survivor queue) against stage C per block: parity subset, then the default bench per flush size
+# Usage (GPU box): bash profiles/probes/r5_defer.sh -- stage C deferred (survivor queue; apply profiles/probes/r5_defer_stage_c.patch and build the variants defer16 .. defer64 with DS2I_BUILD_VARIANT / DS2I_EXTRA_CFLAGS=-DDS2I_RS_DEFER=N first) against stage C per block: parity subset, then the default bench per flush size
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r5_defer
 DS2I_LIB_VARIANT=defer32 timeout 900 python -m pytest tests/test_gpu.py -x -q -m gpu -k "test_query_ops_match_oracle or fuzz_bit_identical or pruning_prunes or test_full_size_c2_properties or correlated" > gpurun_out/r5_defer/pytest.txt 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (GPU box, repo root): bash profiles/probes/r5_final.sh <part>   (round 5 closing measurements; part = prof | ops | scale | cw09 | probes)
+# Usage (GPU box, repo root): bash profiles/probes/r5_final.sh <part>   (round 5 closing measurements; part = prof | pmc | ops | opt | scale | cw09 | probes)
 set -u
 PART=${1:-prof}
 OUT=gpurun_out/r5_final
@@ -21,14 +21,14 @@ if [ $PART = prof ]; then
   timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 60 --warmup 5 > $OUT/prof_bench.json 2> $OUT/prof_bench.err
   KS=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); if [ -n "$KS" ]; then cp "$KS" $OUT/kernel_stats.csv; fi; rm -rf $OUT/kt
   head -12 $OUT/kernel_stats.csv; line $OUT/prof_bench.json traced_default
+  bench default_gov2 --steps 60 --warmup 5
+fi
+if [ $PART = pmc ]; then
   bash profiles/probes/r5_pmc.sh final ranked_and
   bash profiles/probes/r5_pmc.sh final_wand wand
-  bench default_gov2 --steps 60 --warmup 5
 fi
 if [ $PART = ops ]; then
   bench c2 --workload c2 --steps 60 --warmup 5
-  bench gov2_opt --workload gov2 --codec opt --steps 30 --warmup 3
-  bench gov2_opt_wand --workload gov2 --codec opt --op wand --steps 30 --warmup 3 --no-cpu-baseline
   for op in wand maxscore ranked_or and and_freq or or_freq; do bench gov2_$op --workload gov2 --op $op --steps 30 --warmup 3; done
   bench gov2c --workload gov2c --steps 30 --warmup 3
   bench gov2c_wand --workload gov2c --op wand --steps 30 --warmup 3
