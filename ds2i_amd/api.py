@@ -562,7 +562,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("index_bytes", C.c_uint64), ("skip_table_bytes", C.c_uint64), ("block_weight_bytes", C.c_uint64), ("range_table_bytes", C.c_uint64),
                 ("norm_len_bytes", C.c_uint64), ("total_blocks", C.c_uint64), ("total_postings", C.c_uint64), ("has_block_weights", C.c_int),
                 ("has_range_tables", C.c_int), ("has_bitmaps", C.c_int), ("has_membership_hints", C.c_int), ("range_table_entries_per_posting", C.c_int),
-                ("side_table_bytes", C.c_uint64), ("has_side_tables", C.c_int), ("transcoded_from", C.c_int)]
+                ("side_table_bytes", C.c_uint64), ("has_side_tables", C.c_int), ("transcoded_from", C.c_int), ("table_budget_bytes", C.c_uint64)]
 
 
 class Index:

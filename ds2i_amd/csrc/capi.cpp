@@ -160,9 +160,8 @@ int build_block_max_weights(ds2i_hip_index* x) {
     // (a 6 M-posting list of a 25 M-doc collection: one doc-id per byte), a short one coarse ranges of about the same
     // number of bytes per posting -- 1..2 G bytes per posting altogether, every table padded to 64 bytes. Measured on
     // the GOV2-scale ranked_and batch (queries/s): G = 1: 335 k, 2: 460 k, 4: 503 k, 8: 474 k.
-    static const char* gs = std::getenv("DS2I_RMW_G");
-    const double G = gs ? std::atof(gs) : 4.0;
-    if (!(G > 0) || std::getenv("DS2I_NO_RMW")) return DS2I_OK; // asked not to build them
+    const double G = x->plan_g; // (choose_table_plan: DS2I_RMW_G, default 4; DS2I_TABLE_BUDGET may have lowered it)
+    if (!(G > 0)) return DS2I_OK; // asked not to build them
     x->rmw_g = (int)G;
     // The tables are an accelerator, never a reason to fail an upload -- but running without them changes which kernel
     // family answers wand / maxscore / ranked_or and costs ranked_and and `and` most of their speed, so the decision is
@@ -210,7 +209,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
     }
     x->rmw_bytes = bytes;
     // membership hints (abi_structs.hpp, BatchArgs::rmh): a parallel buffer with the tables' offsets (only the level-1 regions are written). Optional like the tables.
-    if (!std::getenv("DS2I_NO_RMH")) { // (every index kind: the ranked / and / wand kernels of all of them consult the hints)
+    if (x->plan_hints) { // (every index kind: the ranked / and / wand kernels of all of them consult the hints)
         static std::mutex hint_alloc_mu;
         std::lock_guard<std::mutex> g(hint_alloc_mu);
         size_t free_b = 0, total_b = 0;
@@ -256,11 +255,65 @@ int build_block_max_weights(ds2i_hip_index* x) {
     return DS2I_OK;
 }
 
+// Bytes of the doc-id-range tables (levels + dense lists' bitmaps) at G entries per posting; the hints are a buffer of the same size.
+static uint64_t range_table_bytes_at(const ds2i_hip_index* x, double G) {
+    uint64_t cursor = 0;
+    const bool bitmaps = !std::getenv("DS2I_NO_BITMAPS");
+    for (uint64_t t = 0; t < x->size; ++t) {
+        uint32_t sh = 0;
+        while (sh < 31 && (double)(x->num_docs >> (sh + 1)) >= G * (double)x->list_n[t]) ++sh;
+        cursor += ds2i_dev::RmwLevels((uint32_t)x->num_docs, sh).bytes() / 64;
+        if (bitmaps && ds2i_dev::RmwLevels::has_bitmap(x->list_n[t], (uint32_t)x->num_docs)) cursor += ds2i_dev::RmwLevels::bitmap_bytes((uint32_t)x->num_docs) / 64;
+    }
+    return cursor * 64 + 64;
+}
+
+// What an upload builds beside the image. Without a budget: range tables at DS2I_RMW_G (4) entries per posting, membership
+// hints, exception side slots (block_optpfor) -- 29.9 GB resident for the 2.8 GB GOV2-scale index. DS2I_TABLE_BUDGET=<bytes>
+// (or <factor>x, e.g. "5x" = five times the image) makes the upload pick, in the order of the rates measured at GOV2 scale
+// (profiles/r05_table_budget.txt), the first configuration whose resident bytes stay under it: whole structures are dropped or
+// the tables' granularity halved -- there is no per-list choice (a list either has every structure the index has or none does).
+// A knob set explicitly (DS2I_RMW_G, DS2I_NO_RMH, DS2I_NO_XSLOTS) is not overridden. Reported by ds2i_hip_index_get_info.
+static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
+    const char* gs = std::getenv("DS2I_RMW_G");
+    x->plan_g = gs ? std::atof(gs) : 4.0;
+    if (!(x->plan_g > 0) || std::getenv("DS2I_NO_RMW")) x->plan_g = 0;
+    x->plan_hints = !std::getenv("DS2I_NO_RMH");
+    x->plan_slots = !std::getenv("DS2I_NO_XSLOTS") && x->kind == DS2I_BLOCK_OPTPFOR;
+    const char* eb = std::getenv("DS2I_TABLE_BUDGET");
+    if (!eb || !*eb) return;
+    char* end = nullptr;
+    const double v = std::strtod(eb, &end);
+    if (!(v > 0)) return;
+    x->table_budget = (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
+    // resident whatever is chosen: the image and its skip table (counted in extra_bytes by now), block weights (4 B per block), norm_lens
+    const uint64_t base = x->arena_bytes + x->extra_bytes + 4ull * x->total_blocks + (x->has_wand ? 4 * x->num_docs : 0);
+    const uint64_t slots = x->kind == DS2I_BLOCK_OPTPFOR ? 4ull * ds2i_dev::XSLOT_DW * x->total_blocks : 0;
+    struct Plan { double g; bool hints, slots; };
+    static const Plan order[] = {{4, true, true}, {4, false, true}, {2, true, true}, {2, false, true}, {1, true, true}, {1, false, true},
+                                 {2, false, false}, {1, false, false}, {0, false, false}};
+    for (const Plan& c : order) {
+        if (gs && c.g != x->plan_g) continue;
+        if (std::getenv("DS2I_NO_RMH") && c.hints) continue;
+        if ((std::getenv("DS2I_NO_XSLOTS") || !slots) && c.slots) continue;
+        const uint64_t tables = c.g > 0 ? range_table_bytes_at(x, c.g) : 0;
+        const uint64_t total = base + tables * (c.hints ? 2 : 1) + (c.slots ? slots : 0);
+        if (total <= x->table_budget || c.g == 0) {
+            x->plan_g = c.g;
+            x->plan_hints = c.hints && c.g > 0;
+            x->plan_slots = c.slots;
+            std::fprintf(stderr, "ds2i_hip: DS2I_TABLE_BUDGET %.2f GB: range tables at %g entries per posting, %s hints, %s side slots (%.2f GB resident)\n",
+                         x->table_budget / 1e9, c.g, x->plan_hints ? "with" : "no", x->plan_slots ? "with" : "no", total / 1e9);
+            return;
+        }
+    }
+}
+
 // block_optpfor: the exception side slots, their overflow area and the tail table (abi_structs.hpp, BatchArgs::xslots).
 // One more pass over the index with the general decoders (k_build_side_tables). Like the range tables they are an
 // accelerator: an upload that cannot afford them (or DS2I_NO_XSLOTS) runs the kernels that parse the Simple16 streams.
 int build_side_tables(ds2i_hip_index* x) {
-    if (std::getenv("DS2I_NO_XSLOTS") || !x->d_skip || !x->total_blocks || x->total_blocks >= (1ull << 32)) return DS2I_OK;
+    if (!x->plan_slots || !x->d_skip || !x->total_blocks || x->total_blocks >= (1ull << 32)) return DS2I_OK;
     const uint64_t V = x->size;
     x->list_tail_off.assign(V, 0);
     uint64_t tail = 0;
@@ -357,7 +410,7 @@ __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU
 std::atomic<bool> g_ds2i_options_frozen{false};
 static std::atomic<bool> g_ds2i_upload_options_frozen{false};
 namespace {
-const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE",
+const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET",
                                     "DS2I_STREAM_SETS", "DS2I_CLASS_PRIORITY"};
 const char* const kBatchKnobs[] = {"DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
                                    "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
@@ -675,6 +728,7 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));
+    choose_table_plan(x.get(), index_bytes);
     if (!bare && x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;
@@ -720,6 +774,7 @@ int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out)
     out->has_bitmaps = idx->d_rmw != nullptr && idx->has_bitmaps;
     out->range_table_entries_per_posting = idx->d_rmw ? idx->rmw_g : 0;
     out->transcoded_from = idx->kind_on_disk;
+    out->table_budget_bytes = idx->table_budget;
     return DS2I_OK;
 }
 

@@ -107,6 +107,10 @@ struct ds2i_hip_index {
     uint32_t* d_xovf = nullptr;
     uint32_t* d_tails = nullptr;
     uint64_t side_bytes = 0;
+    // what this upload builds beside the image (capi.cpp: choose_table_plan; DS2I_TABLE_BUDGET or the explicit knobs)
+    double plan_g = 4.0;            // range-table entries per posting (0 = no range tables)
+    bool plan_hints = true, plan_slots = true;
+    uint64_t table_budget = 0;      // bytes the upload was asked to stay under (0 = no budget)
     std::vector<uint64_t> list_tail_off; // postings in the partial last blocks of all preceding lists
     bool d_skip_or_pef() const { return d_skip != nullptr || kind >= DS2I_OPT; } // what the streaming kernels walk the driving list by
     bool has_bitmaps = false;       // dense lists carry an exact bitmap behind their range-table levels

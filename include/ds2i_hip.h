@@ -101,7 +101,10 @@ int ds2i_hip_set_option(const char* name, const char* value);
 const char* ds2i_hip_last_error(void);
 
 /* Copies the index (and optional wand data) to the device's HBM. The images are not referenced
- * after the call returns. Replaces succinct::mapper::map of queries.cpp:76-77,90-95. */
+ * after the call returns. Replaces succinct::mapper::map of queries.cpp:76-77,90-95.
+ * block_mixed and the freq_index layouts (opt / ef / single / uniform) are decoded once on the device and queried as
+ * block_optpfor (same postings, same answers; ds2i_hip_index_info::transcoded_from says so); DS2I_MIXED_NATIVE=1 /
+ * DS2I_PEF_NATIVE=1 in the environment (or ds2i_hip_set_option) keep the image and run its own kernels. */
 int ds2i_hip_index_open(int device, int index_kind, const void* index_image, size_t index_bytes,
                         const void* wand_image, size_t wand_bytes, ds2i_hip_index** out);
 void ds2i_hip_index_close(ds2i_hip_index* idx);
@@ -133,6 +136,9 @@ typedef struct ds2i_hip_index_info {
     int has_side_tables;
     int transcoded_from;         /* the DS2I_* kind of the image the caller handed over when the upload transcoded it to block_optpfor
                                   * (block_mixed, opt / ef / single / uniform by default: DS2I_MIXED_NATIVE / DS2I_PEF_NATIVE), else -1 */
+    uint64_t table_budget_bytes; /* DS2I_TABLE_BUDGET in effect at the upload (bytes; 0 = none): the upload built the first of
+                                  * {tables at 4 / 2 / 1 entries per posting} x {hints} x {side slots} whose resident bytes fit --
+                                  * range_table_entries_per_posting, has_membership_hints, has_side_tables say which */
 } ds2i_hip_index_info;
 int ds2i_hip_index_get_info(const ds2i_hip_index* idx, ds2i_hip_index_info* out);
 /* document_enumerator::size() of index[term] (block_posting_list.hpp:178-181) */

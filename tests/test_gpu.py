@@ -170,6 +170,33 @@ def test_block_optpfor_without_side_tables(coll, queries, images, monkeypatch):
         _check_against_oracle(idx, oidx, op, queries)
 
 
+@pytest.mark.parametrize("budget", ["half", "3x"])
+def test_table_budget(coll, queries, images, budget, monkeypatch):
+    """DS2I_TABLE_BUDGET (read by ds2i_hip_index_open): the upload drops whole structures (hints, side slots) or halves the range
+    tables' granularity until the resident bytes fit; ds2i_hip_index_get_info says what was built; every list and every
+    operator still equals the oracle on whatever kernels that leaves."""
+    img, wand = images[0]["block_optpfor"], images[1]
+    full = d.Index("block_optpfor", img, wand)
+    fb, finfo = full.device_bytes(), full.info()
+    full.close()
+    assert finfo["table_budget_bytes"] == 0 and finfo["has_membership_hints"] and finfo["has_side_tables"] and finfo["range_table_entries_per_posting"] == 4
+    want = fb // 2 if budget == "half" else 3 * len(img)
+    monkeypatch.setenv("DS2I_TABLE_BUDGET", str(want) if budget == "half" else "3x")
+    idx = d.Index("block_optpfor", img, wand)
+    monkeypatch.delenv("DS2I_TABLE_BUDGET")
+    info = idx.info()
+    assert info["table_budget_bytes"] == want
+    assert idx.device_bytes() <= want or not info["has_range_tables"]   # (nothing left to drop: the budget is below the bare index)
+    assert idx.device_bytes() < fb
+    assert (info["range_table_entries_per_posting"], info["has_membership_hints"], info["has_side_tables"]) != (4, 1, 1)
+    for t, (docs, freqs) in enumerate(coll.lists):
+        dd, ff = idx[t]
+        assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), t
+    oidx = o.Index("block_optpfor", img, wand)
+    for op in ALL_OPS:
+        _check_against_oracle(idx, oidx, op, queries)
+
+
 def test_decode_list_through_both_decoders(coll, images, monkeypatch):
     """ds2i_hip_decode_list on an index WITH side slots: the slot decoder (default) and, with DS2I_DECODE_GENERAL=1, the
     decoder of the on-disk bytes -- the same postings both ways"""
