@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--op", default="ranked_and")
     ap.add_argument("--codec", default="block_optpfor")
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=10, help="results kept per query (the metric is quoted at 10; > 64 runs the big-heap kernels, queries.hpp:152-197)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle", action="store_true", help="skip every oracle leg (A_skip profile, parity sample, cpu baseline)")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipelined timed region")
@@ -186,7 +187,7 @@ def main():
         for i in range(first, first + n):
             if len(tickets) == args.depth:
                 reap()
-            tickets.append(pipe.submit(args.op, flat[i], k=10))
+            tickets.append(pipe.submit(args.op, flat[i], k=args.k))
         while tickets:
             reap()
         return results, cls_ms
@@ -213,7 +214,7 @@ def main():
                    "n": int(len(steady))}
 
     # ---- untimed extras: kernel-resident rate (one prepared batch re-run, round-1's figure) and the instrumented pass
-    batch = d.Batch(idx, args.op, my_queries[args.warmup], k=10)
+    batch = d.Batch(idx, args.op, my_queries[args.warmup], k=args.k)
     batch.set_instrumented(False)
     batch.run()
     first_res_ms = [batch.class_stats(c)[0].kernel_ms for c in range(NCLS)]
@@ -283,7 +284,7 @@ def main():
         "kernel_resident_qps": per_rank_q * world / resident_s,  # one prepared batch re-run (rank 0's rate x ranks)
         "end_to_end_over_resident": qps / (per_rank_q * world / resident_s),
         "config": {"workload": "%s, %s, %s, batch=%d" % (W["label"], args.codec, args.op, args.batch), "num_docs": W["num_docs"], "postings": int(postings), "index_bytes": len(img),
-                   "batch_per_gpu": per_rank_q, "k": 10, "parallelism": "query-batch sharding x%d (%s), index replicated" % (world, args.scaling)},
+                   "batch_per_gpu": per_rank_q, "k": args.k, "parallelism": "query-batch sharding x%d (%s), index replicated" % (world, args.scaling)},
     }
     info = idx.info()
     out["config"]["device_bytes"] = int(idx.device_bytes())
@@ -308,7 +309,7 @@ def main():
         # (1) algorithmic bytes: the instrumented oracle (Profile=true equivalent) over the first timed batch, per class
         cls_q = [[q for q, n in zip(queries, nterms) if cls_of(n) == c] for c in range(NCLS)]
         t0 = time.time()
-        prof = [oidx.query_batch(args.op, cq, k=10, profile=True)[4] if cq else None for cq in cls_q]
+        prof = [oidx.query_batch(args.op, cq, k=args.k, profile=True)[4] if cq else None for cq in cls_q]
         log("oracle profile pass (reference traversal A_skip): %.1fs" % (time.time() - t0))
         a_skip_q = [prof[c]["algorithmic_bytes"] / len(cls_q[c]) if prof[c] else None for c in range(NCLS)]
         out["a_skip_bytes_per_step"] = sum(pr["algorithmic_bytes"] for pr in prof if pr)
@@ -325,24 +326,24 @@ def main():
                 if len(gs) == 1:
                     a_skip_g[(c, g["lists"], g["pipelined_stream"])] = (prof[c]["algorithmic_bytes"] if prof[c] else None, len(cls_q[c]))
                 else:
-                    a_skip_g[(c, g["lists"], g["pipelined_stream"])] = (oidx.query_batch(args.op, gq, k=10, profile=True)[4]["algorithmic_bytes"] if gq else 0, len(gq))
+                    a_skip_g[(c, g["lists"], g["pipelined_stream"])] = (oidx.query_batch(args.op, gq, k=args.k, profile=True)[4]["algorithmic_bytes"] if gq else 0, len(gq))
         # (2) parity spot check in the same run (count + top-k within 1e-5) on the sample the CPU baseline is timed on
         probe = queries[:64]
         t0 = time.time()
-        oidx.query_batch(args.op, probe, k=10)
+        oidx.query_batch(args.op, probe, k=args.k)
         per_q = (time.time() - t0) / len(probe)
         nsample = int(max(64, min(len(queries), 15.0 / (3 * per_q))))
         if not strong:
             nsample = min(nsample, len(count))
         sample = queries[:nsample]
-        oc, otopk, otlen, _, _ = oidx.query_batch(args.op, sample, k=10)
+        oc, otopk, otlen, _, _ = oidx.query_batch(args.op, sample, k=args.k)
         assert np.array_equal(count[:nsample], oc), "GPU/oracle count mismatch"
         if args.op in ("ranked_and", "wand", "maxscore", "ranked_or"):
             fin = np.isfinite(otopk)
             np.testing.assert_allclose(topk[:nsample][fin], otopk[fin], rtol=1e-5)
         if not args.no_cpu_baseline and world == 1:
             # (3) cpu_baseline: the oracle driven like op_perftest (queries.cpp:13-62) on ONE core
-            pt = oidx.perftest(args.op, sample, k=10, runs=2)
+            pt = oidx.perftest(args.op, sample, k=args.k, runs=2)
             cpu_model = "unknown"
             try:
                 cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -374,7 +375,7 @@ def main():
 
             def replay(sl):
                 try:
-                    oidx.perftest(args.op, sl, k=10, runs=1)
+                    oidx.perftest(args.op, sl, k=args.k, runs=1)
                 except Exception as e:  # noqa: BLE001
                     errs.append(e)
 

@@ -21,6 +21,8 @@
 #include <thread>
 #include <limits>
 #include <memory>
+#include <new>
+#include <pthread.h>
 
 #include "capi_internal.hpp"
 #include "host_index.hpp"
@@ -112,8 +114,21 @@ struct PlanPool {
     }
 };
 std::mutex g_plan_pool_user; // one batch at a time uses the pool (several pipelines / replicas may plan concurrently)
+std::atomic<PlanPool*> g_plan_pool{nullptr};
+// fork(): the child has the parent's PlanPool bookkeeping (threads.size() > 0, perhaps a batch half planned, perhaps the user
+// mutex held by a thread that does not exist there) and none of its threads -- it starts over with an empty pool and a fresh mutex
+void plan_pool_after_fork_in_child() {
+    g_plan_pool.store(new PlanPool, std::memory_order_release); // (the old one is leaked: its mutex may be held)
+    new (&g_plan_pool_user) std::mutex;
+}
 void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
-    static PlanPool* pool = new PlanPool; // (leaked on purpose: its detached threads may outlive static destruction)
+    static const bool once = [] {
+        g_plan_pool.store(new PlanPool, std::memory_order_release); // (leaked on purpose: its detached threads may outlive static destruction)
+        pthread_atfork(nullptr, nullptr, plan_pool_after_fork_in_child);
+        return true;
+    }();
+    (void)once;
+    PlanPool* const pool = g_plan_pool.load(std::memory_order_acquire);
     if (n > 1 && g_plan_pool_user.try_lock()) {
         std::lock_guard<std::mutex> user(g_plan_pool_user, std::adopt_lock); // (released when run() throws, too)
         pool->run(n, f);
