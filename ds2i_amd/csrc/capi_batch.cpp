@@ -138,6 +138,15 @@ void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
 }
 } // namespace
 
+// k_ranked_stream is compiled for exactly 2..8 lists; the planner hands it the 2..4-term queries (classes 0 and 1) and, with
+// DS2I_STREAM_NT_MAX=5..8, the 5..8-term class up to that count as well (class 2; the rest of it keeps k_conjunctive<.., 8>)
+static uint32_t rs_stream_nt_max() {
+    static const char* e = std::getenv("DS2I_STREAM_NT_MAX");
+    static const uint32_t v = e ? (uint32_t)std::min(8, std::max(4, std::atoi(e))) : 4u;
+    return v;
+}
+static int rs_stream_classes() { return rs_stream_nt_max() > 4 ? 3 : 2; } // classes that get unit records (BatchArgs::urec)
+
 struct ds2i_hip_batch {
     ds2i_hip_index* idx = nullptr;
     int op = 0;
@@ -174,7 +183,7 @@ struct ds2i_hip_batch {
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
     size_t o_vinfo = 0;
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[2] = {}, o_qterm_q = 0, o_sterms = 0,
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[3] = {}, o_qterm_q = 0, o_sterms = 0,
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -710,8 +719,10 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // ranked_and on block_optpfor with every upload-time table: the 2-, 3- and 4-term queries run the pipelined stream
         // kernel compiled for exactly their list count (ranked_stream.hip), one launch group per count, back to back on the
         // class stream; one-term queries and everything else keep the class kernel
+        // (DS2I_STREAM_NT_MAX = 5..8: the 5..8-term class takes the stream kernel too -- block_optpfor only, off by default: see DESIGN 7c)
         static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
-        const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= 1 && !no_rs && !tables_off &&
+        const uint32_t rs_nt = idx->kind == DS2I_BLOCK_OPTPFOR ? rs_stream_nt_max() : 4u;
+        const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs && !tables_off &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
         if (rs_ok) {
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
@@ -731,7 +742,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 const uint32_t l = nt_of(b->order[c][i]);
                 while (j < b->ncls[c] && nt_of(b->order[c][j]) == l) ++j;
                 ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 ? l : cls_lists};
-                sl.stream = l >= 2 && l <= 4;
+                sl.stream = l >= 2 && l <= rs_nt;
                 b->sub[c].push_back(sl);
                 i = j;
             }
@@ -790,7 +801,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (uint32_t i = 0; i < b->nsplit; ++i) b->hist_slot[b->split_queries[i]] = i;
     b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
-    for (int c = 0; c < 2; ++c) b->o_urec[c] = place(b->order[c].size() * sizeof(ds2i_dev::UnitRec)); // (classes of k_ranked_stream)
+    for (int c = 0; c < 3; ++c) b->o_urec[c] = place(c < rs_stream_classes() ? b->order[c].size() * sizeof(ds2i_dev::UnitRec) : 0); // (classes of k_ranked_stream)
     b->o_qterm_q = place(b->freq_stream ? qterms.size() * 4 : 0);
     b->o_sterms = place(b->sterms.size() * sizeof(ds2i_dev::StreamTerm));
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
@@ -897,7 +908,7 @@ int upload_batch(ds2i_hip_batch* b) {
         for (uint32_t q = 0; q < b->nq; ++q)
             for (uint32_t i = b->qoff[q]; i < b->qoff[q + 1]; ++i) qq[i] = q;
     }
-    for (int c = 0; c < 2 && !b->union_stream; ++c) { // one record per ticket: what k_ranked_stream reads where a unit starts (conjunctive batches)
+    for (int c = 0; c < rs_stream_classes() && !b->union_stream; ++c) { // one record per ticket: what k_ranked_stream reads where a unit starts (conjunctive batches)
         ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
         for (size_t i = 0; i < b->order[c].size(); ++i) {
             const uint32_t uid = b->order[c][i];
@@ -1046,7 +1057,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
-        a.urec = c < 2 ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
+        a.urec = c < rs_stream_classes() ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
         a.nslice = b->ncls[c];
         a.dyn_lists = 0;
         a.num_docs = (uint32_t)idx->num_docs;

@@ -46,7 +46,9 @@ namespace {
 #ifndef DS2I_RS_OCC4
 #define DS2I_RS_OCC4 6 // (round 5, on the leaner kernel: 5 -> 6 waves per SIMD for 3 / 4 lists +3.5 % end to end; 6 -> 7 / 8 for 2 lists: nothing)
 #endif
-#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : DS2I_RS_OCC4)
+// 5..8 lists (DS2I_STREAM_NT_MAX > 4): what fits -- one more decoded block (1 KB of LDS) and nine more parked scalars per list:
+// 7 936 .. 11 008 bytes of LDS per wave
+#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 7 ? 4 : 3)
 
 template <int NT>
 struct LdsRS {
@@ -263,7 +265,8 @@ DS2I_DEV float rs_dtw_bound(uint32_t freq, float norm_len) {
 #endif
 template <int NT, bool STATS>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
-    static_assert(NT >= 2 && NT <= 4, "exact list counts 2..4");
+    static_assert(NT >= 2 && NT <= 8, "exact list counts 2..8");
+    static_assert((NT - 2) * 9 + 8 < 64, "the per-list constants of lists 1.. are parked in the lanes of one VGPR");
     __shared__ LdsRS<NT> L;
     const uint32_t lane = lane_id();
     typename std::conditional<STATS, uint32_t, NullCounter>::type s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
@@ -466,8 +469,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // (a block's freqs are needed once more only if stage C scores it: they wait in the block's staging buffer, whose bytes
         // are dead once decoded, instead of in four registers)
         float boA0 = 0.f, boA1 = 0.f, boB0 = 0.f, boB1 = 0.f;                                  // freq-only bound of the list-0 term score
-        // range-table weight bytes of a lane's two candidates, packed: byte j - 1 = list j (v_cvt_f32_ubyteN unpacks for free)
-        auto gbyte = [](uint32_t g, int j) __attribute__((always_inline)) -> uint32_t { return (g >> (8 * (j - 1))) & 255u; };
+        // range-table weight bytes of a lane's two candidates, packed: byte j - 1 = list j (v_cvt_f32_ubyteN unpacks for free);
+        // one dword holds lists 1..4, six and more lists take a pair
+        using GP = typename std::conditional<(NT > 5), unsigned long long, uint32_t>::type;
+        auto gbyte = [](GP g, int j) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(g >> (8 * (j - 1))) & 255u; };
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]), xs_base = rs_lds_offset(&L.xs[0][0]);
         const uint32_t fw_base = rs_lds_offset(&L.fw[0]);
@@ -527,7 +532,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 if (haveN) { if (shared_floor) rs_wait_vm<PF_LOADS + 1>(); else rs_wait_vm<PF_LOADS>(); } else rs_wait_vm<0>();
                 PT(PH_TOPK);
                 const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane]; // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists)
-                uint32_t gP0 = x0, gP1 = x1;
+                GP gP0 = x0, gP1 = x1;
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
                 bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (x0 != 0u);
                 bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (x1 != 0u);
@@ -558,8 +563,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     if (ballot(ok0) | ballot(ok1)) { // every list's weight byte for what is left
                         auto wload = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            gP0 |= (ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u) << (8 * (j - 1));
-                            gP1 |= (ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u) << (8 * (j - 1));
+                            gP0 |= (GP)(ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u) << (8 * (j - 1));
+                            gP1 |= (GP)(ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u) << (8 * (j - 1));
                             LC(PH_FREQS, lines_of(rt[j] + (dB0 >> rsh[j]), ok0, 1u) + lines_of(rt[j] + (dB1 >> rsh[j]), ok1, 1u));
                         };
                         rs_for<1, NT>(wload);
@@ -574,8 +579,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     if (ballot(ok0) | ballot(ok1)) {
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            gP0 |= (uint32_t)rt[j][(ok0 ? dB0 : 0u) >> rsh[j]] << (8 * (j - 1));
-                            gP1 |= (uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]] << (8 * (j - 1));
+                            gP0 |= (GP)(uint32_t)rt[j][(ok0 ? dB0 : 0u) >> rsh[j]] << (8 * (j - 1));
+                            gP1 |= (GP)(uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]] << (8 * (j - 1));
                         };
                         rs_for<2, NT>(load_one);
                         auto test_one = [&](auto jc) __attribute__((always_inline)) {
@@ -588,7 +593,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 }
                 // what the lists after list `after` can add to this lane's two candidates, from their own bytes (summed from the
                 // last list down, so that the value for `after` is a prefix of the same chain whatever `after` is)
-                auto rest_of = [&](uint32_t g, int after) __attribute__((always_inline)) -> float {
+                auto rest_of = [&](GP g, int after) __attribute__((always_inline)) -> float {
                     float r = 0.f;
                     auto add_one = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
@@ -849,7 +854,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 } // namespace
 
 extern "C" {
-// nt = exact number of distinct terms of every query of the launch (2..4); the caller has checked that the index is
+// nt = exact number of distinct terms of every query of the launch (2..4 by default, up to 8 with DS2I_STREAM_NT_MAX); the caller has checked that the index is
 // block_optpfor with skip table, block weights, range tables and side slots, and that k <= 64
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
@@ -859,6 +864,11 @@ hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hi
     case 2: if (st) hipLaunchKernelGGL((k_ranked_stream<2, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<2, false>), g, b, 0, s, a); break;
     case 3: if (st) hipLaunchKernelGGL((k_ranked_stream<3, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<3, false>), g, b, 0, s, a); break;
     case 4: if (st) hipLaunchKernelGGL((k_ranked_stream<4, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<4, false>), g, b, 0, s, a); break;
+    // 5..8: only with DS2I_STREAM_NT_MAX > 4 (capi_batch.cpp; the default keeps k_conjunctive<.., 8> for that class)
+    case 5: if (st) hipLaunchKernelGGL((k_ranked_stream<5, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<5, false>), g, b, 0, s, a); break;
+    case 6: if (st) hipLaunchKernelGGL((k_ranked_stream<6, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<6, false>), g, b, 0, s, a); break;
+    case 7: if (st) hipLaunchKernelGGL((k_ranked_stream<7, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<7, false>), g, b, 0, s, a); break;
+    case 8: if (st) hipLaunchKernelGGL((k_ranked_stream<8, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<8, false>), g, b, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""k_ranked_stream<5..8> (DS2I_STREAM_NT_MAX=8: the 5..8-term class of a ranked_and batch on block_optpfor takes the pipelined stream
+kernel instead of k_conjunctive<true, true, 8>) against the oracle, bit for bit: random collections, queries of 2..8 distinct terms
+(dense lists among them: non-empty intersections of many lists), k = 1 / 10 / 64, one-shot and pipelined, whole and split queries.
+The knob is read once per process, so this runs as its own process: `DS2I_STREAM_NT_MAX=8 python profiles/probes/rs_nt8_probe.py [seeds]`
+(tests/test_gpu.py::test_ranked_stream_5_to_8_lists_behind_its_knob does that). The oracle is the checker here, nothing else."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import ds2i_amd as d  # noqa: E402
+import oracle as o  # noqa: E402
+
+
+def one(seed):
+    rng = np.random.default_rng(7000 + seed)
+    nd = int(rng.integers(20000, 400000))
+    nt = int(rng.integers(30, 120))
+    p = d.SynthParams(seed=0x5EED0000 + seed, num_docs=nd, num_terms=nt, zipf_exp=float(rng.uniform(0.3, 0.9)),
+                      top_df_frac=float(rng.uniform(0.3, 0.9)), min_len=int(rng.integers(1, 300)), clustered_every=int(rng.integers(0, 5)))
+    lists = [d.synth_list(p, t) for t in range(nt)]
+    sizes = d.synth_doc_sizes(p)
+    if seed % 2 == 0:
+        sizes = np.where(rng.random(nd) < 0.1, 1, sizes).astype(np.uint32)
+    wand = d.build_wand(sizes, lists)
+    qs = []
+    for n in range(2, 9):  # every list count: terms anywhere in the vocabulary (mostly empty intersections, early exits) ...
+        qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(40)]
+        qs += [[int(x) for x in rng.permutation(min(nt, 14))[:n]] for _ in range(60)]  # ... and among the densest lists (big intersections)
+    qs += [list(range(8)), list(range(7, -1, -1)), [0, 1, 2, 3, 4], [nt - 1, 0, 1, 2, 3, 4]]
+    img = d.build_index("block_optpfor", nd, lists)
+    gidx = d.Index("block_optpfor", img, wand)
+    oidx = o.Index("block_optpfor", img, wand)
+    pipe = d.Pipeline(gidx, depth=2)
+    streamed = set()
+    for k in (1, 10, 64):
+        oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", qs, k=k)
+        b = d.Batch(gidx, "ranked_and", qs, k=k)
+        b.run()
+        gc, gtopk, gtlen, _ = b.fetch()
+        for c in range(3):
+            streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
+        b.close()
+        assert np.array_equal(gc, oc) and np.array_equal(gtlen, otlen), (seed, k, np.argwhere(gc != oc)[:3])
+        assert np.array_equal(gtopk, otopk), (seed, k, np.argwhere(gtopk != otopk)[:3])
+        t = pipe.submit("ranked_and", qs, k=k)
+        _, ptopk, _ = pipe.wait(t)
+        assert np.array_equal(ptopk, otopk), (seed, k, "pipelined")
+    pipe.close()
+    want = set(range(2, 9)) if int(os.environ.get("DS2I_STREAM_NT_MAX", "4")) >= 8 else set(range(2, 5))
+    assert streamed == want, (streamed, want)
+    nonempty = int((oc > 0).sum())
+    print("seed %d: %d docs, %d terms, %d queries (%d with results), stream kernels for %s lists: bit-identical to the oracle" %
+          (seed, nd, nt, len(qs), nonempty, sorted(streamed)))
+
+
+if __name__ == "__main__":
+    for s in ([int(x) for x in sys.argv[1:]] or [1, 2, 3]):
+        one(s)
+    print("rs_nt8_probe ok")

@@ -97,7 +97,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     # the three translation units that issue loads by hand: the stream kernels of ranked_and (block_optpfor; block_mixed) and the
     # freqs stream of or_freq. (minimum kernels, minimum hand-issued loads per kernel)
     texts = {}
-    for src, min_kernels, min_dma in (("ranked_stream.hip", 6, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 1, 3)):
+    for src, min_kernels, min_dma in (("ranked_stream.hip", 14, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 1, 3)):
         out = str(tmp_path / (src + ".s"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
                                "-o", out, os.path.join(root, "ds2i_amd", "csrc", src)], stderr=subprocess.DEVNULL)
@@ -126,7 +126,8 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     for blk in re.split(r"\n  - \.agpr_count:", text)[1:]:
         nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
         meta[nm] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "private_segment_fixed_size")}
-    budget = {2: (80, 0, 0, 64), 3: (80, 8, 32, 130), 4: (80, 16, 64, 220)}
+    # (5..8 lists -- DS2I_STREAM_NT_MAX, off by default -- at 4 / 4 / 4 / 3 waves per SIMD: nothing in scratch either)
+    budget = {2: (80, 0, 0, 64), 3: (80, 8, 32, 130), 4: (80, 16, 64, 220), 5: (128, 0, 0, 300), 6: (128, 0, 0, 330), 7: (128, 0, 0, 460), 8: (168, 0, 0, 460)}
     seen = 0
     for nm, m in meta.items():
         mm = re.search(r"k_ranked_streamILi(\d)ELb0EE", nm)
@@ -135,7 +136,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
         seen += 1
         vg, vs, ps, ss = budget[int(mm.group(1))]
         assert m["vgpr_count"] <= vg and m["vgpr_spill_count"] <= vs and m["private_segment_fixed_size"] <= ps and m["sgpr_spill_count"] <= ss, (nm, m)
-    assert seen == 3
+    assert seen == 7
 
 
 def test_documented_knobs_exist_in_the_source():

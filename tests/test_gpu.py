@@ -1170,6 +1170,23 @@ def test_alternative_paths_give_the_same_results(built_lib, knob):
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8"])
+def test_ranked_stream_5_to_8_lists_behind_its_knob(built_lib, extra):
+    """DS2I_STREAM_NT_MAX=8 (off by default): the 5..8-term class of a ranked_and batch on block_optpfor runs
+    k_ranked_stream<5..8> instead of k_conjunctive<true, true, 8> (queries.hpp:322-401 for any number of terms). Same
+    results, bit for bit, whole queries and -- with units capped at 8 blocks -- queries split into many parts that share
+    their floor; the probe also asserts that the stream kernel did run for every list count 2..8 (launch groups)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DS2I_STREAM_NT_MAX="8")
+    if extra:
+        k, v = extra.split("=")
+        env[k] = v
+    r = subprocess.run([sys.executable, os.path.join(root, "profiles", "probes", "rs_nt8_probe.py"), "1", "2", "3"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "rs_nt8_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_bench_two_ranks_on_one_device(built_lib):
     """The N>1 path of bench.py on a single-GPU box: two ranks (gloo rendezvous, both on cuda:0), each with a full index
     replica -- weak (every rank its own batches) and strong (one stream of batches cut with query_slice, results
