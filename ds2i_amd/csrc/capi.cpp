@@ -288,7 +288,18 @@ static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
     x->table_budget = (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
     // resident whatever is chosen: the image and its skip table (counted in extra_bytes by now), block weights (4 B per block), norm_lens
     const uint64_t base = x->arena_bytes + x->extra_bytes + 4ull * x->total_blocks + (x->has_wand ? 4 * x->num_docs : 0);
-    const uint64_t slots = x->kind == DS2I_BLOCK_OPTPFOR ? 4ull * ds2i_dev::XSLOT_DW * x->total_blocks : 0;
+    // side tables = a slot per block + the lists' partial last blocks in plain form + the overflow area at its first-attempt size
+    // (build_side_tables: the same arithmetic; the 256 KB floor of the overflow area is what a small index notices)
+    uint64_t slots = 0;
+    if (x->kind == DS2I_BLOCK_OPTPFOR) {
+        uint64_t tail_dw = 0;
+        for (uint64_t t = 0; t < x->size; ++t)
+            if (x->list_n[t] & 127u) tail_dw += 2 * (x->list_n[t] & 127u) + 2;
+        // (the overflow area is sized by the build pass itself -- blocks with more exceptions than a slot holds, raw and oversize
+        // parts; 38 bytes per block on the GOV2-scale index: the plan reserves 40, and never less than the pass's first attempt)
+        const uint64_t ovf = std::max<uint64_t>(4 * (x->total_blocks / 8 + 65536), 40 * x->total_blocks);
+        slots = 4ull * ds2i_dev::XSLOT_DW * x->total_blocks + (4 * tail_dw + 1024) + ovf;
+    }
     struct Plan { double g; bool hints, slots; };
     static const Plan order[] = {{4, true, true}, {4, false, true}, {2, true, true}, {2, false, true}, {1, true, true}, {1, false, true},
                                  {2, false, false}, {1, false, false}, {0, false, false}};
