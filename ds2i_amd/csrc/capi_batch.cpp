@@ -138,11 +138,14 @@ void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
 }
 } // namespace
 
-// k_ranked_stream is compiled for exactly 2..8 lists; the planner hands it the 2..4-term queries (classes 0 and 1) and, with
-// DS2I_STREAM_NT_MAX=5..8, the 5..8-term class up to that count as well (class 2; the rest of it keeps k_conjunctive<.., 8>)
+// k_ranked_stream is compiled for exactly 2..8 lists; the planner hands it the 2..4-term queries (classes 0 and 1) and the
+// 5..8-term class (class 2) up to DS2I_STREAM_NT_MAX lists (default 8; 4 = that class keeps k_conjunctive<.., 8>, 5..7 = the
+// counts above it do). Measured at GOV2 scale, interleaved on one box: 1 047-1 060 k queries/s against 985-992 k with 4
+// (profiles/r05_final/stream_nt_max_ab_run2.txt) -- the class's own span gets longer (four launch groups back to back:
+// 3.65 against 3.38 ms), the step shorter: its waves issue a fraction of the instructions and leave the CUs to the other classes.
 static uint32_t rs_stream_nt_max() {
     static const char* e = std::getenv("DS2I_STREAM_NT_MAX");
-    static const uint32_t v = e ? (uint32_t)std::min(8, std::max(4, std::atoi(e))) : 4u;
+    static const uint32_t v = e ? (uint32_t)std::min(8, std::max(4, std::atoi(e))) : 8u;
     return v;
 }
 static int rs_stream_classes() { return rs_stream_nt_max() > 4 ? 3 : 2; } // classes that get unit records (BatchArgs::urec)
@@ -719,7 +722,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // ranked_and on block_optpfor with every upload-time table: the 2-, 3- and 4-term queries run the pipelined stream
         // kernel compiled for exactly their list count (ranked_stream.hip), one launch group per count, back to back on the
         // class stream; one-term queries and everything else keep the class kernel
-        // (DS2I_STREAM_NT_MAX = 5..8: the 5..8-term class takes the stream kernel too -- block_optpfor only, off by default: see DESIGN 7c)
+        // (the 5..8-term class takes the stream kernel too, up to DS2I_STREAM_NT_MAX lists -- block_optpfor only)
         static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
         const uint32_t rs_nt = idx->kind == DS2I_BLOCK_OPTPFOR ? rs_stream_nt_max() : 4u;
         const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs && !tables_off &&

@@ -3,7 +3,7 @@
 //
 // Replaces ranked_and_query (reference queries.hpp:322-401: candidate = next posting of the shortest list, next_geq() on
 // every other list, score = sum of bm25 term scores in list order, topk_queue::insert 157-172) for queries of exactly
-// NT = 2..4 distinct terms. Same results as k_conjunctive<true, ...> (kernels.hip), which stays the kernel of every
+// NT = 2..8 distinct terms. Same results as k_conjunctive<true, ...> (kernels.hip), which stays the kernel of every
 // other case (other codecs, no tables, 1 term, 5+ terms; block_mixed: ranked_stream_mixed.hip); what differs is how a unit
 // is executed:
 //
@@ -46,7 +46,7 @@ namespace {
 #ifndef DS2I_RS_OCC4
 #define DS2I_RS_OCC4 6 // (round 5, on the leaner kernel: 5 -> 6 waves per SIMD for 3 / 4 lists +3.5 % end to end; 6 -> 7 / 8 for 2 lists: nothing)
 #endif
-// 5..8 lists (DS2I_STREAM_NT_MAX > 4): what fits -- one more decoded block (1 KB of LDS) and nine more parked scalars per list:
+// 5..8 lists: what fits -- one more decoded block (1 KB of LDS) and nine more parked scalars per list:
 // 7 936 .. 11 008 bytes of LDS per wave
 #define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 7 ? 4 : 3)
 
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 } // namespace
 
 extern "C" {
-// nt = exact number of distinct terms of every query of the launch (2..4 by default, up to 8 with DS2I_STREAM_NT_MAX); the caller has checked that the index is
+// nt = exact number of distinct terms of every query of the launch (2..8; the planner's DS2I_STREAM_NT_MAX caps it); the caller has checked that the index is
 // block_optpfor with skip table, block weights, range tables and side slots, and that k <= 64
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
@@ -864,7 +864,7 @@ hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hi
     case 2: if (st) hipLaunchKernelGGL((k_ranked_stream<2, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<2, false>), g, b, 0, s, a); break;
     case 3: if (st) hipLaunchKernelGGL((k_ranked_stream<3, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<3, false>), g, b, 0, s, a); break;
     case 4: if (st) hipLaunchKernelGGL((k_ranked_stream<4, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<4, false>), g, b, 0, s, a); break;
-    // 5..8: only with DS2I_STREAM_NT_MAX > 4 (capi_batch.cpp; the default keeps k_conjunctive<.., 8> for that class)
+    // 5..8: the 5..8-term class (capi_batch.cpp: up to DS2I_STREAM_NT_MAX lists, default 8)
     case 5: if (st) hipLaunchKernelGGL((k_ranked_stream<5, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<5, false>), g, b, 0, s, a); break;
     case 6: if (st) hipLaunchKernelGGL((k_ranked_stream<6, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<6, false>), g, b, 0, s, a); break;
     case 7: if (st) hipLaunchKernelGGL((k_ranked_stream<7, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<7, false>), g, b, 0, s, a); break;

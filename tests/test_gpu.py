@@ -1150,7 +1150,7 @@ def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
                                   "DS2I_NO_UNION_STREAM=1", "DS2I_UNIT_FACTOR=64", "DS2I_NO_TOPK_STREAM=1", "DS2I_UT_BLOCKS=1",
                                   "DS2I_SEED_STREAM=1", "DS2I_UT_FIRST=0", "DS2I_UT_FIRST=3",
                                   "DS2I_NO_RANKED_STREAM=1", "DS2I_NO_RMH=1", "DS2I_NO_RMH_USE=1", "DS2I_STREAM_SETS=1", "DS2I_UNIT_CAP=8",
-                                  "DS2I_LOOKUP_WEIGHT=0", "DS2I_UNIT_DIV_MANY=1"])
+                                  "DS2I_LOOKUP_WEIGHT=0", "DS2I_UNIT_DIV_MANY=1", "DS2I_STREAM_NT_MAX=4"])
 def test_alternative_paths_give_the_same_results(built_lib, knob):
     """The library reads its A/B knobs once per process, so each alternative path -- no block-max table, table present but
     unused, no interleaved skip table (= no list-0 stream), union kernels without / with exact dynamic-LDS groups, no
@@ -1159,7 +1159,7 @@ def test_alternative_paths_give_the_same_results(built_lib, knob):
     cut to one block per unit, seeded by the ranked_and sub-query pass, and gathering the range-table bytes in one trip / with
     three optional lists in the first of two, ranked_and through the class kernels instead of the pipelined stream kernel,
     no membership hints / hints unused, two alternating sets of class streams, units capped at 8 blocks, the planner's
-    lookup pricing off, the 9-16-term class not cut finer -- is driven through one fuzz collection (every codec, k,
+    lookup pricing off, the 9-16-term class not cut finer, the 5-8-term class of ranked_and through k_conjunctive instead of k_ranked_stream<5..8> -- is driven through one fuzz collection (every codec, k,
     operator; oracle-checked) in a process of its own."""
     import os, subprocess, sys
     env = dict(os.environ)
@@ -1172,7 +1172,7 @@ def test_alternative_paths_give_the_same_results(built_lib, knob):
 
 @pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8"])
 def test_ranked_stream_5_to_8_lists_behind_its_knob(built_lib, extra):
-    """DS2I_STREAM_NT_MAX=8 (off by default): the 5..8-term class of a ranked_and batch on block_optpfor runs
+    """DS2I_STREAM_NT_MAX=8 (the default since the end of round 5; pinned here): the 5..8-term class of a ranked_and batch on block_optpfor runs
     k_ranked_stream<5..8> instead of k_conjunctive<true, true, 8> (queries.hpp:322-401 for any number of terms). Same
     results, bit for bit, whole queries and -- with units capped at 8 blocks -- queries split into many parts that share
     their floor; the probe also asserts that the stream kernel did run for every list count 2..8 (launch groups)."""
