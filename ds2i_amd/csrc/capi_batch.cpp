@@ -719,7 +719,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             b->sub[c].push_back({0u, b->ncls[c], cls_lists});
             continue;
         }
-        // ranked_and on block_optpfor with every upload-time table: the 2-, 3- and 4-term queries run the pipelined stream
+        // ranked_and on block_optpfor with every upload-time table: the 2- .. 8-term queries (block_mixed native: 2 .. 4) run the pipelined stream
         // kernel compiled for exactly their list count (ranked_stream.hip), one launch group per count, back to back on the
         // class stream; one-term queries and everything else keep the class kernel
         // (the 5..8-term class takes the stream kernel too, up to DS2I_STREAM_NT_MAX lists -- block_optpfor only)
