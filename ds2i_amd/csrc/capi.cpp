@@ -426,8 +426,8 @@ namespace {
 const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET",
                                     "DS2I_STREAM_SETS", "DS2I_CLASS_PRIORITY"};
 const char* const kBatchKnobs[] = {"DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
-                                   "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
-                                   "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
+                                   "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_AND_RSTREAM", "DS2I_NO_AND_STREAM", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
+                                   "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_RSTREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
                                    "DS2I_SEED_STREAM", "DS2I_SEED_TERMS", "DS2I_STREAM_NT_MAX", "DS2I_UNIT_CAP", "DS2I_UNIT_CLOCK", "DS2I_UNIT_DIV", "DS2I_UNIT_DIV_MANY", "DS2I_UNIT_DIV_RMW",
                                    "DS2I_UNIT_FACTOR", "DS2I_UNIT_FLOOR", "DS2I_UT_BLOCKS", "DS2I_UT_DIV_MANY", "DS2I_UT_FIRST"};
 }

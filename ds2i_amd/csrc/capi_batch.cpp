@@ -39,6 +39,8 @@ hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned 
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
 hipError_t ds2i_launch_freq_stream(const void* args, unsigned longest, unsigned nqterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_and_stream(const void* args, int with_freqs, unsigned longest, unsigned nterms, hipStream_t s); // freq_stream.hip
+hipError_t ds2i_launch_and_rstream(int nt, const void* args, unsigned grid, hipStream_t s);       // ranked_stream.hip (AND = true)
+hipError_t ds2i_launch_union_stream(int nt, const void* args, unsigned grid, hipStream_t s);     // union_stream.hip (wand / maxscore / ranked_or)
 hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
@@ -174,6 +176,7 @@ struct ds2i_hip_batch {
     std::vector<QTerm> vterms;
     std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
     bool union_stream = false;
+    bool union_rstream = false;   // ... and some class of it runs k_union_stream (union_stream.hip): unit records + the floor words
     // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
     // depend on the union -- by a stream of their own after the merge (freq_stream.hip)
     bool freq_stream = false;
@@ -497,11 +500,13 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
                       !b->long_terms && !no_topk_stream && !tables_off;
     static const bool no_and_stream = std::getenv("DS2I_NO_AND_STREAM") != nullptr;
-    const bool and_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
-                            idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_rmw && idx->has_bitmaps && !no_and_stream &&
-                            !std::getenv("DS2I_NO_BITMAP_USE") && !std::getenv("DS2I_NO_RMW_USE");
+    // (list_stream: what a stream over ONE list needs -- its blocks through the side slots; and_stream: the other lists' bitmaps as well)
+    const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
+                             idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !no_and_stream;
+    const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps && !std::getenv("DS2I_NO_BITMAP_USE") && !std::getenv("DS2I_NO_RMW_USE");
     b->sterms.clear();
     b->sterm_longest = 0;
+    b->union_rstream = false;
     static const bool no_freq_stream = std::getenv("DS2I_NO_FREQ_STREAM") != nullptr;
     b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
                      idx->d_skip && !no_freq_stream && !std::getenv("DS2I_NO_UNION_STREAM");
@@ -544,12 +549,14 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         const double target = std::max(floor_cost, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
                                                        (c == 3 && rmw_cost ? unit_div_many : 1.0));
         ++b->nqcls[c];
-        if (and_stream && nt >= 2 && nt <= 4) {
+        if ((and_stream && nt >= 2 && nt <= 4) || (list_stream && nt == 1)) {
             // every list carries its exact bitmap: the query is a sum over the postings of its shortest list (and, with the freqs,
             // over every list's own postings) of one bit test per other list -- list streams, no units (k_and_stream)
             // (and_query reads only its shortest list: that one needs no bitmap of its own)
+            // One-term queries (and_query walks the list and counts it, queries.hpp:58-84): the same stream with no other list -- beside
+            // the class kernels instead of in front of the two-term group on class 0's stream (424 of 4096 queries, 5 of that class's 9 ms)
             bool dense = true;
-            for (uint32_t i = qoff[q] + (base_op == DS2I_OP_AND ? 1u : 0u); i < qoff[q + 1]; ++i)
+            for (uint32_t i = qoff[q] + (base_op == DS2I_OP_AND ? 1u : 0u); nt > 1 && i < qoff[q + 1]; ++i)
                 dense = dense && ds2i_dev::RmwLevels::has_bitmap(qterms[i].n, (uint32_t)idx->num_docs);
             if (dense) {
                 const uint32_t lists = base_op == DS2I_OP_AND_FREQ ? nt : 1u;
@@ -636,6 +643,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 QTerm drv = qterms[begin + ord[e]];
                 drv.suf_bmw = suffix[e + 1];
                 drv.floor1 = f1;
+                drv.max_weight = suffix[0]; // (k_union_stream: the query's score bound = the scale of its shared histogram)
                 b->vterms.push_back(drv);
                 for (uint32_t j = 0; j < e; ++j) { // exclusion lists
                     QTerm t = qterms[begin + ord[j]];
@@ -657,7 +665,19 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 // (the 9-16-term class runs one wave per SIMD: its units are cut DS2I_UT_DIV_MANY times finer, for more of them at once)
                 static const char* utm = std::getenv("DS2I_UT_DIV_MANY");
                 static const uint32_t ut_div_many = utm && std::atoi(utm) > 0 ? (uint32_t)std::atoi(utm) : 4u;
-                const uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / ut_div_many) : ut_blocks;
+                uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / ut_div_many) : ut_blocks;
+                if (!utb && c <= 2) {
+                    // What a block of a driving list costs falls steeply with e -- the first lists of the order meet a low threshold and
+                    // several optional lists (every candidate asks every table, many are looked up), the later ones are mostly skipped by
+                    // their table window: measured wave time per owned block (DS2I_UNIT_CLOCK, GOV2-scale wand batch), by class and e --
+                    // 2 lists: 3.1 / 0.1 us; 3-4 lists: 6.1 / 0.4 / 0.1; 5-8 lists: 11.8 / 5.6 / 1.6 / 0.6 / 0.4 / 0.1. Cut at 160 blocks
+                    // whatever e, the e = 0 units of the many-list classes ran 3-4 ms each and WERE their launch's span (1 165 of ~3 500
+                    // wave slots busy on average), while the late lists' units paid a unit's start-up for 20 us of work. Units of about
+                    // equal time instead (DS2I_UT_BLOCKS pins one size for every list: A/B).
+                    static const float us_per_block[3][4] = {{3.1f, 0.15f, 0.15f, 0.15f}, {6.1f, 0.4f, 0.15f, 0.15f}, {11.8f, 5.6f, 1.6f, 0.5f}};
+                    const float target_us = 400.f;
+                    utb_c = (uint32_t)std::min(640.f, std::max(16.f, target_us / us_per_block[c][std::min(e, 3u)]));
+                }
                 const uint32_t parts_e = (nbe + utb_c - 1) / utb_c, per = (nbe + parts_e - 1) / parts_e;
                 for (uint32_t lo = 0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
                     add_unit(c, vq, lo, std::min(nbe, lo + per), 0, (double)(nt - e) * 1.0e7 + (double)(std::min(nbe, lo + per) - lo));
@@ -715,8 +735,39 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
         static const char* dm = std::getenv("DS2I_DYN_MINCLS");
         static const int dyn_mincls = dm ? std::atoi(dm) : 2;
-        if (b->union_stream) { // k_union_topk: static LDS, one launch per class
-            b->sub[c].push_back({0u, b->ncls[c], cls_lists});
+        if (b->union_stream) {
+            // block_optpfor with every upload-time table: the virtual queries of 2 .. 8 lists run the pipelined stream kernel compiled for
+            // exactly their list count (union_stream.hip), one launch group per count, back to back on the class stream -- as ranked_and
+            // does (below); everything else (other codecs, 9-16 lists, the empty query's unit): k_union_topk, static LDS, one launch per class
+            static const bool no_us = std::getenv("DS2I_NO_UNION_RSTREAM") != nullptr;
+            const bool us_ok = !no_us && c <= 2 && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw;
+            b->union_rstream = b->union_rstream || us_ok;
+            if (!us_ok) {
+                b->sub[c].push_back({0u, b->ncls[c], cls_lists});
+                continue;
+            }
+            // (list CAPACITIES 2 | 4 | 6 | 8: a launch group holds the virtual queries of cap - 1 and cap lists -- four groups and four tails
+            // per batch instead of seven; inside a group the units stay in cost order)
+            auto cap_of = [&](uint32_t uid) { const uint32_t vq = b->units[uid].q, n = b->voff[vq + 1] - b->voff[vq]; return n < 2 ? 0u : n > 8 ? DS2I_HIP_MAX_TERMS + 1u : (n + 1u) & ~1u; };
+            {   // stable partition by capacity, largest first
+                uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
+                for (uint32_t uid : b->order[c]) ++cnt[cap_of(uid)];
+                uint32_t start[DS2I_HIP_MAX_TERMS + 2], acc = 0;
+                for (int n = DS2I_HIP_MAX_TERMS + 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
+                std::vector<uint32_t>& tmp = b->scratch_u32;
+                tmp.resize(b->order[c].size());
+                for (uint32_t uid : b->order[c]) tmp[start[cap_of(uid)]++] = uid;
+                b->order[c].swap(tmp);
+            }
+            for (uint32_t i = 0; i < b->ncls[c];) {
+                uint32_t j = i;
+                const uint32_t l = cap_of(b->order[c][i]);
+                while (j < b->ncls[c] && cap_of(b->order[c][j]) == l) ++j;
+                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= 8 ? l : cls_lists};
+                sl.stream = l >= 2 && l <= 8;
+                b->sub[c].push_back(sl);
+                i = j;
+            }
             continue;
         }
         // ranked_and on block_optpfor with every upload-time table: the 2- .. 8-term queries (block_mixed native: 2 .. 4) run the pipelined stream
@@ -725,27 +776,39 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // (the 5..8-term class takes the stream kernel too, up to DS2I_STREAM_NT_MAX lists -- block_optpfor only)
         static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
         const uint32_t rs_nt = idx->kind == DS2I_BLOCK_OPTPFOR ? rs_stream_nt_max() : 4u;
-        const bool rs_ok = base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs && !tables_off &&
+        // `and` batches that do not ask for the doc-id lists take the same pipeline with AND = true -- a candidate whose hints settle
+        // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
+        // verifies every survivor of its filters by a probe). DS2I_NO_AND_RSTREAM=1: the class kernels (A/B).
+        static const bool and_rs = std::getenv("DS2I_NO_AND_RSTREAM") == nullptr;
+        const bool rs_and = base_op == DS2I_OP_AND && and_rs && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
+        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs && !tables_off &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
         if (rs_ok) {
+            // launch groups by list CAPACITY 2 | 4 | 6 | 8 (block_optpfor: a group holds the queries of cap - 1 and cap lists, UnitRec::pad says
+            // which; block_mixed native: the exact count, 2 .. 4): four groups and four tails per batch instead of seven; queries beyond
+            // DS2I_STREAM_NT_MAX lists and one-term queries form the class kernel's groups. Inside a group the units stay in cost order.
+            const bool exact = idx->kind != DS2I_BLOCK_OPTPFOR;
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
-            {   // stable partition by list count, longest first (a class holds at most five different counts: one pass per count
-                // would do; a counting sort does it in two)
+            auto cap_of = [&](uint32_t uid) {
+                const uint32_t n = nt_of(uid);
+                return n < 2 ? n : n > rs_nt ? DS2I_HIP_MAX_TERMS + 1u : exact ? n : (n + 1u) & ~1u;
+            };
+            {   // stable partition by capacity, largest first
                 uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
-                for (uint32_t uid : b->order[c]) ++cnt[std::min<uint32_t>(nt_of(uid), DS2I_HIP_MAX_TERMS + 1)];
+                for (uint32_t uid : b->order[c]) ++cnt[cap_of(uid)];
                 uint32_t start[DS2I_HIP_MAX_TERMS + 2], acc = 0;
                 for (int n = DS2I_HIP_MAX_TERMS + 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
                 std::vector<uint32_t>& tmp = b->scratch_u32;
                 tmp.resize(b->order[c].size());
-                for (uint32_t uid : b->order[c]) tmp[start[std::min<uint32_t>(nt_of(uid), DS2I_HIP_MAX_TERMS + 1)]++] = uid;
+                for (uint32_t uid : b->order[c]) tmp[start[cap_of(uid)]++] = uid;
                 b->order[c].swap(tmp);
             }
             for (uint32_t i = 0; i < b->ncls[c];) {
                 uint32_t j = i;
-                const uint32_t l = nt_of(b->order[c][i]);
-                while (j < b->ncls[c] && nt_of(b->order[c][j]) == l) ++j;
-                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 ? l : cls_lists};
-                sl.stream = l >= 2 && l <= rs_nt;
+                const uint32_t l = cap_of(b->order[c][i]);
+                while (j < b->ncls[c] && cap_of(b->order[c][j]) == l) ++j;
+                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= DS2I_HIP_MAX_TERMS ? l : cls_lists};
+                sl.stream = l >= 2 && l <= 8;
                 b->sub[c].push_back(sl);
                 i = j;
             }
@@ -804,7 +867,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (uint32_t i = 0; i < b->nsplit; ++i) b->hist_slot[b->split_queries[i]] = i;
     b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
-    for (int c = 0; c < 3; ++c) b->o_urec[c] = place(c < rs_stream_classes() ? b->order[c].size() * sizeof(ds2i_dev::UnitRec) : 0); // (classes of k_ranked_stream)
+    for (int c = 0; c < 3; ++c) b->o_urec[c] = place((b->union_rstream || c < rs_stream_classes()) ? b->order[c].size() * sizeof(ds2i_dev::UnitRec) : 0); // (classes of k_ranked_stream / k_union_stream)
     b->o_qterm_q = place(b->freq_stream ? qterms.size() * 4 : 0);
     b->o_sterms = place(b->sterms.size() * sizeof(ds2i_dev::StreamTerm));
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
@@ -911,12 +974,21 @@ int upload_batch(ds2i_hip_batch* b) {
         for (uint32_t q = 0; q < b->nq; ++q)
             for (uint32_t i = b->qoff[q]; i < b->qoff[q + 1]; ++i) qq[i] = q;
     }
+    for (int c = 0; c < 3 && b->union_rstream; ++c) { // k_union_stream: the unit, its virtual query's terms, its REAL query (results, histogram), its exclusion lists
+        ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
+        for (size_t i = 0; i < b->order[c].size(); ++i) {
+            const uint32_t uid = b->order[c][i];
+            const Unit& u = b->units[uid];
+            const uint32_t rq = b->vinfo[3 * (size_t)u.q];
+            r[i] = ds2i_dev::UnitRec{uid, rq, u.blk_begin, u.blk_end, u.nparts, b->qoff[u.q], b->hist_slot[rq], b->vinfo[3 * (size_t)u.q + 1] | ((b->qoff[u.q + 1] - b->qoff[u.q]) << 8)};
+        }
+    }
     for (int c = 0; c < rs_stream_classes() && !b->union_stream; ++c) { // one record per ticket: what k_ranked_stream reads where a unit starts (conjunctive batches)
         ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
         for (size_t i = 0; i < b->order[c].size(); ++i) {
             const uint32_t uid = b->order[c][i];
             const Unit& u = b->units[uid];
-            r[i] = ds2i_dev::UnitRec{uid, u.q, u.blk_begin, u.blk_end, u.nparts, b->qoff[u.q], b->hist_slot[u.q], 0u};
+            r[i] = ds2i_dev::UnitRec{uid, u.q, u.blk_begin, u.blk_end, u.nparts, b->qoff[u.q], b->hist_slot[u.q], b->qoff[u.q + 1] - b->qoff[u.q]};
         }
     }
     if (b->want_matches) put(b->o_match_off, b->match_off.data(), b->match_off.size() * 8);
@@ -1034,7 +1106,12 @@ int launch_batch(ds2i_hip_batch* b) {
     static const bool spread = e_spread && std::atoi(e_spread) > 0;
     hipStream_t spare[NCLS];
     int nspare = 0, next_spare = 0;
-    if (spread && !b->sset)
+    // Independently of the knob: ranked_and's one-term queries (the class kernel's group of class 0: 0.9 ms behind the two-term stream
+    // kernel's 2.5 ms on that class's stream) go to a spare stream -- class 0 is one of three co-critical class streams of the step
+    const bool side_group0 = base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && b->ncls[0] && b->sub[0].size() > 1 && b->sub[0].front().stream;
+    // ... and wand / maxscore / ranked_or's second stream group of the 5-8-list class (capacity 6 behind capacity 8: 3.6 ms behind 7.5 ms)
+    const bool side_group2 = b->union_rstream && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
+    if ((spread || side_group0 || side_group2) && !b->sset)
         for (int c = NCLS - 1; c >= 0; --c)
             if (!b->ncls[c]) {
                 spare[nspare] = idx->stream[c];
@@ -1060,7 +1137,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
-        a.urec = c < rs_stream_classes() ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
+        a.urec = (c < 3 && (b->union_rstream || c < rs_stream_classes())) ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
         a.nslice = b->ncls[c];
         a.dyn_lists = 0;
         a.num_docs = (uint32_t)idx->num_docs;
@@ -1080,7 +1157,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.seed_topk = b->use_seed ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
         a.seed_len = b->use_seed ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
         const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-        a.q_floor = base_op == DS2I_OP_RANKED_AND ? b->d_scr.at<unsigned int>(b->o_qfloorw) : nullptr;
+        a.q_floor = (base_op == DS2I_OP_RANKED_AND || b->union_rstream) ? b->d_scr.at<unsigned int>(b->o_qfloorw) : nullptr;
         a.q_hist = (!(b->op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_topk))
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
         a.q_hist_slot = b->d_up.at<uint32_t>(b->o_hslot);
@@ -1114,10 +1191,12 @@ int launch_batch(ds2i_hip_batch* b) {
                 HIP_OK(hipEventCreate(&e));
                 b->ev_g[c].push_back(e);
             }
-            hipStream_t sg = (gi > 0 && nspare) ? spare[next_spare++ % nspare] : s;
+            hipStream_t sg = (gi > 0 && nspare && (spread || (c == 0 && side_group0 && !sl.stream) || (c == 2 && side_group2 && gi == 1))) ? spare[next_spare++ % nspare] : s;
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
-                HIP_OK(idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
+                HIP_OK(b->union_stream ? ds2i_launch_union_stream((int)sl.lists, &a, a.nslice, sg)
+                       : base_op == DS2I_OP_AND ? ds2i_launch_and_rstream((int)sl.lists, &a, a.nslice, sg)
+                       : idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
             else HIP_OK(ds2i_launch_batch(b->freq_stream ? (int)DS2I_OP_OR : (b->op & (0xFF | DS2I_OP_REFERENCE_ORDER)), c, &a, a.nslice, sg));
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));
             if (sg != s) HIP_OK(hipStreamWaitEvent(sm, b->ev_g[c][2 * gi + 1], 0));
@@ -1196,6 +1275,20 @@ int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
             std::fprintf(stderr, "ds2i unit clock: class %d: %zu units, span %.0f us, sum of unit times %.0f us (= %.0f waves busy on average), median unit %.1f us, p99 %.1f us\n",
                          c, durs.size(), (t1 - t0) * tick_us, busy * tick_us, busy / (double)(t1 - t0), durs[durs.size() / 2].first * tick_us,
                          durs[durs.size() * 99 / 100].first * tick_us);
+            if (b->union_stream && !b->vinfo.empty()) { // wand / maxscore / ranked_or: where the time goes by driving list (e = its exclusion lists)
+                double by_e[DS2I_HIP_MAX_TERMS + 1] = {}, blocks_e[DS2I_HIP_MAX_TERMS + 1] = {};
+                size_t n_e[DS2I_HIP_MAX_TERMS + 1] = {};
+                for (const auto& d : durs) {
+                    const Unit& u = b->units[d.second];
+                    const uint32_t e = std::min<uint32_t>(b->vinfo[3 * (size_t)u.q + 1], DS2I_HIP_MAX_TERMS);
+                    by_e[e] += (double)d.first;
+                    blocks_e[e] += (double)(u.blk_end - u.blk_begin);
+                    ++n_e[e];
+                }
+                for (uint32_t e = 0; e <= DS2I_HIP_MAX_TERMS; ++e)
+                    if (n_e[e]) std::fprintf(stderr, "    driving list %u: %zu units of %.0f blocks, %.0f us of unit time (%.1f us per owned block)\n", e, n_e[e], blocks_e[e], by_e[e] * tick_us,
+                                             by_e[e] * tick_us / std::max(1.0, blocks_e[e]));
+            }
             for (size_t i = 0; i < 8 && i < durs.size(); ++i) {
                 const auto& d = durs[durs.size() - 1 - i];
                 const Unit& u = b->units[d.second];

@@ -35,8 +35,10 @@
 
 #include "device_enum.hpp"
 #include "device_score.hpp"
+#include "stream_common.hpp"
 
 using namespace ds2i_dev;
+using namespace ds2i_dev::stream;
 
 namespace {
 
@@ -48,7 +50,7 @@ namespace {
 #endif
 // 5..8 lists: what fits -- one more decoded block (1 KB of LDS) and nine more parked scalars per list:
 // 7 936 .. 11 008 bytes of LDS per wave
-#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 7 ? 4 : 3)
+#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 6 ? 4 : 3)
 
 template <int NT>
 struct LdsRS {
@@ -62,210 +64,20 @@ struct LdsRS {
     uint32_t fw[64];             // the query's shared floor word, as fetched an iteration ago (LDS-DMA: one copy per lane)
 };
 
-// first block >= from of a list whose block_max >= lb, with its table words; rows = the list's interleaved skip table
-// ({block_max, end offset} per block), wtab = its block weights. 64 rows per probe: the 64 after `from`, then a 64-ary
-// search (the reference scans block_max linearly, block_posting_list.hpp:134-137).
-struct Found { uint32_t blk, bmax, base, ep; float w; };
-// the first probe's rows (from-1 .. from+62; lane 0 = the block before `from`, never a candidate itself): they do not depend on
-// the doc-id searched for, so stage C requests them together with the candidates' norm_lens, one round trip earlier
-struct Rows { uint2 e; float w; };
-DS2I_DEV Rows rows_load(const uint2* tab, const float* wtab, uint32_t nb, uint32_t from) {
-    const uint32_t idx = (from ? from - 1 : 0) + lane_id();
-    Rows r{make_uint2(0xFFFFFFFFu, 0u), 0.f};
-    if (idx < nb) { r.e = tab[idx]; r.w = wtab[idx]; }
-    return r;
-}
-DS2I_DEV bool find_block_rows(const uint2* tab, const float* wtab, uint32_t nb, uint32_t from, uint32_t lb, Found& o, const Rows& first_rows) {
-    const uint32_t lane = lane_id();
-    if (from >= nb) return false;
-    float wv = 0.f;
-    auto finish = [&](uint2 e, uint32_t first_idx, uint64_t hit) __attribute__((always_inline)) {
-        const uint32_t f = (uint32_t)__builtin_ctzll(hit);
-        o.blk = first_idx + f;
-        o.w = __uint_as_float(bcast(__float_as_uint(wv), f));
-        o.bmax = bcast(e.x, f);
-        const uint32_t pf = f ? f - 1 : 0;
-        const uint32_t pmax = bcast(e.x, pf), pend = bcast(e.y, pf);
-        o.base = o.blk ? pmax + 1u : 0u;
-        o.ep = o.blk ? pend : 0u;
-    };
-    {
-        const uint32_t first = from ? from - 1 : 0;
-        const uint32_t idx = first + lane;
-        const uint2 e = first_rows.e;
-        wv = first_rows.w;
-        const uint64_t hit = ballot(idx >= from && idx < nb && e.x >= lb);
-        if (hit) { finish(e, first, hit); return true; }
-        if (first + 64 >= nb) return false;
-    }
-    uint32_t lo = (from ? from - 1 : 0) + 64, hi = nb; // answer in [lo, hi) or none
-    while (hi - lo > 63) {
-        const uint32_t stride = (hi - lo + 63) / 64;
-        uint32_t idx = lo + (lane + 1) * stride - 1;
-        if (idx >= hi) idx = hi - 1;
-        const uint32_t v = tab[idx].x;
-        const uint64_t hit = ballot(v >= lb);
-        if (!hit) return false;
-        const uint32_t f = (uint32_t)__builtin_ctzll(hit);
-        const uint32_t nhi = lo + (f + 1) * stride;
-        hi = nhi < hi ? nhi : hi;
-        lo = lo + f * stride;
-    }
-    const uint32_t first = lo - 1; // (lo >= 64 here)
-    const uint32_t idx = first + lane;
-    uint2 e = make_uint2(0xFFFFFFFFu, 0u);
-    if (idx < hi) { e = tab[idx]; wv = wtab[idx]; }
-    const uint64_t hit = ballot(idx >= lo && idx < hi && e.x >= lb);
-    if (!hit) return false;
-    finish(e, first, hit);
-    return true;
-}
-
-// position of c in the sorted block d[128] (valid iff `want`): binary search per lane
-DS2I_DEV bool rs_member(const uint32_t* d, uint32_t c, bool want, uint32_t& pos) {
-    uint32_t idx = 0;
-    if (want) {
-#pragma unroll
-        for (uint32_t step = 64; step; step >>= 1)
-            if (d[idx + step - 1] < c) idx += step;
-    }
-    pos = idx;
-    return want && d[idx] == c;
-}
-
-DS2I_DEV void store_topk_rs(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopK& tk) {
-    const uint32_t lane = lane_id();
-    if (lane < k) topk[(size_t)slot * k + lane] = tk.v;
-    if (lane == 0) topk_len[slot] = tk.n;
-}
-
-template <int I, int N, class F>
-DS2I_DEV void rs_for(F& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        rs_for<I + 1, N>(f);
-    }
-}
-template <int I, int LO, class F>
-DS2I_DEV void rs_for_down(F& f) { // I-1 down to LO
-    if constexpr (I > LO) {
-        f(std::integral_constant<int, I - 1>{});
-        rs_for_down<I - 1, LO>(f);
-    }
-}
-
-// The argument block is ~40 pointers and scalars. Read as a by-value kernel argument the compiler loads all of them at
-// kernel entry and keeps them in SGPRs for the kernel's lifetime. Here the kernarg segment is addressed explicitly: the few
-// hot fields are read where a unit starts, the cold ones at their use site through a pointer the optimiser cannot see through
-// (so the loads stay where they are written instead of being hoisted above the loops).
-typedef const BatchArgs __attribute__((address_space(4))) * KArgs; // (constant address space: uniform reads are s_load)
-DS2I_DEV KArgs rs_args() {
-    KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// a wave-uniform value / pointer the compiler could not prove uniform (anything loaded through a global pointer): through
-// v_readfirstlane, so that what is computed from it is scalar arithmetic and the "s" constraints below get scalar registers
-// (given a VGPR pair they assemble to nothing)
-template <class T> DS2I_DEV const T* rs_uniform_ptr(const T* p) {
-    const unsigned long long v = (unsigned long long)(uintptr_t)p;
-    return (const T*)(uintptr_t)(((unsigned long long)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v));
-}
-DS2I_DEV unsigned long long rs_uniform64(unsigned long long v) { return ((unsigned long long)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v); }
-DS2I_DEV float rs_uniformf(float v) { return __uint_as_float(uniform(__float_as_uint(v))); }
-
-// ---- loads the compiler must not count. hipcc drains vmcnt to 0 wherever control flow joins with a load pending on
-// some path, which would put every round trip back on the critical path; these are issued and waited for by hand.
-// (i) block bytes + side slot: LDS-DMA, global -> LDS with no register in between (nothing the compiler could copy or spill
-// early). 512 bytes at g (4-byte aligned) -> LDS byte offset `lds`, 256 bytes at gx -> lds_x; voff = lane * 4. M0 is the DMA's
-// LDS base: compiler-reserved, so it is saved, set and restored inside the statement. (The instruction offset moves the global
-// AND the LDS address: measured, profiles/probes/ldsdma_probe.hip.)
-DS2I_DEV uint32_t rs_lds_offset(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
-DS2I_DEV void rs_prefetch_blk(const uint8_t* g, uint32_t lds, const uint32_t* gx, uint32_t lds_x, uint32_t voff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %2 offset:256\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(g), "s"(uniform(lds)), "s"(gx), "s"(uniform(lds_x)) : "memory");
-}
-static constexpr int PF_LOADS = 3; // hand-issued loads of one block prefetch
-// (i') one dword at g, read past this CU's L1 (sc1: other CUs update it with atomics) -> the 64 dwords at LDS byte offset lds
-DS2I_DEV void rs_fetch_word(const unsigned int* g, uint32_t lds) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(0u), "s"(g), "s"(uniform(lds)) : "memory");
-}
-// (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
-// lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
-// destination is written when the statement ends, and under register pressure it did copy the still-pending register
-// (tests/asm_audit.py found it before the GPU did).
-DS2I_DEV void rs_gather_u8(const uint8_t* tab, uint32_t off, uint32_t lds) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(tab), "s"(uniform(lds)) : "memory");
-}
-// one lane of a VGPR takes a wave-uniform value (v_writelane_b32; there is no builtin for it in this toolchain)
-template <int LANE> DS2I_DEV void rs_writelane(uint32_t& dst, uint32_t v) {
-    const uint32_t sv = uniform(v);
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(sv), "n"(LANE));
-}
-template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// stage C: the 512 bytes from g (dword aligned) and the 256-byte side slot at gx -> LDS, by plain loads
-DS2I_DEV void rs_stage_block(const uint32_t* g, const uint32_t* gx, uint32_t* st, uint32_t* xs) {
-    const uint32_t lane = lane_id();
-    const uint32_t w0 = g[lane], w1 = g[lane + 64], x = gx[lane];
-    st[lane] = w0;
-    st[lane + 64] = w1;
-    xs[lane] = x;
-    wave_sync();
-}
-// the partial last block of a list from the tail table (BatchArgs::tails; entry = sz gaps-1, sz freqs-1, bytes of the docs
-// part, bytes of the freqs part). Rare (once per list and unit at most): plain loads, waited for here.
-DS2I_DEV void rs_tail(const uint32_t* tails, unsigned long long entry, uint32_t sz, uint32_t& d0, uint32_t& d1, uint32_t& f0, uint32_t& f1, uint32_t& cons_d, uint32_t& cons_f) {
-    const uint32_t lane = lane_id();
-    const uint32_t* const t = tails + entry;
-    uint32_t a0 = (lane < sz) ? t[lane] : 0u, a1 = (lane + 64 < sz) ? t[lane + 64] : 0u;
-    uint32_t b0 = (lane < sz) ? t[sz + lane] : 0u, b1 = (lane + 64 < sz) ? t[sz + lane + 64] : 0u;
-    uint32_t c0 = t[2u * sz], c1 = t[2u * sz + 1u];
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1)::"memory");
-    d0 = a0;
-    d1 = a1;
-    f0 = b0;
-    f1 = b1;
-    cons_d = uniform(c0);
-    cons_f = uniform(c1);
-}
-// docs (gaps-1) and freqs-1 of a full block staged at st / slot: the branch-free pair decoder, or -- a block in 10^4: raw parts,
-// parts beyond the staged bytes, adds in the overflow area -- the general side-slot decoder part by part. gblk = the block's
-// address in the arena.
-DS2I_DEV void rs_decode_full(const uint32_t* st, const uint32_t* slot, const uint8_t* gblk, const uint32_t* xovf, uint32_t& d0, uint32_t& d1, uint32_t& f0,
-                             uint32_t& f1, uint32_t& cons_d, uint32_t& cons_f) {
-    const SlotHead h = optpfor_slot_head(slot);
-    if (__builtin_expect(h.flag == 0u, 1)) {
-        optpfor_decode_pair(st, slot, h, d0, d1, f0, f1, cons_d, cons_f);
-    } else {
-        uint32_t nd = 0;
-        cons_d = optpfor_decode_side(st, STAGE_DW, slot, gblk, xovf, 0u, 0u, d0, d1, &nd);
-        const uint32_t skip_dw = cons_d >> 2;
-        cons_f = optpfor_decode_side(st + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, slot, gblk + cons_d, xovf, 1u, nd, f0, f1);
-    }
-}
-
-// an UPPER bound of bm25 doc_term_weight(f, nl) = f / (f + k1 (1 - b + b nl)) (device_enum.hpp) for the pruning tests: the
-// quotient through v_rcp_f32 (1 ulp) instead of the IEEE division sequence (11 instructions), widened by 2^-20 -- far more than
-// the reciprocal's and the product's rounding can lose. Scores themselves are always computed with the exact division.
-DS2I_DEV float rs_dtw_bound(uint32_t freq, float norm_len) {
-    const float f = (float)freq;
-    return f * __builtin_amdgcn_rcpf(f + 1.2f * (0.5f + 0.5f * norm_len)) * (1.0f + 1.0f / 1048576.0f);
-}
-
+// stage C as ONE loop body over the lists (run-time list index) from this capacity on; below it the body is unrolled per list
+#ifndef RS_ONE_BODY
+#define RS_ONE_BODY 4
+#endif
 #ifndef RS_HINT_FIRST
 #define RS_HINT_FIRST(nt) ((nt) > 2)
 #endif
-template <int NT, bool STATS>
+// AND = true: and_query (queries.hpp:35-86, count only) through the same pipeline -- no scores, no heap: a candidate of list 0 is
+// a result iff every other list holds it. The membership hints settle that exactly wherever a range holds one posting and is at
+// most 254 doc-ids wide (rmh_code is injective there): such a candidate is counted without list j ever being searched or decoded;
+// only candidates in ranges with several postings (hint 255), in wider ranges, or of an upload without hints are probed.
+template <int NT, bool STATS, bool AND = false>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
-    static_assert(NT >= 2 && NT <= 8, "exact list counts 2..8");
+    static_assert(NT >= 2 && NT <= 8, "list capacities 2..8");
     static_assert((NT - 2) * 9 + 8 < 64, "the per-list constants of lists 1.. are parked in the lanes of one VGPR");
     __shared__ LdsRS<NT> L;
     const uint32_t lane = lane_id();
@@ -315,9 +127,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         }
         const uint32_t q = uniform(u.q), blk_begin = uniform(u.blk_begin), blk_end = uniform(u.blk_end);
         const bool whole = uniform(u.nparts) == 1u;
-        const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(u.qt_off)); // exactly NT terms (the planner's launch groups)
+        // NT is the list CAPACITY of the instantiation (2, 4, 6, 8); the query has nt <= NT lists (UnitRec::pad; two lists: always 2).
+        // A list slot j >= nt does not exist: its bytes are never loaded, count as zero, and no test looks at them.
+        const uint32_t nt = NT == 2 ? 2u : uniform(u.pad);
+        const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(u.qt_off)); // nt terms
         TopK tk;
         tk.init(a->k);
+        unsigned long long and_count = 0; // (AND: results of this unit)
         // ---- list 0: the stream
         const uint32_t n0 = uniform(qt[0].n), nb0 = (n0 + 127u) >> 7;
         const uint32_t vl0 = 1u + (n0 >= (1u << 7)) + (n0 >= (1u << 14)) + (n0 >= (1u << 21)) + (n0 >= (1u << 28));
@@ -331,11 +147,22 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         float rsc[NT];
         auto bind_one = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            rt[j] = a->rmw + 64ull * uniform(qt[j].rmw_off64);
-            rsh[j] = uniform(qt[j].rmw_shift);
-            rsc[j] = rs_uniformf(qt[j].rmw_scale);
+            if ((uint32_t)j < nt) {
+                rt[j] = a->rmw + 64ull * uniform(qt[j].rmw_off64);
+                rsh[j] = uniform(qt[j].rmw_shift);
+                rsc[j] = rs_uniformf(qt[j].rmw_scale);
+            } else {
+                rt[j] = a->rmw;
+                rsh[j] = 31u;
+                rsc[j] = 0.f;
+            }
         };
         rs_for<1, NT>(bind_one);
+        float rscv = 0.f; // lane j = rsc[j] (read by stage C's one-body list loop)
+        if constexpr (NT >= RS_ONE_BODY) {
+            auto spread = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rscv = lane == (uint32_t)j ? rsc[j] : rscv; };
+            rs_for<1, NT>(spread);
+        }
         // what lists 1.. can add to any document at most (their list maxima), and the collection's shortest document: a posting of
         // list 0 with freq f scores at most qw0 * doc_term_weight(f, min_nl) there
         float rest_all = 0.f;
@@ -350,7 +177,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // list); the hint also settles the ranges with a single posting, so that the further lists are asked about a few per cent
         // of the candidates only -- first their hints, then, for what is left, every list's weight for the threshold test.
         // (Two lists: the weight stays first, its threshold test removes more than the hint does.)
-        const bool hint_first = RS_HINT_FIRST(NT) && hdelta != 0;
+        const bool hint_first = (AND || RS_HINT_FIRST(NT)) && hdelta != 0; // (AND: the hint is the answer, the weight says nothing it needs)
         const uint8_t* const gt1 = hint_first ? rt[1] + hdelta : rt[1];
         // block of list j whose doc-ids and freqs are in L.dj[j-1] / L.fj[j-1] (cur = ~0: none) and its block_max. Only stage C
         // touches them: they live in the lanes of one VGPR (v_readlane / v_writelane at a constant lane).
@@ -364,6 +191,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             auto park = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int CB = (j - 1) * C_PER;
+                if ((uint32_t)j >= nt) return;
                 const unsigned long long lo = qt[j].list_off, tl = qt[j].aux1;
                 cset(CB + C_N, qt[j].n);
                 cset(CB + C_BB, qt[j].blk_base);
@@ -377,7 +205,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         }
         // ---- pruning state: the parts of a split query share a score histogram (device_score.hpp)
         unsigned int* const q_hist = a->q_hist;
-        const bool shared_floor = !whole && q_hist;
+        const bool shared_floor = AND ? false : (!whole && q_hist);
         ScoreHist sh;
         sh.init(shared_floor ? q_hist : nullptr, shared_floor ? uniform(u.hist_slot) : 0u, shared_floor ? rs_uniformf(qt[0].max_bmw + qt[0].suf_bmw) : 0.f,
                 1.0f - 1.0f / 1048576.0f);
@@ -385,7 +213,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // wave-uniform values that are refreshed whenever the heap or the floor changes
         float e_floor = tk.floor, e_gt = -__builtin_inff();
         auto refresh = [&]() __attribute__((always_inline)) { e_floor = tk.floor; e_gt = tk.n < tk.k ? -__builtin_inff() : tk.thr; };
-        auto enters = [&](float s) __attribute__((always_inline)) -> bool { return (s >= e_floor) & (s > e_gt); };
+        auto enters = [&](float s) __attribute__((always_inline)) -> bool {
+            if constexpr (AND) return true; // (no threshold: every document of the intersection is a result)
+            else return (s >= e_floor) & (s > e_gt);
+        };
         // The floor the histogram implies is published in one word per split query (BatchArgs::q_floor, float bits: scores are
         // >= 0, so the bit patterns order like the values): whoever puts a score into its heap re-reads the histogram -- the only
         // moment the floor can have moved -- and raises the word; everybody else gets the word with every block, fetched an
@@ -424,6 +255,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             bool dead = false;
             auto one_list = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
+                if ((uint32_t)j >= nt) return;
                 const RmwLevels g(rs_args()->num_docs, rsh[j]);
                 uint32_t lsh = rsh[j], lvl = 0;
                 while (lvl < 2 && (t2 >> lsh) - (b2 >> lsh) >= 16u) { lsh += 6; ++lvl; }
@@ -437,7 +269,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 acc = acc + rsc[j] * (float)best;
             };
             rs_for_down<NT, 1>(one_list);
-            s_ub = (dead || !row) ? -1.0f : (qw0 * s_w + acc) * BOUND_SLACK; // (scores are >= 0: -1 never enters)
+            if constexpr (AND) s_ub = (dead || !row) ? -1.0f : 0.0f; // (a live row: some posting of every other list lies in the block's span)
+            else s_ub = (dead || !row) ? -1.0f : (qw0 * s_w + acc) * BOUND_SLACK; // (scores are >= 0: -1 never enters)
         };
         // a block of list 0 on its way through the stages
         struct Blk { uint32_t blk, base, ep; };
@@ -516,10 +349,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);
                 dA0 = (lane < szA) ? A.base + i0 - 1u : 0xFFFFFFFFu;
                 dA1 = (lane + 64 < szA) ? A.base + i1 - 1u : 0xFFFFFFFFu;
-                boA0 = qw0 * rs_dtw_bound(fv0 + 1u, min_nl);
-                boA1 = qw0 * rs_dtw_bound(fv1 + 1u, min_nl);
-                L.stage[bufA][lane] = fv0 + 1u; // (same lanes write and read: no fence needed before stage C's read an iteration later)
-                L.stage[bufA][lane + 64] = fv1 + 1u;
+                if constexpr (!AND) {
+                    boA0 = qw0 * rs_dtw_bound(fv0 + 1u, min_nl);
+                    boA1 = qw0 * rs_dtw_bound(fv1 + 1u, min_nl);
+                    L.stage[bufA][lane] = fv0 + 1u; // (same lanes write and read: no fence needed before stage C's read an iteration later)
+                    L.stage[bufA][lane + 64] = fv1 + 1u;
+                }
                 ++s_docs_blocks;
                 ++s_freqs_blocks;
                 s_bm_examined += 1;
@@ -536,10 +371,17 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
                 bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (x0 != 0u);
                 bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (x1 != 0u);
+                // AND: bit j = list j has to be searched for this candidate (its hint did not settle it: several postings in the range,
+                // a range wider than rmh_code is injective over, or no hints at all)
+                uint32_t need0 = 0, need1 = 0;
                 if (hint_first) {
                     ok0 = ok0 & ((x0 == 255u) | (x0 == rmh_code(dB0, rsh[1])));
                     ok1 = ok1 & ((x1 == 255u) | (x1 == rmh_code(dB1, rsh[1])));
                     gP0 = gP1 = 0u;
+                    if constexpr (AND) {
+                        need0 = ((x0 == 255u) | (rsh[1] > 7u)) ? 2u : 0u;
+                        need1 = ((x1 == 255u) | (rsh[1] > 7u)) ? 2u : 0u;
+                    }
                     LC(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                     if constexpr (NT > 2) {
                         if (ballot(ok0) | ballot(ok1)) { // the further lists' hints, all requested before any is tested
@@ -547,24 +389,29 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             auto hload = [&](auto jc) __attribute__((always_inline)) {
                                 constexpr int j = decltype(jc)::value;
                                 const uint8_t* const ht = rt[j] + hdelta;
-                                h0[j] = ok0 ? (uint32_t)ht[dB0 >> rsh[j]] : 0u;
-                                h1[j] = ok1 ? (uint32_t)ht[dB1 >> rsh[j]] : 0u;
+                                h0[j] = (ok0 & ((uint32_t)j < nt)) ? (uint32_t)ht[dB0 >> rsh[j]] : 0u;
+                                h1[j] = (ok1 & ((uint32_t)j < nt)) ? (uint32_t)ht[dB1 >> rsh[j]] : 0u;
                                 LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1, 1u));
                             };
                             rs_for<2, NT>(hload);
                             auto htest = [&](auto jc) __attribute__((always_inline)) {
                                 constexpr int j = decltype(jc)::value;
+                                if ((uint32_t)j >= nt) return;
                                 ok0 = ok0 & (h0[j] != 0u) & ((h0[j] == 255u) | (h0[j] == rmh_code(dB0, rsh[j])));
                                 ok1 = ok1 & (h1[j] != 0u) & ((h1[j] == 255u) | (h1[j] == rmh_code(dB1, rsh[j])));
+                                if constexpr (AND) {
+                                    need0 |= ((h0[j] == 255u) | (rsh[j] > 7u)) ? (1u << j) : 0u;
+                                    need1 |= ((h1[j] == 255u) | (rsh[j] > 7u)) ? (1u << j) : 0u;
+                                }
                             };
                             rs_for<2, NT>(htest);
                         }
                     }
-                    if (ballot(ok0) | ballot(ok1)) { // every list's weight byte for what is left
+                    if (!AND && (ballot(ok0) | ballot(ok1))) { // every list's weight byte for what is left (AND: nothing to weigh)
                         auto wload = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
-                            gP0 |= (GP)(ok0 ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u) << (8 * (j - 1));
-                            gP1 |= (GP)(ok1 ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u) << (8 * (j - 1));
+                            gP0 |= (GP)((ok0 & ((uint32_t)j < nt)) ? (uint32_t)rt[j][dB0 >> rsh[j]] : 0u) << (8 * (j - 1));
+                            gP1 |= (GP)((ok1 & ((uint32_t)j < nt)) ? (uint32_t)rt[j][dB1 >> rsh[j]] : 0u) << (8 * (j - 1));
                             LC(PH_FREQS, lines_of(rt[j] + (dB0 >> rsh[j]), ok0, 1u) + lines_of(rt[j] + (dB1 >> rsh[j]), ok1, 1u));
                         };
                         rs_for<1, NT>(wload);
@@ -579,12 +426,14 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     if (ballot(ok0) | ballot(ok1)) {
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
+                            if ((uint32_t)j >= nt) return;
                             gP0 |= (GP)(uint32_t)rt[j][(ok0 ? dB0 : 0u) >> rsh[j]] << (8 * (j - 1));
                             gP1 |= (GP)(uint32_t)rt[j][(ok1 ? dB1 : 0u) >> rsh[j]] << (8 * (j - 1));
                         };
                         rs_for<2, NT>(load_one);
                         auto test_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
+                            if ((uint32_t)j >= nt) return;
                             ok0 = ok0 & (gbyte(gP0, j) != 0u);
                             ok1 = ok1 & (gbyte(gP1, j) != 0u);
                         };
@@ -602,6 +451,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     rs_for_down<NT, 1>(add_one);
                     return r;
                 };
+                if constexpr (AND) {
+                    if (!hint_first) { // an upload without hints: a non-zero byte is the answer only where an entry is one doc-id
+                        auto nm = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; if (rsh[j] != 0u && (uint32_t)j < nt) need0 |= 1u << j; };
+                        rs_for<1, NT>(nm);
+                        need1 = need0;
+                    }
+                }
                 float r0 = rest_of(gP0, 0), r1 = rest_of(gP1, 0);
                 ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
                 ok1 = ok1 & enters((boB1 + r1) * BOUND_SLACK);
@@ -614,7 +470,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     auto hint_one = [&](auto jc) __attribute__((always_inline)) {
                         constexpr int j = decltype(jc)::value;
                         const uint8_t* const ht = rt[j] + hdelta;
-                        const bool hashint = rsh[j] != 0u; // (one doc-id per entry: the weight byte was the answer)
+                        const bool hashint = rsh[j] != 0u && (uint32_t)j < nt; // (one doc-id per entry: the weight byte was the answer)
                         const uint32_t h0 = (ok0 & hashint) ? (uint32_t)ht[dB0 >> rsh[j]] : 255u, h1 = (ok1 & hashint) ? (uint32_t)ht[dB1 >> rsh[j]] : 255u;
                         LC(PH_MEMBER, lines_of(ht + (dB0 >> rsh[j]), ok0 & hashint, 1u) + lines_of(ht + (dB1 >> rsh[j]), ok1 & hashint, 1u));
                         ok0 = ok0 & ((h0 == 255u) | (h0 == rmh_code(dB0, rsh[j])));
@@ -631,24 +487,40 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     const uint8_t* const arena = rs_args()->arena;
                     // (list 1's rows after its current block go out together with the norm_lens: the search they serve comes first
                     // in the probe below and does not depend on which candidate it is for)
-                    const Rows rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
-                    const float nl0 = ok0 ? norm_lens[dB0] : 1.f, nl1 = ok1 ? norm_lens[dB1] : 1.f;
-                    LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
-                    const uint32_t fB0 = L.stage[bufB][lane], fB1 = L.stage[bufB][lane + 64];
-                    float pa0 = qw0 * doc_term_weight(fB0, nl0), pa1 = qw0 * doc_term_weight(fB1, nl1);
-                    {
-                        const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
-                        s_scored += nv;
-                        s_bytes += 4ull * nv;
+                    // (AND: nothing is scored -- no norm_lens, no freqs -- and list 1 is searched only if somebody needs it: no rows ahead)
+                    Rows rows1{make_uint2(0xFFFFFFFFu, 0u), 0.f};
+                    float nl0 = 1.f, nl1 = 1.f, pa0 = 0.f, pa1 = 0.f;
+                    if constexpr (!AND) {
+                        rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
+                        nl0 = ok0 ? norm_lens[dB0] : 1.f;
+                        nl1 = ok1 ? norm_lens[dB1] : 1.f;
+                        LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
+                        const uint32_t fB0 = L.stage[bufB][lane], fB1 = L.stage[bufB][lane + 64];
+                        pa0 = qw0 * doc_term_weight(fB0, nl0);
+                        pa1 = qw0 * doc_term_weight(fB1, nl1);
+                        {
+                            const uint32_t nv = (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
+                            s_scored += nv;
+                            s_bytes += 4ull * nv;
+                        }
+                        ok0 = ok0 & enters((pa0 + r0) * BOUND_SLACK);
+                        ok1 = ok1 & enters((pa1 + r1) * BOUND_SLACK);
                     }
-                    ok0 = ok0 & enters((pa0 + r0) * BOUND_SLACK);
-                    ok1 = ok1 & enters((pa1 + r1) * BOUND_SLACK);
                     // lists 1 .. NT-1 in order: a candidate moves on only while partial score + what the later lists can add to IT
                     // can still enter the heap
+                    // (up to four lists the body is unrolled per list, the lanes of `cold` are compile-time constants; beyond that it is ONE
+                    // loop body over the lists: unrolled, the 8-list kernel was 80 KB of code -- more than the instruction cache two CUs
+                    // share -- and ran its 77 queries in the time the 5-list kernel ran 338)
                     auto probe = [&](auto jc) __attribute__((always_inline)) {
-                        constexpr int j = decltype(jc)::value;
-                        constexpr int CB = (j - 1) * C_PER; // this list's lanes of `cold`
-                        uint64_t todo0 = ballot(ok0), todo1 = ballot(ok1);
+                        constexpr bool RT = std::is_same<decltype(jc), uint32_t>::value; // run-time list index
+                        const uint32_t j = (uint32_t)jc;
+                        if (j >= nt) return;
+                        const uint32_t CB = (j - 1u) * C_PER; // this list's lanes of `cold`
+                        float rsc_j = 0.f; // rsc[j]: from lane j of rscv where j is a run-time index (an array indexed at run time goes to scratch)
+                        if constexpr (RT) rsc_j = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rscv), (int)j));
+                        else rsc_j = rsc[decltype(jc)::value];
+                        // (AND: only the candidates list j's hint left open are searched; the others are members already)
+                        uint64_t todo0 = AND ? ballot(ok0 & (((need0 >> j) & 1u) != 0u)) : ballot(ok0), todo1 = AND ? ballot(ok1 & (((need1 >> j) & 1u) != 0u)) : ballot(ok1);
                         if (!(todo0 | todo1)) return;
                         const uint32_t nj = cget(CB + C_N), nbj = (nj + 127u) >> 7, bbj = cget(CB + C_BB);
                         const uint32_t vlj = 1u + (nj >= (1u << 7)) + (nj >= (1u << 14)) + (nj >= (1u << 21)) + (nj >= (1u << 28));
@@ -656,9 +528,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         const uint2* const tabj = (const uint2*)rs_args()->skip + bbj;
                         const float* const wtabj = rs_args()->bmw + bbj;
                         const float qwj = __uint_as_float(cget(CB + C_QW));
-                        bool rows_fresh = j == 1; // (rows1 was loaded for from = list 1's current block + 1)
+                        bool rows_fresh = !AND && j == 1; // (rows1 was loaded for from = list 1's current block + 1)
                         const float rj0 = rest_of(gP0, j), rj1 = rest_of(gP1, j); // the lists after j
-                        const float bj0 = rsc[j] * (float)gbyte(gP0, j), bj1 = rsc[j] * (float)gbyte(gP1, j);
+                        const float bj0 = rsc_j * (float)gbyte(gP0, j), bj1 = rsc_j * (float)gbyte(gP1, j);
                         uint32_t* const dj = L.dj[j - 1];
                         uint32_t* const fj = L.fj[j - 1];
                         bool mem0 = false, mem1 = false;
@@ -710,8 +582,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 wave_sync();
                                 curj = fb.blk;
                                 bmj = fb.bmax;
-                                cset(CB + C_CUR, curj);
-                                cset(CB + C_BMAX, bmj);
+                                if constexpr (RT) {
+                                    rs_writelane_at(cold, curj, CB + C_CUR);
+                                    rs_writelane_at(cold, bmj, CB + C_BMAX);
+                                } else {
+                                    cset((decltype(jc)::value - 1) * C_PER + C_CUR, curj);
+                                    cset((decltype(jc)::value - 1) * C_PER + C_BMAX, bmj);
+                                }
                                 ++s_docs_blocks;
                                 ++s_freqs_blocks;
                                 s_bytes += 4 + consD + consF2;
@@ -747,18 +624,33 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             todo0 &= ~ib0;
                             todo1 &= ~ib1;
                             // members take list j's term score at once
-                            if (m0) { pa0 = pa0 + qwj * doc_term_weight(fj[q0], nl0); mem0 = true; }
-                            if (m1) { pa1 = pa1 + qwj * doc_term_weight(fj[q1], nl1); mem1 = true; }
+                            if constexpr (AND) {
+                                mem0 = mem0 | m0;
+                                mem1 = mem1 | m1;
+                            } else {
+                                if (m0) { pa0 = pa0 + qwj * doc_term_weight(fj[q0], nl0); mem0 = true; }
+                                if (m1) { pa1 = pa1 + qwj * doc_term_weight(fj[q1], nl1); mem1 = true; }
+                            }
                         }
                         // members whose score can still enter go on to the next list (a candidate the loop left unsettled -- list j
                         // ended below it -- is not a member)
-                        ok0 = ok0 & mem0 & enters((pa0 + rj0) * BOUND_SLACK);
-                        ok1 = ok1 & mem1 & enters((pa1 + rj1) * BOUND_SLACK);
+                        if constexpr (AND) {
+                            ok0 = ok0 & (mem0 | (((need0 >> j) & 1u) == 0u));
+                            ok1 = ok1 & (mem1 | (((need1 >> j) & 1u) == 0u));
+                        } else {
+                            ok0 = ok0 & mem0 & enters((pa0 + rj0) * BOUND_SLACK);
+                            ok1 = ok1 & mem1 & enters((pa1 + rj1) * BOUND_SLACK);
+                        }
                     };
-                    rs_for<1, NT>(probe);
+                    if constexpr (NT >= RS_ONE_BODY) {
+#pragma nounroll
+                        for (uint32_t j = 1; j < nt; ++j) probe(j);
+                    }
+                    else rs_for<1, NT>(probe);
+                    if constexpr (AND) and_count += (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1))); // documents of the intersection
                     // pa0 / pa1 are complete scores of documents of the intersection now
                     uint32_t inserted = 0;
-                    for (int half = 0; half < 2; ++half) {
+                    for (int half = 0; !AND && half < 2; ++half) {
                         const float sc = half ? pa1 : pa0;
                         uint64_t todo = ballot((half ? ok1 : ok0) & enters(sc));
                         while (todo) {
@@ -824,7 +716,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             unsigned long long* const clk = r->unit_clock;
             if (clk && lane == 0) clk[2ull * uid + 1] = wall_clock64();
         }
-        if (whole) {
+        if constexpr (AND) { // and_query returns the size of the intersection (queries.hpp:85); the parts of a split query are summed by k_merge
+            if (lane == 0) {
+                if (whole) { r->out_count[q] = and_count; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }
+                else { r->unit_count[uid] = and_count; r->unit_freq_sum[uid] = 0; }
+            }
+        } else if (whole) {
             if (lane == 0) { r->out_count[q] = tk.n; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }
             store_topk_rs(r->out_topk, r->out_topk_len, tk.k, q, tk);
         } else {
@@ -854,23 +751,32 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 } // namespace
 
 extern "C" {
-// nt = exact number of distinct terms of every query of the launch (2..8; the planner's DS2I_STREAM_NT_MAX caps it); the caller has checked that the index is
-// block_optpfor with skip table, block weights, range tables and side slots, and that k <= 64
-hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s) {
+// cap = list capacity of the launch (2, 4, 6, 8): every query of it has cap - 1 or cap distinct terms (UnitRec::pad = the count; the
+// planner's DS2I_STREAM_NT_MAX caps it); the caller has checked that the index is block_optpfor with skip table, block weights, range
+// tables and side slots, and that k <= 64
+hipError_t ds2i_launch_ranked_stream(int cap, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
     const dim3 g(grid), b(64);
     const bool st = a.stats != nullptr;
-    switch (nt) {
-    case 2: if (st) hipLaunchKernelGGL((k_ranked_stream<2, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<2, false>), g, b, 0, s, a); break;
-    case 3: if (st) hipLaunchKernelGGL((k_ranked_stream<3, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<3, false>), g, b, 0, s, a); break;
-    case 4: if (st) hipLaunchKernelGGL((k_ranked_stream<4, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<4, false>), g, b, 0, s, a); break;
-    // 5..8: the 5..8-term class (capi_batch.cpp: up to DS2I_STREAM_NT_MAX lists, default 8)
-    case 5: if (st) hipLaunchKernelGGL((k_ranked_stream<5, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<5, false>), g, b, 0, s, a); break;
-    case 6: if (st) hipLaunchKernelGGL((k_ranked_stream<6, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<6, false>), g, b, 0, s, a); break;
-    case 7: if (st) hipLaunchKernelGGL((k_ranked_stream<7, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<7, false>), g, b, 0, s, a); break;
-    case 8: if (st) hipLaunchKernelGGL((k_ranked_stream<8, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<8, false>), g, b, 0, s, a); break;
+#define DS2I_RS_CASE(N) case N: if (st) hipLaunchKernelGGL((k_ranked_stream<N, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false>), g, b, 0, s, a); break;
+    switch (cap) {
+    DS2I_RS_CASE(2) DS2I_RS_CASE(4) DS2I_RS_CASE(6) DS2I_RS_CASE(8)
     default: return hipErrorInvalidValue;
     }
+#undef DS2I_RS_CASE
+    return hipGetLastError();
+}
+// and_query (count only) through the same pipeline (k_ranked_stream<cap, ., AND = true>); same preconditions
+hipError_t ds2i_launch_and_rstream(int cap, const void* args, unsigned grid, hipStream_t s) {
+    const BatchArgs& a = *(const BatchArgs*)args;
+    const dim3 g(grid), b(64);
+    const bool st = a.stats != nullptr;
+#define DS2I_AND_CASE(N) case N: if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, true>), g, b, 0, s, a); break;
+    switch (cap) {
+    DS2I_AND_CASE(2) DS2I_AND_CASE(4) DS2I_AND_CASE(6) DS2I_AND_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef DS2I_AND_CASE
     return hipGetLastError();
 }
 }

@@ -14,7 +14,7 @@ def kernels(asm_text):
     out, cur, name = {}, None, None
     for line in asm_text.splitlines():
         m = re.match(r"^(_Z\w+):", line)
-        if m and ("k_ranked_stream" in m.group(1) or "k_freq_stream" in m.group(1)):
+        if m and any(k in m.group(1) for k in ("k_ranked_stream", "k_freq_stream", "k_and_stream", "k_union_stream")):
             name, cur = m.group(1), []
             out[name] = cur
             continue

@@ -1,15 +1,14 @@
 #!/usr/bin/env python
-"""k_ranked_stream<5..8> (DS2I_STREAM_NT_MAX=8, the default since the end of round 5: the 5..8-term class of a ranked_and batch on
-block_optpfor takes the pipelined stream kernel instead of k_conjunctive<true, true, 8>) against the oracle, bit for bit: random collections, queries of 2..8 distinct terms
-(dense lists among them: non-empty intersections of many lists), k = 1 / 10 / 64, one-shot and pipelined, whole and split queries.
-The knob is read once per process, so this runs as its own process: `DS2I_STREAM_NT_MAX=8 python profiles/probes/rs_nt8_probe.py [seeds]`
-(tests/test_gpu.py::test_ranked_stream_5_to_8_lists_behind_its_knob does that). The oracle is the checker here, nothing else."""
+"""ranked_and through the stream pipeline (k_ranked_stream<cap>, cap = list capacity 2 | 4 | 6 | 8 of a launch group: ranked_stream.hip) against the
+oracle, bit for bit: random collections, queries of 2..8 distinct terms (dense lists among them: non-empty intersections of many lists), k = 1 / 10 /
+64, one-shot and pipelined, whole and split queries. Run as a subprocess by tests/test_gpu.py (the library's knobs are read once per process):
+`[DS2I_STREAM_NT_MAX=n] [DS2I_UNIT_CAP=8] python tests/ranked_stream_probe.py [seeds]`. The oracle is the checker here, nothing else."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ds2i_amd as d  # noqa: E402
 import oracle as o  # noqa: E402
@@ -50,7 +49,8 @@ def one(seed):
         _, ptopk, _ = pipe.wait(t)
         assert np.array_equal(ptopk, otopk), (seed, k, "pipelined")
     pipe.close()
-    want = set(range(2, 9)) if int(os.environ.get("DS2I_STREAM_NT_MAX", "8")) >= 8 else set(range(2, 5))
+    # launch groups by list capacity (2 | 3-4 | 5-6 | 7-8)
+    want = {2, 4, 6, 8} if int(os.environ.get("DS2I_STREAM_NT_MAX", "8")) >= 8 else {2, 4}
     assert streamed == want, (streamed, want)
     nonempty = int((oc > 0).sum())
     print("seed %d: %d docs, %d terms, %d queries (%d with results), stream kernels for %s lists: bit-identical to the oracle" %

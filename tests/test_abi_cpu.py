@@ -94,10 +94,10 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not found")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the three translation units that issue loads by hand: the stream kernels of ranked_and (block_optpfor; block_mixed) and the
-    # freqs stream of or_freq. (minimum kernels, minimum hand-issued loads per kernel)
+    # the four translation units that issue loads by hand: the stream kernels of ranked_and / and (block_optpfor; block_mixed), of
+    # wand / maxscore / ranked_or, and the list streams of or_freq / and. (minimum kernels, minimum hand-issued loads per kernel)
     texts = {}
-    for src, min_kernels, min_dma in (("ranked_stream.hip", 14, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 1, 3)):
+    for src, min_kernels, min_dma in (("ranked_stream.hip", 16, 6), ("union_stream.hip", 8, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 3, 3)):
         out = str(tmp_path / (src + ".s"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
                                "-o", out, os.path.join(root, "ds2i_amd", "csrc", src)], stderr=subprocess.DEVNULL)
@@ -115,28 +115,44 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
                 elif in_asm and re.match(r"(global|buffer|flat)_load", t):
                     assert "_lds_" in t.split()[0], (name, t)
                     dma += 1
-            assert dma >= min_dma, (src, name)
+            # (the AND instantiations of k_ranked_stream have no shared floor word to fetch: one hand-issued load fewer)
+            assert dma >= (min_dma - 1 if re.search(r"k_ranked_streamILi\dELb\dELb1EE", name) else min_dma), (src, name)
             assert asm_audit.audit(lines) == [], (src, name)
     # Register budget of the shipped (uninstrumented block_optpfor) instantiations of k_ranked_stream, from the code-object
-    # metadata of the same listing. Round 5: 6 waves per SIMD for every list count (80 VGPRs); with two lists nothing is spilled
-    # to scratch and the kernel needs no private segment; the scalars the compiler keeps in VGPR lanes (v_writelane /
-    # v_readlane pairs) are held where they are -- VERDICT r4 asked for <= 16, round 4 shipped 120 / 216 / 302.
+    # metadata of the same listing: capacity 2 / 4 at 6 waves per SIMD (80 VGPRs), 6 / 8 at 4 / 3. With two lists nothing is
+    # spilled and the kernel needs no private segment; from capacity 4 on stage C is one loop body over the lists (round 6), which
+    # took the scalars the compiler parks in VGPR lanes from 124 / 214 (3 / 4 lists, round 5) to 105 and from 256 .. 417 (5 .. 8
+    # lists) to 143 / 178; capacity 4 still spills 11 VGPRs at its 80-register budget.
     text = texts["ranked_stream.hip"]
     meta = {}
     for blk in re.split(r"\n  - \.agpr_count:", text)[1:]:
         nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
         meta[nm] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "private_segment_fixed_size")}
-    # (5..8 lists -- DS2I_STREAM_NT_MAX, off by default -- at 4 / 4 / 4 / 3 waves per SIMD: nothing in scratch either)
-    budget = {2: (80, 0, 0, 64), 3: (80, 8, 32, 130), 4: (80, 16, 64, 220), 5: (128, 0, 0, 300), 6: (128, 0, 0, 330), 7: (128, 0, 0, 460), 8: (168, 0, 0, 460)}
+    budget = {2: (80, 0, 0, 64), 4: (80, 12, 48, 110), 6: (128, 0, 0, 150), 8: (168, 0, 0, 190)}
     seen = 0
     for nm, m in meta.items():
-        mm = re.search(r"k_ranked_streamILi(\d)ELb0EE", nm)
+        mm = re.search(r"k_ranked_streamILi(\d)ELb0ELb0EE", nm)  # (capacity, STATS = false, AND = false: the shipped ranked_and instantiations)
         if not mm:
             continue
         seen += 1
         vg, vs, ps, ss = budget[int(mm.group(1))]
         assert m["vgpr_count"] <= vg and m["vgpr_spill_count"] <= vs and m["private_segment_fixed_size"] <= ps and m["sgpr_spill_count"] <= ss, (nm, m)
-    assert seen == 7
+    assert seen == 4
+    # ... and of k_union_stream (wand / maxscore / ranked_or): nothing in scratch beyond one register of capacity 4
+    umeta = {}
+    for blk in re.split(r"\n  - \.agpr_count:", texts["union_stream.hip"])[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        umeta[nm] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "private_segment_fixed_size")}
+    ubudget = {2: (80, 0, 0, 64), 4: (96, 2, 8, 140), 6: (128, 0, 0, 200), 8: (168, 0, 0, 270)}
+    seen = 0
+    for nm, m in umeta.items():
+        mm = re.search(r"k_union_streamILi(\d)ELb0EE", nm)
+        if not mm:
+            continue
+        seen += 1
+        vg, vs, ps, ss = ubudget[int(mm.group(1))]
+        assert m["vgpr_count"] <= vg and m["vgpr_spill_count"] <= vs and m["private_segment_fixed_size"] <= ps and m["sgpr_spill_count"] <= ss, (nm, m)
+    assert seen == 4
 
 
 def test_documented_knobs_exist_in_the_source():

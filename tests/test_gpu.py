@@ -1182,9 +1182,26 @@ def test_ranked_stream_5_to_8_lists_behind_its_knob(built_lib, extra):
     if extra:
         k, v = extra.split("=")
         env[k] = v
-    r = subprocess.run([sys.executable, os.path.join(root, "profiles", "probes", "rs_nt8_probe.py"), "1", "2", "3"], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "ranked_stream_probe.py"), "1", "2", "3"], env=env, capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "rs_nt8_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8", "DS2I_NO_RMH=1", "DS2I_RMW_G=1", "DS2I_NO_AND_RSTREAM=1"])
+def test_and_through_the_stream_pipeline(built_lib, extra):
+    """and_query (queries.hpp:35-86) counts through k_ranked_stream<n, ., AND> (the default for `and` batches that do not ask for the
+    doc-id lists): candidates whose membership hints settle every other list are counted without a search or a decode of those lists;
+    one-term queries are list streams (k_and_stream). Counts equal the oracle's -- whole and split queries, an upload without hints
+    (every survivor probed), coarse tables (ranges too wide for the hint to be proof), and the class kernels behind DS2I_NO_AND_RSTREAM."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if extra:
+        k, v = extra.split("=")
+        env[k] = v
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "and_stream_probe.py"), "1", "2", "3"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "and_rstream_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_bench_two_ranks_on_one_device(built_lib):

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""wand / maxscore / ranked_or through the stream pipeline (k_union_stream<n>, n = 2..8 lists: union_stream.hip) against the oracle's
+reference-order traversals (queries.hpp:200-319, 404-476, 478-591): random collections -- short and long lists paired (ranges wider than
+128 doc-ids: an exclusion list's hint is no proof there), dense lists (one doc-id per table entry), clustered lists (several postings per
+range: hint 255) -- queries of 2..8 terms anywhere in the vocabulary, among the densest lists, among the shortest; k = 10 and a k larger
+than most unions. Checked: top-k lengths equal, scores within 1e-5 relative of the oracle's, wand == maxscore == ranked_or bit for bit,
+the pipelined ABI gives the same bits. Run as a subprocess by tests/test_gpu.py (the library's knobs are read once per process):
+`[DS2I_NO_RMH=1 | DS2I_RMW_G=1 | DS2I_NO_UNION_RSTREAM=1] python tests/union_stream_probe.py [seeds]`. The oracle is the checker, nothing else."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ds2i_amd as d  # noqa: E402
+import oracle as o  # noqa: E402
+
+
+def one(seed):
+    rng = np.random.default_rng(7000 + seed)
+    nd = int(rng.integers(20000, 600000))
+    nt = int(rng.integers(30, 160))
+    p = d.SynthParams(seed=0xB2D00000 + seed, num_docs=nd, num_terms=nt, zipf_exp=float(rng.uniform(0.3, 1.1)),
+                      top_df_frac=float(rng.uniform(0.2, 0.95)), min_len=int(rng.integers(1, 300)), clustered_every=int(rng.integers(0, 4)))
+    lists = [d.synth_list(p, t) for t in range(nt)]
+    sizes = d.synth_doc_sizes(p)
+    wand = d.build_wand(sizes, lists)
+    qs = []
+    for n in range(2, 9):
+        qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(24)]   # anywhere in the vocabulary: short lists among them
+        qs += [[int(x) for x in rng.permutation(min(nt, 14))[:n]] for _ in range(24)]              # the densest lists
+        qs += [[int(x) for x in rng.permutation(nt)[-min(nt, 20):][:n]] for _ in range(12)]        # only short lists (wide ranges)
+    qs += [[0, nt - 1], [nt - 1, nt - 2], [0, 1], list(range(8)), [5, 5, 9], [2]]
+    img = d.build_index("block_optpfor", nd, lists)
+    gidx = d.Index("block_optpfor", img, wand)
+    oidx = o.Index("block_optpfor", img, wand)
+    streamed = set()
+    for k in (10, 37):
+        _, otopk, olen, _, _ = oidx.query_batch("wand", qs, k=k)
+        got = {}
+        for op in ("wand", "maxscore", "ranked_or"):
+            b = d.Batch(gidx, op, qs, k=k)
+            b.run()
+            _, topk, tlen, _ = b.fetch()
+            for c in range(3):
+                streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
+            b.close()
+            assert np.array_equal(tlen, olen), (seed, op, k, np.argwhere(tlen != olen)[:5])
+            f = np.isfinite(otopk)
+            np.testing.assert_allclose(topk[f], otopk[f], rtol=1e-5, err_msg="seed %d %s k %d" % (seed, op, k))
+            got[op] = topk
+        assert np.array_equal(got["wand"], got["maxscore"], equal_nan=True) and np.array_equal(got["wand"], got["ranked_or"], equal_nan=True), (seed, k)
+        pipe = d.Pipeline(gidx, depth=2)
+        t = pipe.submit("wand", qs, k=k)
+        _, ptopk, plen = pipe.wait(t)
+        pipe.close()
+        assert np.array_equal(plen, olen) and np.array_equal(ptopk, got["wand"], equal_nan=True), (seed, k, "pipelined")
+    if not os.environ.get("DS2I_NO_UNION_RSTREAM"):
+        assert streamed, "the stream kernel did not run"
+    print("seed %d: %d docs, %d terms, %d queries, stream groups for %s lists: wand == maxscore == ranked_or, all within 1e-5 of the oracle" %
+          (seed, nd, nt, len(qs), sorted(streamed)))
+
+
+if __name__ == "__main__":
+    for s in ([int(x) for x in sys.argv[1:]] or [1, 2, 3, 4]):
+        one(s)
+    print("union_stream_probe ok")
