@@ -212,6 +212,9 @@ def main():
     steady = gaps[args.depth:] if len(gaps) > 2 * args.depth else gaps
     step_spread = {"min": 1e3 * float(steady.min()), "median": 1e3 * float(np.median(steady)), "max": 1e3 * float(steady.max()),
                    "n": int(len(steady))}
+    # 95 % interval of the mean step time from the same intervals (normal approximation; the batches are distinct, so the spread is
+    # the workload's as much as the machine's), carried over to `value` as a relative +-
+    rel_ci = float(1.96 * steady.std(ddof=1) / np.sqrt(len(steady)) / steady.mean()) if len(steady) > 2 else None
 
     # ---- untimed extras: kernel-resident rate (one prepared batch re-run, round-1's figure) and the instrumented pass
     batch = d.Batch(idx, args.op, my_queries[args.warmup], k=args.k)
@@ -276,6 +279,8 @@ def main():
     out = {
         "metric": "queries/sec (%s, %s)" % (args.op, args.codec), "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "value_ci95": ({"rel": rel_ci, "low": qps / (1.0 + rel_ci), "high": qps / max(1e-9, 1.0 - rel_ci),
+                        "note": "95 %% interval of the mean step time over %d completion intervals of the timed region" % len(steady)} if rel_ci is not None else None),
         "mean_us_per_query": 1e6 / qps, "step_ms_spread": step_spread,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
         "timing": "end-to-end over %d distinct batches through ds2i_hip_pipeline_submit/wait (host planning + H2D + kernels + D2H), "
@@ -414,6 +419,8 @@ def main():
             return ("k_union<%s> (<=%d lists)" if stream else "k_disjunctive<TMAX=%d> (%s)") % (
                 ("true" if args.op == "or_freq" else "false", (2, 4, 8, 16)[c]) if stream else ((2, 4, 8, 16)[c], args.op))
         stream = not any(os.environ.get(e) for e in ("DS2I_NO_TOPK_STREAM", "DS2I_NO_BMW_PRUNE", "DS2I_NO_RMW_USE", "DS2I_NO_RMW"))
+        if stream and not os.environ.get("DS2I_NO_UNION_RSTREAM") and not os.environ.get("DS2I_NO_XSLOTS"):  # (every index kind is queried as block_optpfor + side tables by default)
+            return "k_union_stream, class of <=%d lists (%s)" % ((2, 4, 8, 16)[c], args.op)
         return ("k_union_topk<TMAX=%d> (%s)" if stream else "k_disjunctive<TMAX=%d> (%s)") % ((2, 4, 8, 16)[c], args.op)
     per_class = []
     for c in range(NCLS):
@@ -431,7 +438,12 @@ def main():
     # ... and per KERNEL: a class stream runs its launch groups back to back, each timed with its own pair of hipEvents on
     # that stream (ds2i_hip_pipeline_class_groups); rocprofv3 --kernel-trace --stats reports the same kernels by name
     def group_kernel_name(c, lists, pipelined):
-        return "k_ranked_stream<%d>" % lists if pipelined else kernel_name(c)
+        # `lists` of a pipelined group = the list CAPACITY of its instantiation (2 | 4 | 6 | 8 (| 16): it holds the queries of cap - 1 and cap lists)
+        if not pipelined:
+            return kernel_name(c)
+        if args.op in ("wand", "maxscore", "ranked_or"):
+            return "k_union_stream<%d>" % lists
+        return "k_ranked_stream<%d%s>" % (lists, ",AND" if args.op == "and" else "")
     per_kernel = []
     for key, (tot, n) in sorted(timed_grp_ms.items()):
         c, lists, pipelined = key
@@ -479,7 +491,11 @@ def main():
     traffic_src = None
     traffic_step = None
     tjson = {}
-    tj = args.traffic_json or os.path.join(ROOT, "profiles", "r05_traffic_%s_%s.json" % (wl, args.op))
+    tj = args.traffic_json
+    for rnd in ("r06", "r05"):  # the newest committed counter pass of this workload / operator
+        if not tj and os.path.exists(os.path.join(ROOT, "profiles", "%s_traffic_%s_%s.json" % (rnd, wl, args.op))):
+            tj = os.path.join(ROOT, "profiles", "%s_traffic_%s_%s.json" % (rnd, wl, args.op))
+    tj = tj or ""
     if os.path.exists(tj) and args.codec == "block_optpfor":
         tjson = json.load(open(tj))
         name = dom_k["kernel"] if dom_k else kernel_name(dom)
@@ -508,6 +524,11 @@ def main():
     # the class kernels of a batch (and of the neighbouring batches) overlap, so one kernel's launch duration stretches
     # when another class is given more of the GPU; the whole step is the figure that cannot: every class's algorithmic
     # bytes over the wall time of a step
+    # what the kernels' OWN (pruned) traversal decodes per step, priced like A_skip (device-counted, the instrumented pass), and --
+    # when a counter pass is committed -- how many bytes of 128-byte lines the fabric moved per byte of it
+    own = int(sum(cls_stats[c][0].algorithmic_bytes for c in range(NCLS)))
+    out["roofline"]["own_traversal_bytes_per_step"] = own
+    out["roofline"]["lines_per_useful_byte"] = (traffic_step / own) if (traffic_step and own) else None
     if out.get("a_skip_bytes_per_step"):
         out["roofline"]["step_algorithmic_bytes"] = int(out["a_skip_bytes_per_step"])
         out["roofline"]["step_achieved"] = out["a_skip_bytes_per_step"] / (out["ms_per_step"] * 1e-3) / 1e9

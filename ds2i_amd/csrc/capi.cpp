@@ -274,18 +274,25 @@ static uint64_t range_table_bytes_at(const ds2i_hip_index* x, double G) {
 // (profiles/r05_table_budget.txt), the first configuration whose resident bytes stay under it: whole structures are dropped or
 // the tables' granularity halved -- there is no per-list choice (a list either has every structure the index has or none does).
 // A knob set explicitly (DS2I_RMW_G, DS2I_NO_RMH, DS2I_NO_XSLOTS) is not overridden. Reported by ds2i_hip_index_get_info.
+// DS2I_TABLE_BUDGET in bytes ("<bytes>" or "<factor>x" of the CALLER's image -- for a transcoded upload the image handed to
+// ds2i_hip_index_open, not its re-encoded form), 0 = none
+static uint64_t table_budget_bytes(size_t image_bytes) {
+    const char* eb = std::getenv("DS2I_TABLE_BUDGET");
+    if (!eb || !*eb) return 0;
+    char* end = nullptr;
+    const double v = std::strtod(eb, &end);
+    if (!(v > 0)) return 0;
+    return (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
+}
 static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
     const char* gs = std::getenv("DS2I_RMW_G");
     x->plan_g = gs ? std::atof(gs) : 4.0;
     if (!(x->plan_g > 0) || std::getenv("DS2I_NO_RMW")) x->plan_g = 0;
     x->plan_hints = !std::getenv("DS2I_NO_RMH");
     x->plan_slots = !std::getenv("DS2I_NO_XSLOTS") && x->kind == DS2I_BLOCK_OPTPFOR;
-    const char* eb = std::getenv("DS2I_TABLE_BUDGET");
-    if (!eb || !*eb) return;
-    char* end = nullptr;
-    const double v = std::strtod(eb, &end);
-    if (!(v > 0)) return;
-    x->table_budget = (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
+    x->table_budget = table_budget_bytes(image_bytes);
+    if (!x->table_budget) return;
+    const bool g_pinned = gs != nullptr || std::getenv("DS2I_NO_RMW") != nullptr; // (an explicit knob pins the granularity: DS2I_NO_RMW = none)
     // resident whatever is chosen: the image and its skip table (counted in extra_bytes by now), block weights (4 B per block), norm_lens
     const uint64_t base = x->arena_bytes + x->extra_bytes + 4ull * x->total_blocks + (x->has_wand ? 4 * x->num_docs : 0);
     // side tables = a slot per block + the lists' partial last blocks in plain form + the overflow area at its first-attempt size
@@ -306,7 +313,7 @@ static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
     static const Plan order[] = {{4, true, true}, {2, true, true}, {4, false, true}, {2, false, true}, {1, true, true}, {1, false, true},
                                  {2, false, false}, {1, false, false}, {0, false, false}};
     for (const Plan& c : order) {
-        if (gs && c.g != x->plan_g) continue;
+        if (g_pinned && c.g != x->plan_g) continue;
         if (std::getenv("DS2I_NO_RMH") && c.hints) continue;
         if ((std::getenv("DS2I_NO_XSLOTS") || !slots) && c.slots) continue;
         const uint64_t tables = c.g > 0 ? range_table_bytes_at(x, c.g) : 0;
@@ -320,6 +327,9 @@ static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
             return;
         }
     }
+    // no candidate matches the pinned knobs (e.g. DS2I_RMW_G outside {4, 2, 1}): the knobs win, the budget is not enforced -- and says so
+    std::fprintf(stderr, "ds2i_hip: DS2I_TABLE_BUDGET %.2f GB is not enforced: no table plan matches the pinned knobs (DS2I_RMW_G = %g)\n", x->table_budget / 1e9, x->plan_g);
+    x->table_budget = 0;
 }
 
 // block_optpfor: the exception side slots, their overflow area and the tail table (abi_structs.hpp, BatchArgs::xslots).
@@ -425,11 +435,11 @@ static std::atomic<bool> g_ds2i_upload_options_frozen{false};
 namespace {
 const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET",
                                     "DS2I_STREAM_SETS", "DS2I_CLASS_PRIORITY"};
-const char* const kBatchKnobs[] = {"DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
+const char* const kBatchKnobs[] = {"DS2I_AND_UNIT_BLOCKS", "DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
                                    "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_AND_RSTREAM", "DS2I_NO_AND_STREAM", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
                                    "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_RSTREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
                                    "DS2I_SEED_STREAM", "DS2I_SEED_TERMS", "DS2I_STREAM_NT_MAX", "DS2I_UNIT_CAP", "DS2I_UNIT_CLOCK", "DS2I_UNIT_DIV", "DS2I_UNIT_DIV_MANY", "DS2I_UNIT_DIV_RMW",
-                                   "DS2I_UNIT_FACTOR", "DS2I_UNIT_FLOOR", "DS2I_UT_BLOCKS", "DS2I_UT_DIV_MANY", "DS2I_UT_FIRST"};
+                                   "DS2I_UNIT_FACTOR", "DS2I_UNIT_FLOOR", "DS2I_UT_BLOCKS", "DS2I_UT_DIV_MANY", "DS2I_UT_FIRST", "DS2I_UT_WARM"};
 }
 
 int ds2i_hip_set_option(const char* name, const char* value) {
@@ -454,7 +464,7 @@ int ds2i_hip_device_count(void) {
 }
 
 static int index_open_impl(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, bool bare,
-                           ds2i_hip_index** out);
+                           ds2i_hip_index** out, size_t budget_base_bytes = 0);
 
 // block_mixed, the default upload: the image is TRANSCODED to the block codec this device decodes fastest. The mixed
 // image is uploaded bare (no tables), every list decoded by the mixed-block kernels (mixed_block.hpp:198-217: OptPFor /
@@ -482,33 +492,58 @@ static int index_open_transcoded(int device, int kind, const void* index_image, 
         offs[t + 1] = offs[t] + raw->list_n[t];
         longest = std::max(longest, raw->list_n[t]);
     }
+    // Transcoding is a choice, not an obligation: what a transcoded index needs at the very least -- ~2 bytes per posting of
+    // block_optpfor image, a side slot per block, its skip table and block weights -- is several times a partitioned Elias-Fano image.
+    // Under a DS2I_TABLE_BUDGET it does not fit, or when the host cannot hold the decoded postings (8 bytes each), the image is
+    // uploaded AS IT IS and queried by its own kernels (DS2I_PEF_NATIVE / DS2I_MIXED_NATIVE behaviour), with the tables the budget allows.
+    auto native = [&](const char* why) {
+        std::fprintf(stderr, "ds2i_hip: %s: the %s image is uploaded as it is (native kernels)\n", why, kind == DS2I_BLOCK_MIXED ? "block_mixed" : "freq_index");
+        guard.reset();
+        return index_open_impl(device, kind, index_image, index_bytes, wand_image, wand_bytes, false, out);
+    };
+    const uint64_t budget = table_budget_bytes(index_bytes);
+    const uint64_t least = 2 * offs[V] + (4ull * ds2i_dev::XSLOT_DW + 8 + 4) * ((offs[V] + 127) / 128) + 4 * raw->num_docs;
+    if (budget && least > budget) return native("DS2I_TABLE_BUDGET is below what a transcoded index needs");
     std::vector<uint32_t> docs, freqs;
     try {
         docs.resize(offs[V]);
         freqs.resize(offs[V]);
     } catch (std::bad_alloc const&) {
-        return ds2i_set_error(DS2I_ENOMEM, "out of host memory transcoding the index to block_optpfor (DS2I_MIXED_NATIVE=1 / DS2I_PEF_NATIVE=1 upload it as it is)");
+        std::vector<uint32_t>().swap(docs);
+        return native("not enough host memory to hold the decoded postings");
     }
     {
+        // lists are decoded a CHUNK at a time: every list of the chunk by a launch of its own into its place in two device buffers
+        // (no host synchronisation in between), then one copy per buffer -- not a launch, two copies and a synchronisation per list
+        // (a collection has millions of lists, most of them a few postings long)
         DevTemps tmp;
         uint32_t *d_docs = nullptr, *d_freqs = nullptr;
-        HIP_OK(tmp.alloc(&d_docs, 4 * ((size_t)longest + 128)));
-        HIP_OK(tmp.alloc(&d_freqs, 4 * ((size_t)longest + 128)));
-        for (uint64_t t = 0; t < V; ++t) {
-            DecodeArgs a{};
-            a.arena = raw->d_arena;
-            a.bits0 = raw->d_bits0;
-            a.bits1 = raw->d_bits1;
-            a.skip = raw->d_skip;
-            a.term = ds2i_make_qterm(raw, (uint32_t)t);
-            a.codec = kind >= DS2I_OPT ? (int)DS2I_OPT : kind; // (every freq_index layout decodes through the chunk directory)
-            a.num_docs = (uint32_t)raw->num_docs;
-            a.out_docs = d_docs;
-            a.out_freqs = d_freqs;
-            HIP_OK(ds2i_launch_decode_list(&a, (unsigned)std::min<uint64_t>(raw->list_nb[t], uint64_t(raw->num_cus) * 16), raw->stream[0]));
-            HIP_OK(hipMemcpyAsync(docs.data() + offs[t], d_docs, 4 * (size_t)raw->list_n[t], hipMemcpyDeviceToHost, raw->stream[0]));
-            HIP_OK(hipMemcpyAsync(freqs.data() + offs[t], d_freqs, 4 * (size_t)raw->list_n[t], hipMemcpyDeviceToHost, raw->stream[0]));
-            HIP_OK(hipStreamSynchronize(raw->stream[0])); // (the two device buffers are reused by the next list)
+        const uint64_t chunk_cap = std::max<uint64_t>((uint64_t)longest + 128, 64ull << 20); // postings per chunk (256 MB per buffer)
+        if (tmp.alloc(&d_docs, 4 * (size_t)chunk_cap) != hipSuccess || tmp.alloc(&d_freqs, 4 * (size_t)chunk_cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return native("not enough device memory for the decode buffers");
+        }
+        for (uint64_t t0 = 0; t0 < V;) {
+            uint64_t t1 = t0, fill = 0;
+            while (t1 < V && fill + raw->list_n[t1] + 128 <= chunk_cap) { // (+128: the decode kernels write whole blocks)
+                DecodeArgs a{};
+                a.arena = raw->d_arena;
+                a.bits0 = raw->d_bits0;
+                a.bits1 = raw->d_bits1;
+                a.skip = raw->d_skip;
+                a.term = ds2i_make_qterm(raw, (uint32_t)t1);
+                a.codec = kind >= DS2I_OPT ? (int)DS2I_OPT : kind; // (every freq_index layout decodes through the chunk directory)
+                a.num_docs = (uint32_t)raw->num_docs;
+                a.out_docs = d_docs + fill;
+                a.out_freqs = d_freqs + fill;
+                HIP_OK(ds2i_launch_decode_list(&a, (unsigned)std::min<uint64_t>(raw->list_nb[t1], uint64_t(raw->num_cus) * 16), raw->stream[0]));
+                fill += raw->list_n[t1];
+                ++t1;
+            }
+            HIP_OK(hipMemcpyAsync(docs.data() + offs[t0], d_docs, 4 * (size_t)fill, hipMemcpyDeviceToHost, raw->stream[0]));
+            HIP_OK(hipMemcpyAsync(freqs.data() + offs[t0], d_freqs, 4 * (size_t)fill, hipMemcpyDeviceToHost, raw->stream[0]));
+            HIP_OK(hipStreamSynchronize(raw->stream[0])); // (the two device buffers are reused by the next chunk)
+            t0 = t1;
         }
     }
     const uint64_t num_docs = raw->num_docs;
@@ -518,7 +553,7 @@ static int index_open_transcoded(int device, int kind, const void* index_image, 
     if (rc) return rc;
     std::vector<uint32_t>().swap(docs);
     std::vector<uint32_t>().swap(freqs);
-    rc = index_open_impl(device, DS2I_BLOCK_OPTPFOR, ds2i_blob_data(img), ds2i_blob_size(img), wand_image, wand_bytes, false, out);
+    rc = index_open_impl(device, DS2I_BLOCK_OPTPFOR, ds2i_blob_data(img), ds2i_blob_size(img), wand_image, wand_bytes, false, out, index_bytes);
     ds2i_blob_free(img);
     if (rc == DS2I_OK) (*out)->kind_on_disk = kind;
     return rc;
@@ -538,7 +573,7 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
 }
 
 static int index_open_impl(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image, size_t wand_bytes, bool bare,
-                           ds2i_hip_index** out) {
+                           ds2i_hip_index** out, size_t budget_base_bytes) {
     if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
     if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_UNIFORM)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
@@ -741,7 +776,8 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));
-    choose_table_plan(x.get(), index_bytes);
+    if (!bare) choose_table_plan(x.get(), budget_base_bytes ? budget_base_bytes : index_bytes);
+    else x->plan_g = 0, x->plan_hints = x->plan_slots = false;
     if (!bare && x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;

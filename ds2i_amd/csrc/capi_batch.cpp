@@ -176,6 +176,8 @@ struct ds2i_hip_batch {
     std::vector<QTerm> vterms;
     std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
     bool union_stream = false;
+    std::vector<uint8_t> warm_flag;
+    std::vector<uint32_t> warm_units; // DS2I_UT_WARM: units launched ahead of their query's other units
     bool union_rstream = false;   // ... and some class of it runs k_union_stream (union_stream.hip): unit records + the floor words
     // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
     // depend on the union -- by a stream of their own after the merge (freq_stream.hip)
@@ -189,7 +191,7 @@ struct ds2i_hip_batch {
     uint32_t nunits = 0, nsplit = 0, nsingle = 0, long_terms = 0;
     // ---- one upload block (pinned mirror h_up -> d_up), byte offsets
     size_t o_vinfo = 0;
-    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[3] = {}, o_qterm_q = 0, o_sterms = 0,
+    size_t o_qterms = 0, o_qoff = 0, o_units = 0, o_q_unit_off = 0, o_split = 0, o_single = 0, o_hslot = 0, o_order[NCLS] = {}, o_urec[4] = {}, o_qterm_q = 0, o_sterms = 0,
            o_match_off = 0, up_bytes = 0;
     // ---- one result block (d_out -> pinned mirror h_out)
     size_t o_count = 0, o_topk = 0, o_topk_len = 0, o_freq_sum = 0, out_bytes = 0;
@@ -504,9 +506,14 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
                              idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !no_and_stream;
     const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps && !std::getenv("DS2I_NO_BITMAP_USE") && !std::getenv("DS2I_NO_RMW_USE");
+    static const char* aub = std::getenv("DS2I_AND_UNIT_BLOCKS");
+    static const uint32_t and_unit_blocks = aub && std::atoi(aub) > 0 ? (uint32_t)std::atoi(aub) : 96u;
+    const bool and_rs_units = base_op == DS2I_OP_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
+                              idx->d_bmw && idx->d_rmw && !tables_off && !std::getenv("DS2I_NO_AND_RSTREAM") && !std::getenv("DS2I_NO_RANKED_STREAM") && !std::getenv("DS2I_NO_SKIPTAB");
     b->sterms.clear();
     b->sterm_longest = 0;
     b->union_rstream = false;
+    b->warm_units.clear();
     static const bool no_freq_stream = std::getenv("DS2I_NO_FREQ_STREAM") != nullptr;
     b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
                      idx->d_skip && !no_freq_stream && !std::getenv("DS2I_NO_UNION_STREAM");
@@ -514,7 +521,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     b->voff.assign(1, 0);
     b->vinfo.clear();
     static const char* utb = std::getenv("DS2I_UT_BLOCKS");
-    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 160u; // blocks of the driving list per unit (re-measured with the membership hints: 96: 335 k, 128-256: 345-352 k, 384: 335 k queries/s)
+    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 320u; // blocks of the driving list per unit (k_union_topk, round 4: 96: 335 k, 128-256: 345-352 k, 384: 335 k queries/s; k_union_stream, round 6: 64: 240 k, 160: 378 k, 320: 401 k)
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
         u.q = q;
@@ -608,6 +615,10 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 static const uint32_t cap_env = uc && std::atoi(uc) > 0 ? (uint32_t)std::atoi(uc) : 0u;
                 if (cap_env) parts = std::max(parts, (nb0 + (c == 0 ? cap_env : std::max(8u, cap_env / 2)) - 1) / (c == 0 ? cap_env : std::max(8u, cap_env / 2)));
             }
+            // `and` through the stream pipeline has no heap to warm up -- a part costs its blocks and nothing else -- and a two-list query
+            // left whole was a single wave for up to 13 ms (DS2I_UNIT_CLOCK: class 0 = 487 units, median 4.9 ms, 229 waves busy on
+            // average, the span of the whole batch): at most DS2I_AND_UNIT_BLOCKS (96) blocks of the shortest list per unit
+            if (and_rs_units && split_ok && nt > 1 && nt <= 8) parts = std::max(parts, (nb0 + and_unit_blocks - 1) / and_unit_blocks);
             const uint32_t per = (nb0 + parts - 1) / parts;
             parts = (nb0 + per - 1) / per;
             if (parts > 1) b->split_queries.push_back(q);
@@ -666,20 +677,19 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 static const char* utm = std::getenv("DS2I_UT_DIV_MANY");
                 static const uint32_t ut_div_many = utm && std::atoi(utm) > 0 ? (uint32_t)std::atoi(utm) : 4u;
                 uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / ut_div_many) : ut_blocks;
-                if (!utb && c <= 2) {
-                    // What a block of a driving list costs falls steeply with e -- the first lists of the order meet a low threshold and
-                    // several optional lists (every candidate asks every table, many are looked up), the later ones are mostly skipped by
-                    // their table window: measured wave time per owned block (DS2I_UNIT_CLOCK, GOV2-scale wand batch), by class and e --
-                    // 2 lists: 3.1 / 0.1 us; 3-4 lists: 6.1 / 0.4 / 0.1; 5-8 lists: 11.8 / 5.6 / 1.6 / 0.6 / 0.4 / 0.1. Cut at 160 blocks
-                    // whatever e, the e = 0 units of the many-list classes ran 3-4 ms each and WERE their launch's span (1 165 of ~3 500
-                    // wave slots busy on average), while the late lists' units paid a unit's start-up for 20 us of work. Units of about
-                    // equal time instead (DS2I_UT_BLOCKS pins one size for every list: A/B).
-                    static const float us_per_block[3][4] = {{3.1f, 0.15f, 0.15f, 0.15f}, {6.1f, 0.4f, 0.15f, 0.15f}, {11.8f, 5.6f, 1.6f, 0.5f}};
-                    const float target_us = 400.f;
-                    utb_c = (uint32_t)std::min(640.f, std::max(16.f, target_us / us_per_block[c][std::min(e, 3u)]));
+                // DS2I_UT_WARM=n (experiment): the first n blocks of a query's first driving list are a unit of their own, launched AHEAD of
+                // the query's other units (a launch group of its own at the head of the class stream), so that those start with a floor
+                static const char* utw = std::getenv("DS2I_UT_WARM");
+                static const uint32_t ut_warm = utw && std::atoi(utw) > 0 ? (uint32_t)std::atoi(utw) : 0u;
+                uint32_t lo0 = 0;
+                if (ut_warm && e == 0 && nbe > ut_warm && c <= 3) {
+                    b->warm_units.push_back((uint32_t)b->units.size());
+                    add_unit(c, vq, 0, ut_warm, 0, 1.0e9);
+                    lo0 = ut_warm;
                 }
-                const uint32_t parts_e = (nbe + utb_c - 1) / utb_c, per = (nbe + parts_e - 1) / parts_e;
-                for (uint32_t lo = 0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
+                const uint32_t nrest = nbe - lo0;
+                const uint32_t parts_e = (nrest + utb_c - 1) / utb_c, per = (nrest + parts_e - 1) / parts_e;
+                for (uint32_t lo = lo0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
                     add_unit(c, vq, lo, std::min(nbe, lo + per), 0, (double)(nt - e) * 1.0e7 + (double)(std::min(nbe, lo + per) - lo));
             }
             const uint32_t total = (uint32_t)(b->units.size() - first_unit);
@@ -740,7 +750,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             // exactly their list count (union_stream.hip), one launch group per count, back to back on the class stream -- as ranked_and
             // does (below); everything else (other codecs, 9-16 lists, the empty query's unit): k_union_topk, static LDS, one launch per class
             static const bool no_us = std::getenv("DS2I_NO_UNION_RSTREAM") != nullptr;
-            const bool us_ok = !no_us && c <= 2 && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw;
+            const bool us_ok = !no_us && c <= 3 && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw;
             b->union_rstream = b->union_rstream || us_ok;
             if (!us_ok) {
                 b->sub[c].push_back({0u, b->ncls[c], cls_lists});
@@ -748,23 +758,28 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             }
             // (list CAPACITIES 2 | 4 | 6 | 8: a launch group holds the virtual queries of cap - 1 and cap lists -- four groups and four tails
             // per batch instead of seven; inside a group the units stay in cost order)
-            auto cap_of = [&](uint32_t uid) { const uint32_t vq = b->units[uid].q, n = b->voff[vq + 1] - b->voff[vq]; return n < 2 ? 0u : n > 8 ? DS2I_HIP_MAX_TERMS + 1u : (n + 1u) & ~1u; };
+            std::vector<uint8_t>& warm = b->warm_flag;
+            warm.assign(b->units.size(), 0);
+            for (uint32_t uid : b->warm_units) warm[uid] = 1;
+            constexpr uint32_t KW = DS2I_HIP_MAX_TERMS + 2; // (warm groups: key + KW, ahead of every main group)
+            auto cap_of = [&](uint32_t uid) { const uint32_t vq = b->units[uid].q, n = b->voff[vq + 1] - b->voff[vq]; return n < 2 ? 0u : n > DS2I_HIP_MAX_TERMS ? DS2I_HIP_MAX_TERMS + 1u : n > 8 ? (uint32_t)DS2I_HIP_MAX_TERMS : (n + 1u) & ~1u; };
+            auto key_of = [&](uint32_t uid) { return cap_of(uid) + (warm[uid] ? KW : 0u); };
             {   // stable partition by capacity, largest first
-                uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
-                for (uint32_t uid : b->order[c]) ++cnt[cap_of(uid)];
-                uint32_t start[DS2I_HIP_MAX_TERMS + 2], acc = 0;
-                for (int n = DS2I_HIP_MAX_TERMS + 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
+                uint32_t cnt[2 * KW] = {};
+                for (uint32_t uid : b->order[c]) ++cnt[key_of(uid)];
+                uint32_t start[2 * KW], acc = 0;
+                for (int n = 2 * KW - 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
                 std::vector<uint32_t>& tmp = b->scratch_u32;
                 tmp.resize(b->order[c].size());
-                for (uint32_t uid : b->order[c]) tmp[start[cap_of(uid)]++] = uid;
+                for (uint32_t uid : b->order[c]) tmp[start[key_of(uid)]++] = uid;
                 b->order[c].swap(tmp);
             }
             for (uint32_t i = 0; i < b->ncls[c];) {
                 uint32_t j = i;
-                const uint32_t l = cap_of(b->order[c][i]);
-                while (j < b->ncls[c] && cap_of(b->order[c][j]) == l) ++j;
-                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= 8 ? l : cls_lists};
-                sl.stream = l >= 2 && l <= 8;
+                const uint32_t kk = key_of(b->order[c][i]), l = kk >= KW ? kk - KW : kk;
+                while (j < b->ncls[c] && key_of(b->order[c][j]) == kk) ++j;
+                ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= DS2I_HIP_MAX_TERMS ? l : cls_lists};
+                sl.stream = l >= 2 && l <= DS2I_HIP_MAX_TERMS;
                 b->sub[c].push_back(sl);
                 i = j;
             }
@@ -867,7 +882,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (uint32_t i = 0; i < b->nsplit; ++i) b->hist_slot[b->split_queries[i]] = i;
     b->o_hslot = place(b->hist_slot.size() * 4);
     for (int c = 0; c < NCLS; ++c) b->o_order[c] = place(b->order[c].size() * 4);
-    for (int c = 0; c < 3; ++c) b->o_urec[c] = place((b->union_rstream || c < rs_stream_classes()) ? b->order[c].size() * sizeof(ds2i_dev::UnitRec) : 0); // (classes of k_ranked_stream / k_union_stream)
+    for (int c = 0; c < 4; ++c) b->o_urec[c] = place((b->union_rstream || c < rs_stream_classes()) ? b->order[c].size() * sizeof(ds2i_dev::UnitRec) : 0); // (classes of k_ranked_stream / k_union_stream)
     b->o_qterm_q = place(b->freq_stream ? qterms.size() * 4 : 0);
     b->o_sterms = place(b->sterms.size() * sizeof(ds2i_dev::StreamTerm));
     b->o_match_off = place(b->want_matches ? b->match_off.size() * 8 : 0);
@@ -974,7 +989,7 @@ int upload_batch(ds2i_hip_batch* b) {
         for (uint32_t q = 0; q < b->nq; ++q)
             for (uint32_t i = b->qoff[q]; i < b->qoff[q + 1]; ++i) qq[i] = q;
     }
-    for (int c = 0; c < 3 && b->union_rstream; ++c) { // k_union_stream: the unit, its virtual query's terms, its REAL query (results, histogram), its exclusion lists
+    for (int c = 0; c < 4 && b->union_rstream; ++c) { // k_union_stream: the unit, its virtual query's terms, its REAL query (results, histogram), its exclusion lists
         ds2i_dev::UnitRec* r = (ds2i_dev::UnitRec*)(h + b->o_urec[c]);
         for (size_t i = 0; i < b->order[c].size(); ++i) {
             const uint32_t uid = b->order[c][i];
@@ -1110,7 +1125,7 @@ int launch_batch(ds2i_hip_batch* b) {
     // kernel's 2.5 ms on that class's stream) go to a spare stream -- class 0 is one of three co-critical class streams of the step
     const bool side_group0 = base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && b->ncls[0] && b->sub[0].size() > 1 && b->sub[0].front().stream;
     // ... and wand / maxscore / ranked_or's second stream group of the 5-8-list class (capacity 6 behind capacity 8: 3.6 ms behind 7.5 ms)
-    const bool side_group2 = b->union_rstream && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
+    const bool side_group2 = b->union_rstream && b->warm_units.empty() && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
     if ((spread || side_group0 || side_group2) && !b->sset)
         for (int c = NCLS - 1; c >= 0; --c)
             if (!b->ncls[c]) {
@@ -1137,7 +1152,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
-        a.urec = (c < 3 && (b->union_rstream || c < rs_stream_classes())) ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
+        a.urec = (c < 4 && (b->union_rstream || c < rs_stream_classes())) ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
         a.nslice = b->ncls[c];
         a.dyn_lists = 0;
         a.num_docs = (uint32_t)idx->num_docs;

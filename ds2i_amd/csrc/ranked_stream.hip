@@ -163,13 +163,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             auto spread = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rscv = lane == (uint32_t)j ? rsc[j] : rscv; };
             rs_for<1, NT>(spread);
         }
-        // what lists 1.. can add to any document at most (their list maxima), and the collection's shortest document: a posting of
-        // list 0 with freq f scores at most qw0 * doc_term_weight(f, min_nl) there
-        float rest_all = 0.f;
-        {
-            auto add_max = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; rest_all = rest_all + rsc[j] * 255.0f; };
-            rs_for_down<NT, 1>(add_max);
-        }
+        // the collection's shortest document: a posting of list 0 with freq f scores at most qw0 * doc_term_weight(f, min_nl) there
         const float min_nl = a->min_norm_len;
         const long long hdelta = a->rmh ? (long long)(a->rmh - a->rmw) : 0ll; // hint of an entry = the byte at the same offset of the parallel buffer
         // Three and four lists: the byte fetched ahead for every candidate is list 1's HINT, not its weight. A weight byte lets a
@@ -232,9 +226,11 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // each other list the largest range-table entry over the block's own doc-id span (read from the level whose entries are
         // wide enough for <= 16 of them to cover the span); -1 = no such row, or some other list has no posting in the span.
         // Before the first fill (s_valid == 0) no row is live and the refill starts at the unit's first block.
+        // (kept per row as well: the other lists' part of that bound -- what they can add to any posting of the block at most. The
+        // candidates' first test uses it where the lists' maxima would let more of them through to list 1's table)
         uint32_t s_first = 0, s_valid = 0;
         uint2 s_e = make_uint2(0xFFFFFFFFu, 0u);
-        float s_ub = -1.f;
+        float s_ub = -1.f, s_rest = 0.f;
 
         auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
             s_first = first;
@@ -269,11 +265,12 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 acc = acc + rsc[j] * (float)best;
             };
             rs_for_down<NT, 1>(one_list);
+            s_rest = acc;
             if constexpr (AND) s_ub = (dead || !row) ? -1.0f : 0.0f; // (a live row: some posting of every other list lies in the block's span)
             else s_ub = (dead || !row) ? -1.0f : (qw0 * s_w + acc) * BOUND_SLACK; // (scores are >= 0: -1 never enters)
         };
         // a block of list 0 on its way through the stages
-        struct Blk { uint32_t blk, base, ep; };
+        struct Blk { uint32_t blk, base, ep; float rest; };
         auto select = [&](uint32_t from, Blk& o) __attribute__((always_inline)) -> uint32_t { // first block >= from worth a visit
             for (;;) {
                 if (from >= blk_end) return 0u;
@@ -284,6 +281,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     o.blk = s_first + f;
                     o.base = o.blk ? bcast(s_e.x, fp) + 1u : 0u;
                     o.ep = o.blk ? bcast(s_e.y, fp) : 0u;
+                    if constexpr (!AND) o.rest = __uint_as_float(bcast(__float_as_uint(s_rest), f));
                     return 1u;
                 }
                 if (s_valid && s_first + 64u >= blk_end) return 0u;
@@ -369,8 +367,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane]; // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists)
                 GP gP0 = x0, gP1 = x1;
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
-                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK) & (x0 != 0u);
-                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK) & (x1 != 0u);
+                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + B.rest) * BOUND_SLACK) & (x0 != 0u);
+                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + B.rest) * BOUND_SLACK) & (x1 != 0u);
                 // AND: bit j = list j has to be searched for this candidate (its hint did not settle it: several postings in the range,
                 // a range wider than rmh_code is injective over, or no hints at all)
                 uint32_t need0 = 0, need1 = 0;
@@ -688,7 +686,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // only the candidates whose own bound + the other lists' maxima can still enter the heap ask list 1's table (the others
                 // read entry 0: one shared line); a block without any such candidate is done. One byte per candidate from list 1 (the
                 // other lists' bytes are fetched in stage B for the candidates inside list 1's ranges only: most die at list 1).
-                const bool al0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + rest_all) * BOUND_SLACK), al1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + rest_all) * BOUND_SLACK);
+                const bool al0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + B.rest) * BOUND_SLACK), al1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + B.rest) * BOUND_SLACK);
                 haveB = (ballot(al0) | ballot(al1)) != 0 ? 1u : 0u;
                 if (haveB) {
                     LC(PH_C_ALIVE, __builtin_popcountll(ballot(al0)) + __builtin_popcountll(ballot(al1)));

@@ -44,10 +44,10 @@ using namespace ds2i_dev::stream;
 
 namespace {
 
-// NT = list CAPACITY of an instantiation (2, 4, 6, 8); a unit's virtual query has nt <= NT lists (UnitRec::pad). One launch per
-// capacity: 2 | 3-4 | 5-6 | 7-8 lists -- four launch groups of a batch instead of seven, each with one tail.
-// 2 lists: 6 waves per SIMD; 3..4: 5; 5..8: what the LDS of one decoded block per list leaves
-#define US_WAVES(NT) ((NT) <= 2 ? 6 : (NT) <= 4 ? 5 : (NT) <= 6 ? 4 : 3)
+// NT = list CAPACITY of an instantiation (2, 4, 6, 8, 16); a unit's virtual query has nt <= NT lists (UnitRec::pad). One launch per
+// capacity: 2 | 3-4 | 5-6 | 7-8 | 9-16 lists -- five launch groups of a batch, each with one tail.
+// 2 lists: 6 waves per SIMD; 3..4: 5; beyond: what the LDS of one decoded block per list leaves (16 lists: 20 KB per wave)
+#define US_WAVES(NT) ((NT) <= 2 ? 6 : (NT) <= 4 ? 5 : (NT) <= 6 ? 4 : (NT) <= 8 ? 3 : 2)
 
 template <int NT>
 struct LdsUS {
@@ -67,13 +67,24 @@ enum { LS_CUR = 0, LS_BMAX, LS_N, LS_BB, LS_LOLO, LS_LOHI, LS_QW, LS_TLLO, LS_TL
 
 template <int NT, bool STATS>
 __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_unused) {
-    static_assert(NT >= 2 && NT <= 8, "list capacities 2..8");
+    static_assert(NT >= 2 && NT <= 16, "list capacities 2..16");
     __shared__ LdsUS<NT> L;
     const uint32_t lane = lane_id();
     typename std::conditional<STATS, uint32_t, NullCounter>::type s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
     typename std::conditional<STATS, unsigned long long, NullCounter>::type s_bytes;
     s_docs_blocks = s_freqs_blocks = s_bm_examined = s_scored = s_rounds = 0;
     s_bytes = 0;
+#ifdef DS2I_US_PHASE
+    // diagnostic build (-DDS2I_US_PHASE, instrumented runs): shader cycles of a wave by where it spends them and a few event counts,
+    // reported through Stats::phase_cycles (profiles/probes/us_phase_probe.py). PT(slot) closes the interval since the previous PT.
+    unsigned long long pt[PH_COUNT] = {};
+    unsigned long long pt_prev = __builtin_readcyclecounter();
+#define PT(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); pt[slot] += t_ - pt_prev; pt_prev = t_; } while (0)
+#define EV(slot, n) pt[slot] += (n)
+#else
+#define PT(slot) ((void)0)
+#define EV(slot, n) ((void)0)
+#endif
     const uint32_t nslice = rs_args()->nslice;
     for (uint32_t tkt = blockIdx.x; tkt < nslice; tkt += gridDim.x) {
         KArgs a = rs_args(); // (fields read below stay live for the unit; the cold ones are re-read at their use site)
@@ -115,9 +126,9 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
         };
         rs_for<1, NT>(bind_one);
         // range-table weight bytes of a lane's two candidates, packed: byte j - 1 = list j (v_cvt_f32_ubyteN unpacks for free); one
-        // dword holds lists 1..4, six and more lists take a pair. The bytes of EXCLUSION lists stay zero in these words, so that the
-        // sums below run over every list and add exactly what the optional ones can add.
-        using GP = typename std::conditional<(NT > 5), unsigned long long, uint32_t>::type;
+        // dword holds lists 1..4, six and more lists take a pair, ten and more a quad. The bytes of EXCLUSION lists stay zero in these
+        // words, so that the sums below run over every list and add exactly what the optional ones can add.
+        using GP = typename std::conditional<(NT > 9), unsigned __int128, typename std::conditional<(NT > 5), unsigned long long, uint32_t>::type>::type;
         auto gbyte = [](GP g, uint32_t j) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(g >> (8u * (j - 1u))) & 255u; };
         // what the lists after list `after` can add to a candidate, from their bytes (summed from the last list down, so that the
         // value for `after` is a prefix of the same chain whatever `after` is)
@@ -135,7 +146,6 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
             auto mark = [&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; if ((uint32_t)j > nexcl && (uint32_t)j < nt) g_ff |= (GP)255u << (8 * (j - 1)); };
             rs_for<1, NT>(mark);
         }
-        const float opt_all = rest_of(g_ff, 0); // what the optional lists can add to any document at most
         const float min_nl = a->min_norm_len;
         const long long hdelta = a->rmh ? (long long)(a->rmh - a->rmw) : 0ll; // hint of an entry = the byte at the same offset of the parallel buffer
         // the byte fetched ahead for every candidate: list 1's HINT where list 1 is an exclusion (the hint answers "is it theirs"),
@@ -200,9 +210,13 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
         // ---- the 64-row window of the driver's table (lane j: row s_first + j; lane 0 is the row before the first block the window
         // can serve, unless that is block 0): the block's weight and what a document of that block can score at most = block weight +
         // for each OPTIONAL list the largest range-table entry over the block's own doc-id span; -1 = no such row
-        uint32_t s_first = 0, s_valid = 0;
+        // ... kept per row as well: the optional lists' part of that bound (what any posting of the block can gain at most -- the
+        // candidates' first test uses it where a list maximum would let nearly everybody through: 73-114 of 128 candidates of a 3-8-list
+        // block asked every table, 1-2 survived their bytes) and one bit per list: some posting of list j lies in the block's doc-id
+        // span at all (a clear bit: nobody of this block is in list j -- its table is not asked, for an exclusion list the verdict is in)
+        uint32_t s_first = 0, s_valid = 0, s_mask = 0;
         uint2 s_e2 = make_uint2(0xFFFFFFFFu, 0u);
-        float s_ub = -1.f, s_w = 0.f;
+        float s_ub = -1.f, s_w = 0.f, s_rest = 0.f;
         auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
             s_first = first;
             const uint32_t idx = first + lane;
@@ -218,9 +232,10 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
             const bool row = idx < blk_end && (lane > 0 || idx == 0) && top != 0xFFFFFFFFu && base <= top;
             const uint32_t b2 = row ? base : 0u, t2 = row ? top : 0u; // branch-free: a lane without a row reads entry 0 and discards it
             float acc = 0.f;
+            uint32_t mask = 0;
             auto one_list = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                if ((uint32_t)j <= nexcl || (uint32_t)j >= nt) return; // (an exclusion list adds nothing)
+                if ((uint32_t)j >= nt) return;
                 const RmwLevels g(rs_args()->num_docs, rsh[j]);
                 uint32_t lsh = rsh[j], lvl = 0;
                 while (lvl < 2 && (t2 >> lsh) - (b2 >> lsh) >= 16u) { lsh += 6; ++lvl; }
@@ -229,13 +244,16 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                 const uint64_t loff = lvl == 0 ? 0ull : lvl == 1 ? g.off[1] : g.off[2]; // (selects: a run-time index would put the array into scratch)
                 const uint32_t m = max_of_bytes16(rt[j] + loff + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
                 const uint32_t best = (row && fits) ? m : 255u; // (255 = the list maximum)
-                acc = acc + rsc[j] * (float)best;
+                mask |= best != 0u ? 1u << j : 0u;
+                if ((uint32_t)j > nexcl) acc = acc + rsc[j] * (float)best; // (an exclusion list adds nothing)
             };
             rs_for_down<NT, 1>(one_list);
+            s_rest = acc;
+            s_mask = mask;
             s_ub = row ? (qw0 * s_w + acc) * BOUND_SLACK : -1.0f; // (scores are >= 0: -1 never enters)
         };
         // a block of the driver on its way through the stages (w = its block weight x the driver's query weight)
-        struct Blk { uint32_t blk, base, ep; float w; };
+        struct Blk { uint32_t blk, base, ep, mask; float w, rest; };
         auto select = [&](uint32_t from, Blk& o) __attribute__((always_inline)) -> uint32_t { // first block >= from worth a visit
             for (;;) {
                 if (from >= blk_end) return 0u;
@@ -247,6 +265,8 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                     o.base = o.blk ? bcast(s_e2.x, fp) + 1u : 0u;
                     o.ep = o.blk ? bcast(s_e2.y, fp) : 0u;
                     o.w = qw0 * __uint_as_float(bcast(__float_as_uint(s_w), f));
+                    o.rest = __uint_as_float(bcast(__float_as_uint(s_rest), f));
+                    o.mask = bcast(s_mask, f);
                     return 1u;
                 }
                 if (s_valid && s_first + 64u >= blk_end) return 0u;
@@ -270,12 +290,14 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
         const uint32_t voff = lane * 4u;
         uint32_t bufB = 0, bufA = 1, bufN = 2;
         if (!enters(s_e)) from = blk_end; // the driver is non-essential from the start
+        PT(PH_UNIT);
         for (;;) {
             // ---------------- stage N: the next block worth a visit as things stand now, its bytes and side slot requested
             // A's bytes (and the floor word) were requested an iteration ago; the only loads issued after them are B's two gathers
             if (haveA) {
                 ++s_rounds;
                 if (haveB) rs_wait_vm<2>(); else rs_wait_vm<0>();
+                PT(PH_PREFETCH);
                 if (shared_floor) adopt_word(uniform(L.fw[0]));
             }
             Blk N{};
@@ -289,6 +311,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                                 xs_base + bufN * (XSLOT_DW * 4u), voff);
                 if (shared_floor) rs_fetch_word(fwp, fw_base);
             }
+            PT(PH_STREAM);
             if (haveA) {
                 // ---------------- stage A: docs and freqs of block A; every posting gets a bound of its OWN term score
                 const uint32_t szA = ((A.blk + 1u) * 128u <= n0) ? 128u : (n0 & 127u);
@@ -310,14 +333,18 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                 s_bm_examined += 1;
                 s_bytes += 8 + consA + consF; // block_max + endpoint + both parts
             }
+            PT(PH_DOCS);
             if (haveB) {
                 // ---------------- stage B: the gathers of block B, issued before stage A ran; the only loads issued after them are
                 // those of the prefetch above
                 if (haveN) { if (shared_floor) rs_wait_vm<PF_LOADS + 1>(); else rs_wait_vm<PF_LOADS>(); } else rs_wait_vm<0>();
+                PT(PH_TOPK);
+                EV(PH_C_GBLOCKS, 1);
                 const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane];
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
-                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + opt_all) * BOUND_SLACK);
-                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + opt_all) * BOUND_SLACK);
+                bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + B.rest) * BOUND_SLACK);
+                bool ok1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + B.rest) * BOUND_SLACK);
+                EV(PH_C_ALIVE, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 GP gP0 = 0, gP1 = 0;          // weight bytes of the optional lists
                 uint32_t need0 = 0, need1 = 0; // bit j: exclusion list j has to be searched for this candidate
                 // what an exclusion list's byte says about a candidate (hint: 0 = no posting in its range, 255 = several, else the code
@@ -333,7 +360,10 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                         ok = ok & !((x != 0u) & exact);
                     }
                 };
-                if (ex1) {
+                const bool in1 = (B.mask & 2u) != 0u; // (list 1 has a posting in this block's span: its bytes were fetched)
+                if (!in1) {
+                    // nobody of this block is in list 1: not excluded by it, nothing added by it
+                } else if (ex1) {
                     excl_byte(x0, dB0, rsh[1], ok0, need0, 2u);
                     excl_byte(x1, dB1, rsh[1], ok1, need1, 2u);
                 } else {
@@ -351,8 +381,9 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             const uint8_t* const tj = ((uint32_t)j <= nexcl && hdelta != 0) ? rt[j] + hdelta : rt[j];
-                            y0[j] = (ok0 & ((uint32_t)j < nt)) ? (uint32_t)tj[dB0 >> rsh[j]] : 0u;
-                            y1[j] = (ok1 & ((uint32_t)j < nt)) ? (uint32_t)tj[dB1 >> rsh[j]] : 0u;
+                            const bool inj = ((B.mask >> j) & 1u) != 0u; // (a list without a posting in the block's span is not asked: its bytes are zero)
+                            y0[j] = (ok0 & inj) ? (uint32_t)tj[dB0 >> rsh[j]] : 0u;
+                            y1[j] = (ok1 & inj) ? (uint32_t)tj[dB1 >> rsh[j]] : 0u;
                         };
                         rs_for<2, NT>(load_one);
                         auto use_one = [&](auto jc) __attribute__((always_inline)) {
@@ -368,9 +399,11 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                         rs_for<2, NT>(use_one);
                     }
                 }
+                PT(PH_MEMBER);
                 float r0 = rest_of(gP0, 0), r1 = rest_of(gP1, 0);
                 ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
                 ok1 = ok1 & enters((boB1 + r1) * BOUND_SLACK);
+                EV(PH_C_SURV1, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 if (hdelta != 0 && (ballot(ok0) | ballot(ok1)) != 0 && nexcl + 1u < nt) {
                     // membership hints of the OPTIONAL lists: a weight byte only says that SOME posting of list j lies in the candidate's
                     // range; where that range holds exactly one posting its hint says which. A candidate at another offset is not in the
@@ -396,7 +429,10 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                     ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
                     ok1 = ok1 & enters((boB1 + r1) * BOUND_SLACK);
                 }
+                PT(PH_FREQS);
+                EV(PH_C_SURV2, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 if (__builtin_expect((ballot(ok0) | ballot(ok1)) != 0, 0)) {
+                    EV(PH_C_LIVEROUNDS, 1);
                     // ---------------- stage C: somebody of block B may enter the heap: norm_len, exact driver score
                     const float* const norm_lens = rs_args()->norm_lens;
                     const uint8_t* const arena = rs_args()->arena;
@@ -410,6 +446,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                     }
                     ok0 = ok0 & enters((pa0 + r0) * BOUND_SLACK);
                     ok1 = ok1 & enters((pa1 + r1) * BOUND_SLACK);
+                    PT(PH_SCORE);
                     // slots 1 .. NT-1 in order: exclusions first, then the optional lists by decreasing max score. A list is consulted
                     // only for the candidates its byte left open; a candidate moves on only while partial score + what the later lists
                     // can add to IT can still enter the heap
@@ -439,6 +476,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                                 if (curj == 0xFFFFFFFFu || amin > bmj) {
                                     Found fb;
                                     const bool found = find_block_rows(tabj, wtabj, nbj, curj + 1u, amin, fb, rows_load(tabj, wtabj, nbj, curj + 1u));
+                                    EV(PH_C_VISIT, 1);
                                     if (!found) { // list j has nothing >= amin: nobody left is in it, now or later in this unit
                                         s_bm_examined += 1;
                                         s_bytes += 4;
@@ -485,6 +523,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                                     bmj = fb.bmax;
                                     if (lane == 0) { ls[LS_CUR] = curj; ls[LS_BMAX] = bmj; }
                                     ++s_docs_blocks;
+                                    EV(PH_C_BDOCS, 1);
                                     s_bytes += 4 + consD;
                                     if (!ex) { ++s_freqs_blocks; s_bytes += consF2; }
                                 }
@@ -532,6 +571,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                             ok1 = ok1 & enters((pa1 + rj1) * BOUND_SLACK);
                         }
                     }
+                    PT(PH_PROBE);
                     // pa0 / pa1 are complete scores of documents this driver owns now
                     uint32_t inserted = 0;
                     for (int half = 0; half < 2; ++half) {
@@ -541,6 +581,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                             todo &= todo - 1;
                             const float v = __uint_as_float(bcast(__float_as_uint(sc), src));
+                            EV(PH_C_HEAP, 1);
                             if (tk.insert(v)) {
                                 refresh();
                                 inserted = 1;
@@ -557,6 +598,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                     }
                 }
             }
+            PT(PH_INSERT);
             // ---------------- rotate: A becomes B (its gathers are issued now and consumed an iteration later, behind the next
             // block's decode), the block whose bytes were requested becomes A
             B = A;
@@ -568,13 +610,15 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
             if (haveB) {
                 // only the candidates whose own bound + the optional lists' maxima can still enter the heap ask list 1's table (the
                 // others read entry 0: one shared line); a block without any such candidate is done
-                const bool al0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + opt_all) * BOUND_SLACK), al1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + opt_all) * BOUND_SLACK);
+                const bool al0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + B.rest) * BOUND_SLACK), al1 = (dB1 != 0xFFFFFFFFu) & enters((boB1 + B.rest) * BOUND_SLACK);
                 haveB = (ballot(al0) | ballot(al1)) != 0 ? 1u : 0u;
-                if (haveB) {
-                    rs_gather_u8(gt1, (al0 ? dB0 : 0u) >> rsh[1], gb_base);
-                    rs_gather_u8(gt1, (al1 ? dB1 : 0u) >> rsh[1], gb_base + 256u);
+                if (haveB) { // (always two loads, so that the counted waits hold: with no posting of list 1 in the block's span everybody reads entry 0)
+                    const bool in1 = (B.mask & 2u) != 0u;
+                    rs_gather_u8(gt1, ((al0 & in1) ? dB0 : 0u) >> rsh[1], gb_base);
+                    rs_gather_u8(gt1, ((al1 & in1) ? dB1 : 0u) >> rsh[1], gb_base + 256u);
                 }
             }
+            PT(PH_FIND);
             A = N;
             haveA = haveN;
             const uint32_t t = bufB;
@@ -584,6 +628,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
             if (!(haveA | haveB)) break;
         }
         rs_wait_vm<0>();
+        PT(PH_TOTAL);
         KArgs r = rs_args();
         if constexpr (STATS) {
             unsigned long long* const clk = r->unit_clock;
@@ -605,13 +650,18 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
         atomicAdd(&stats->algorithmic_bytes, (unsigned long long)s_bytes);
         atomicAdd(&stats->postings_scored, (unsigned long long)s_scored);
         atomicAdd(&stats->rounds, (unsigned long long)s_rounds);
+#ifdef DS2I_US_PHASE
+        for (int i = 0; i < PH_COUNT; ++i) if (pt[i]) atomicAdd(&stats->phase_cycles[i], pt[i]);
+#endif
     }
+#undef PT
+#undef EV
 }
 
 } // namespace
 
 extern "C" {
-// cap = list capacity of the launch (2, 4, 6, 8): every virtual query of it has cap - 1 or cap lists (driver + exclusions + optional
+// cap = list capacity of the launch (2, 4, 6, 8, 16): every virtual query of it has cap - 1 or cap (16: 9 .. 16) lists (driver + exclusions + optional
 // lists; UnitRec::pad = exclusion lists | lists << 8); the caller has checked that the index is block_optpfor with skip table, block
 // weights, range tables and side slots, that k <= 64, and has filled BatchArgs::urec and BatchArgs::q_floor
 hipError_t ds2i_launch_union_stream(int cap, const void* args, unsigned grid, hipStream_t s) {
@@ -620,7 +670,7 @@ hipError_t ds2i_launch_union_stream(int cap, const void* args, unsigned grid, hi
     const bool st = a.stats != nullptr;
 #define DS2I_US_CASE(N) case N: if (st) hipLaunchKernelGGL((k_union_stream<N, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_union_stream<N, false>), g, b, 0, s, a); break;
     switch (cap) {
-    DS2I_US_CASE(2) DS2I_US_CASE(4) DS2I_US_CASE(6) DS2I_US_CASE(8)
+    DS2I_US_CASE(2) DS2I_US_CASE(4) DS2I_US_CASE(6) DS2I_US_CASE(8) DS2I_US_CASE(16)
     default: return hipErrorInvalidValue;
     }
 #undef DS2I_US_CASE

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""wand / maxscore / ranked_or through the stream pipeline (k_union_stream<n>, n = 2..8 lists: union_stream.hip) against the oracle's
+"""wand / maxscore / ranked_or through the stream pipeline (k_union_stream<cap>, list capacities 2 | 4 | 6 | 8 | 16: union_stream.hip) against the oracle's
 reference-order traversals (queries.hpp:200-319, 404-476, 478-591): random collections -- short and long lists paired (ranges wider than
 128 doc-ids: an exclusion list's hint is no proof there), dense lists (one doc-id per table entry), clustered lists (several postings per
-range: hint 255) -- queries of 2..8 terms anywhere in the vocabulary, among the densest lists, among the shortest; k = 10 and a k larger
+range: hint 255) -- queries of 2..16 terms anywhere in the vocabulary, among the densest lists, among the shortest; k = 10 and a k larger
 than most unions. Checked: top-k lengths equal, scores within 1e-5 relative of the oracle's, wand == maxscore == ranked_or bit for bit,
 the pipelined ABI gives the same bits. Run as a subprocess by tests/test_gpu.py (the library's knobs are read once per process):
 `[DS2I_NO_RMH=1 | DS2I_RMW_G=1 | DS2I_NO_UNION_RSTREAM=1] python tests/union_stream_probe.py [seeds]`. The oracle is the checker, nothing else."""
@@ -27,10 +27,11 @@ def one(seed):
     sizes = d.synth_doc_sizes(p)
     wand = d.build_wand(sizes, lists)
     qs = []
-    for n in range(2, 9):
-        qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(24)]   # anywhere in the vocabulary: short lists among them
-        qs += [[int(x) for x in rng.permutation(min(nt, 14))[:n]] for _ in range(24)]              # the densest lists
-        qs += [[int(x) for x in rng.permutation(nt)[-min(nt, 20):][:n]] for _ in range(12)]        # only short lists (wide ranges)
+    for n in range(2, 17):
+        reps = 24 if n <= 8 else 6
+        qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(reps)]       # anywhere in the vocabulary: short lists among them
+        qs += [[int(x) for x in rng.permutation(min(nt, 14 if n <= 8 else 24))[:n]] for _ in range(reps)]  # the densest lists
+        qs += [[int(x) for x in rng.permutation(nt)[-min(nt, 20):][:n]] for _ in range(reps // 2)]      # only short lists (wide ranges)
     qs += [[0, nt - 1], [nt - 1, nt - 2], [0, 1], list(range(8)), [5, 5, 9], [2]]
     img = d.build_index("block_optpfor", nd, lists)
     gidx = d.Index("block_optpfor", img, wand)
@@ -43,7 +44,7 @@ def one(seed):
             b = d.Batch(gidx, op, qs, k=k)
             b.run()
             _, topk, tlen, _ = b.fetch()
-            for c in range(3):
+            for c in range(4):
                 streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
             b.close()
             assert np.array_equal(tlen, olen), (seed, op, k, np.argwhere(tlen != olen)[:5])
