@@ -415,10 +415,10 @@ def main():
         if args.op in kname:
             return "%s,TMAX=%d>" % (kname[args.op], (2, 4, 8, 16)[c])
         if args.op in ("or", "or_freq"):
-            stream = not os.environ.get("DS2I_NO_UNION_STREAM")
+            stream = True
             return ("k_union<%s> (<=%d lists)" if stream else "k_disjunctive<TMAX=%d> (%s)") % (
                 ("true" if args.op == "or_freq" else "false", (2, 4, 8, 16)[c]) if stream else ((2, 4, 8, 16)[c], args.op))
-        stream = not any(os.environ.get(e) for e in ("DS2I_NO_TOPK_STREAM", "DS2I_NO_BMW_PRUNE", "DS2I_NO_RMW_USE", "DS2I_NO_RMW"))
+        stream = not any(os.environ.get(e) for e in ("DS2I_NO_BMW", "DS2I_NO_RMW"))
         if stream and not os.environ.get("DS2I_NO_UNION_RSTREAM") and not os.environ.get("DS2I_NO_XSLOTS"):  # (every index kind is queried as block_optpfor + side tables by default)
             return "k_union_stream, class of <=%d lists (%s)" % ((2, 4, 8, 16)[c], args.op)
         return ("k_union_topk<TMAX=%d> (%s)" if stream else "k_disjunctive<TMAX=%d> (%s)") % ((2, 4, 8, 16)[c], args.op)

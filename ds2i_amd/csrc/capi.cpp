@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "knobs.hpp"
 #include "../../include/ds2i_build.h"
 #include "host_index.hpp"
 #include "host_pef.hpp"
@@ -82,7 +83,6 @@ void free_index(ds2i_hip_index* x) {
     if (x->d_tails) (void)hipFree(x->d_tails);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
-    for (auto& s : x->stream_b) if (s) (void)hipStreamDestroy(s);
     if (x->s_up) (void)hipStreamDestroy(x->s_up);
     if (x->s_merge) (void)hipStreamDestroy(x->s_merge);
     delete x;
@@ -170,7 +170,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
     auto without_tables = [&](const char* why, uint64_t want) -> int {
         x->list_rmw_off64.clear();
         x->list_rmw_shift.clear();
-        if (std::getenv("DS2I_RMW_REQUIRE")) {
+        if (ds2i_knobs().rmw_require) {
             char msg[256];
             std::snprintf(msg, sizeof msg, "doc-id-range tables (%.2f GB) cannot be built: %s (DS2I_RMW_REQUIRE is set)", want / 1e9, why);
             return ds2i_set_error(DS2I_ENOMEM, msg);
@@ -188,7 +188,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
         x->list_rmw_shift[t] = sh;
         x->list_rmw_off64[t] = (uint32_t)cursor;
         cursor += ds2i_dev::RmwLevels((uint32_t)x->num_docs, sh).bytes() / 64; // level 1 + its two coarser levels
-        if (ds2i_dev::RmwLevels::has_bitmap(x->list_n[t], (uint32_t)x->num_docs) && !std::getenv("DS2I_NO_BITMAPS"))
+        if (ds2i_dev::RmwLevels::has_bitmap(x->list_n[t], (uint32_t)x->num_docs) && !ds2i_knobs().no_bitmaps)
             cursor += ds2i_dev::RmwLevels::bitmap_bytes((uint32_t)x->num_docs) / 64; // dense list: + its exact bitmap
         if (cursor >= (1ull << 32)) return without_tables("more than 256 GB of tables", cursor * 64);
     }
@@ -232,7 +232,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
     a.rmw = x->d_rmw;
     a.rmh = x->d_rmh;
     a.rmw_level = 0;
-    a.bitmaps = std::getenv("DS2I_NO_BITMAPS") ? 0u : 1u;
+    a.bitmaps = ds2i_knobs().no_bitmaps ? 0u : 1u;
     x->has_bitmaps = a.bitmaps != 0;
     HIP_OK(ds2i_launch_block_max_weights(&a, grid, x->stream[0]));
     for (uint32_t lvl = 1; lvl <= 2; ++lvl) { // level lvl + 1 = maxima of 64 entries of level lvl, 4096 entries per item
@@ -258,7 +258,7 @@ int build_block_max_weights(ds2i_hip_index* x) {
 // Bytes of the doc-id-range tables (levels + dense lists' bitmaps) at G entries per posting; the hints are a buffer of the same size.
 static uint64_t range_table_bytes_at(const ds2i_hip_index* x, double G) {
     uint64_t cursor = 0;
-    const bool bitmaps = !std::getenv("DS2I_NO_BITMAPS");
+    const bool bitmaps = !ds2i_knobs().no_bitmaps;
     for (uint64_t t = 0; t < x->size; ++t) {
         uint32_t sh = 0;
         while (sh < 31 && (double)(x->num_docs >> (sh + 1)) >= G * (double)x->list_n[t]) ++sh;
@@ -277,7 +277,7 @@ static uint64_t range_table_bytes_at(const ds2i_hip_index* x, double G) {
 // DS2I_TABLE_BUDGET in bytes ("<bytes>" or "<factor>x" of the CALLER's image -- for a transcoded upload the image handed to
 // ds2i_hip_index_open, not its re-encoded form), 0 = none
 static uint64_t table_budget_bytes(size_t image_bytes) {
-    const char* eb = std::getenv("DS2I_TABLE_BUDGET");
+    const char* eb = ds2i_knobs().table_budget;
     if (!eb || !*eb) return 0;
     char* end = nullptr;
     const double v = std::strtod(eb, &end);
@@ -285,14 +285,14 @@ static uint64_t table_budget_bytes(size_t image_bytes) {
     return (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
 }
 static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
-    const char* gs = std::getenv("DS2I_RMW_G");
-    x->plan_g = gs ? std::atof(gs) : 4.0;
-    if (!(x->plan_g > 0) || std::getenv("DS2I_NO_RMW")) x->plan_g = 0;
-    x->plan_hints = !std::getenv("DS2I_NO_RMH");
-    x->plan_slots = !std::getenv("DS2I_NO_XSLOTS") && x->kind == DS2I_BLOCK_OPTPFOR;
+    const Ds2iKnobs& kn = ds2i_knobs();
+    x->plan_g = kn.rmw_g;
+    if (!(x->plan_g > 0) || kn.no_rmw) x->plan_g = 0;
+    x->plan_hints = !kn.no_rmh;
+    x->plan_slots = !kn.no_xslots && x->kind == DS2I_BLOCK_OPTPFOR;
     x->table_budget = table_budget_bytes(image_bytes);
     if (!x->table_budget) return;
-    const bool g_pinned = gs != nullptr || std::getenv("DS2I_NO_RMW") != nullptr; // (an explicit knob pins the granularity: DS2I_NO_RMW = none)
+    const bool g_pinned = kn.rmw_g_set || kn.no_rmw; // (an explicit knob pins the granularity: DS2I_NO_RMW = none)
     // resident whatever is chosen: the image and its skip table (counted in extra_bytes by now), block weights (4 B per block), norm_lens
     const uint64_t base = x->arena_bytes + x->extra_bytes + 4ull * x->total_blocks + (x->has_wand ? 4 * x->num_docs : 0);
     // side tables = a slot per block + the lists' partial last blocks in plain form + the overflow area at its first-attempt size
@@ -314,8 +314,8 @@ static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
                                  {2, false, false}, {1, false, false}, {0, false, false}};
     for (const Plan& c : order) {
         if (g_pinned && c.g != x->plan_g) continue;
-        if (std::getenv("DS2I_NO_RMH") && c.hints) continue;
-        if ((std::getenv("DS2I_NO_XSLOTS") || !slots) && c.slots) continue;
+        if (kn.no_rmh && c.hints) continue;
+        if ((kn.no_xslots || !slots) && c.slots) continue;
         const uint64_t tables = c.g > 0 ? range_table_bytes_at(x, c.g) : 0;
         const uint64_t total = base + tables * (c.hints ? 2 : 1) + (c.slots ? slots : 0);
         if (total <= x->table_budget || c.g == 0) {
@@ -427,32 +427,56 @@ const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
 // before the runtime initialises; an explicit setting of the user wins.
 __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
-// Two phases of the knobs: the ones an upload reads (tables to build, stream sets) are frozen by the first
-// ds2i_hip_index_open, the ones the planner / launcher read by the first batch (capi_batch.cpp). Both are function-local
-// statics or per-upload reads of the environment; setting one after its phase would be silently ignored, so it is refused.
-std::atomic<bool> g_ds2i_options_frozen{false};
-static std::atomic<bool> g_ds2i_upload_options_frozen{false};
+// The knobs (knobs.hpp) are read once, by the first ds2i_hip_index_open or the first batch; setting one afterwards would be silently
+// ignored, so it is refused.
+static std::atomic<bool> g_ds2i_knobs_read{false};
 namespace {
-const char* const kUploadKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_RMW_REQUIRE", "DS2I_NO_XSLOTS", "DS2I_MIXED_NATIVE", "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET",
-                                    "DS2I_STREAM_SETS", "DS2I_CLASS_PRIORITY"};
-const char* const kBatchKnobs[] = {"DS2I_AND_UNIT_BLOCKS", "DS2I_DEBUG_PLAN", "DS2I_DECODE_GENERAL", "DS2I_DISJ_SCALE", "DS2I_DYN_GROUP", "DS2I_DYN_MINCLS", "DS2I_GROUP_SPREAD", "DS2I_LAUNCH_ORDER",
-                                   "DS2I_LOOKUP_WEIGHT", "DS2I_NO_BITMAP_USE", "DS2I_NO_BMW_PRUNE", "DS2I_NO_AND_RSTREAM", "DS2I_NO_AND_STREAM", "DS2I_NO_FREQ_STREAM", "DS2I_NO_RANKED_STREAM", "DS2I_NO_RMH_USE",
-                                   "DS2I_NO_RMW_USE", "DS2I_NO_SKIPTAB", "DS2I_NO_TOPK_STREAM", "DS2I_NO_UNION_RSTREAM", "DS2I_NO_UNION_STREAM", "DS2I_PLAN_THREAD", "DS2I_PLAN_THREADS",
-                                   "DS2I_SEED_STREAM", "DS2I_SEED_TERMS", "DS2I_STREAM_NT_MAX", "DS2I_UNIT_CAP", "DS2I_UNIT_CLOCK", "DS2I_UNIT_DIV", "DS2I_UNIT_DIV_MANY", "DS2I_UNIT_DIV_RMW",
-                                   "DS2I_UNIT_FACTOR", "DS2I_UNIT_FLOOR", "DS2I_UT_BLOCKS", "DS2I_UT_DIV_MANY", "DS2I_UT_FIRST", "DS2I_UT_WARM"};
+const char* const kKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_NO_XSLOTS", "DS2I_RMW_REQUIRE", "DS2I_MIXED_NATIVE",
+                              "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET", "DS2I_PLAN_THREADS", "DS2I_UNIT_FACTOR", "DS2I_UNIT_CAP", "DS2I_UT_BLOCKS", "DS2I_STREAM_NT_MAX",
+                              "DS2I_NO_RANKED_STREAM", "DS2I_NO_UNION_RSTREAM", "DS2I_NO_LIST_STREAMS", "DS2I_DECODE_GENERAL", "DS2I_UNIT_CLOCK"};
+}
+
+extern "C++" const Ds2iKnobs& ds2i_knobs() {
+    static const Ds2iKnobs k = [] {
+        g_ds2i_knobs_read.store(true);
+        auto env = [](const char* n) -> const char* { return std::getenv(n); }; // (the one place the library reads its knobs)
+        auto on = [&](const char* n) { return env(n) != nullptr; };
+        auto num = [&](const char* n, double dflt) { const char* e = env(n); return e && std::atof(e) > 0 ? std::atof(e) : dflt; };
+        Ds2iKnobs v{};
+        v.rmw_g_set = on("DS2I_RMW_G");
+        v.rmw_g = v.rmw_g_set ? std::atof(env("DS2I_RMW_G")) : 4.0;
+        v.no_rmw = on("DS2I_NO_RMW");
+        v.no_rmh = on("DS2I_NO_RMH");
+        v.no_bitmaps = on("DS2I_NO_BITMAPS");
+        v.no_bmw = on("DS2I_NO_BMW");
+        v.no_xslots = on("DS2I_NO_XSLOTS");
+        v.rmw_require = on("DS2I_RMW_REQUIRE");
+        v.mixed_native = on("DS2I_MIXED_NATIVE");
+        v.pef_native = on("DS2I_PEF_NATIVE");
+        v.table_budget = env("DS2I_TABLE_BUDGET");
+        v.plan_threads = (unsigned)num("DS2I_PLAN_THREADS", 0);
+        v.unit_factor = num("DS2I_UNIT_FACTOR", 0);
+        v.unit_cap = (uint32_t)num("DS2I_UNIT_CAP", 0);
+        v.ut_blocks = (uint32_t)num("DS2I_UT_BLOCKS", 320);
+        v.stream_nt_max = (uint32_t)std::min(8.0, std::max(2.0, num("DS2I_STREAM_NT_MAX", 8)));
+        v.no_ranked_stream = on("DS2I_NO_RANKED_STREAM");
+        v.no_union_rstream = on("DS2I_NO_UNION_RSTREAM");
+        v.no_list_streams = on("DS2I_NO_LIST_STREAMS");
+        v.decode_general = on("DS2I_DECODE_GENERAL");
+        v.unit_clock = on("DS2I_UNIT_CLOCK");
+        return v;
+    }();
+    return k;
 }
 
 int ds2i_hip_set_option(const char* name, const char* value) {
     if (!name || std::strncmp(name, "DS2I_", 5) != 0 || std::strlen(name) > 48) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
     for (const char* c = name; *c; ++c)
         if (!((*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_')) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: not a DS2I_* knob");
-    bool upload = false, batch = false;
-    for (const char* k : kUploadKnobs) upload = upload || std::strcmp(k, name) == 0;
-    for (const char* k : kBatchKnobs) batch = batch || std::strcmp(k, name) == 0;
-    if (!upload && !batch) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: unknown knob (DESIGN.md 7c lists them)");
-    if (upload && g_ds2i_upload_options_frozen.load())
-        return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: an index has been uploaded already (this knob is read by ds2i_hip_index_open)");
-    if (g_ds2i_options_frozen.load()) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first batch)");
+    bool known = false;
+    for (const char* k : kKnobs) known = known || std::strcmp(k, name) == 0;
+    if (!known) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: unknown knob (DESIGN.md 7 lists them)");
+    if (g_ds2i_knobs_read.load()) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first upload)");
     if (value) setenv(name, value, 1); else unsetenv(name);
     return DS2I_OK;
 }
@@ -561,12 +585,13 @@ static int index_open_transcoded(int device, int kind, const void* index_image, 
 
 int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t index_bytes, const void* wand_image,
                         size_t wand_bytes, ds2i_hip_index** out) {
-    g_ds2i_upload_options_frozen.store(true);
-    const bool transcode = (kind == DS2I_BLOCK_MIXED && !std::getenv("DS2I_MIXED_NATIVE")) ||
-                           (kind >= DS2I_OPT && kind <= DS2I_UNIFORM && !std::getenv("DS2I_PEF_NATIVE"));
-    if (transcode && out && index_image) {
-        const int ndev = ds2i_hip_device_count();
-        if (device < 0 || device >= ndev) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
+    if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
+    if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_UNIFORM) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
+    if (device < 0 || device >= ds2i_hip_device_count()) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
+    // (the knobs are read -- once -- by the first upload that has a device to go to)
+    const bool transcode = (kind == DS2I_BLOCK_MIXED && !ds2i_knobs().mixed_native) ||
+                           (kind >= DS2I_OPT && kind <= DS2I_UNIFORM && !ds2i_knobs().pef_native);
+    if (transcode) {
         return index_open_transcoded(device, kind, index_image, index_bytes, wand_image, wand_bytes, out);
     }
     return index_open_impl(device, kind, index_image, index_bytes, wand_image, wand_bytes, false, out);
@@ -753,32 +778,18 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
     }
     HIP_OK(hipMalloc((void**)&x->d_ticket, 64 * sizeof(unsigned int)));
     {
-        // One stream per class, all of ONE priority. Rounds 2-4 gave the many-list classes (few, LDS-hungry workgroups with long
-        // dependent chains) a higher queue priority than the <=2-list flood, which starved them at the time (class 2 alone:
-        // 4 ms, next to class 0: 21 ms). With the stream kernels the <=2-list class IS the critical path of a step, and what the
-        // priorities do turned out to depend on the history of the process: the first index a process uploads ran at 990 k
-        // queries/s either way, but an index uploaded after another one had been closed -- every transcoding upload -- got
-        // hardware queues on which the priorities bite (class 0: 3.5 -> 4.4 ms per launch, the others faster, the step 18 %
-        // longer). Equal priorities: 990 k-1 000 k in every order of uploads (profiles/probes/r5_prio.sh). DS2I_CLASS_PRIORITY=1
-        // restores the old scheme.
+        // One stream per class, all of ONE priority. Rounds 2-4 gave the many-list classes a higher queue priority than the <=2-list
+        // flood; with the stream kernels what the priorities do turned out to depend on the history of the process (an index
+        // uploaded after another one had been closed -- every transcoding upload -- ran 18 % slower): equal priorities since round 5.
         int lo_pri = 0, hi_pri = 0; // numerically lower = higher priority
         HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-        static const bool by_class = std::getenv("DS2I_CLASS_PRIORITY") != nullptr;
-        for (int c = 0; c < NCLS; ++c) {
-            int pri = (lo_pri + hi_pri) / 2;
-            if (by_class) pri = c == 0 ? lo_pri : c == 1 ? (lo_pri + hi_pri) / 2 : hi_pri;
-            HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, pri));
-            // (the second set exists only when asked for: every stream is a hardware queue, and two replicas on one device --
-            // or anything else that shares the GPU -- push the total past what the queues serve without time-slicing)
-            static const char* e_sets = std::getenv("DS2I_STREAM_SETS");
-            if (c < 3 && e_sets && std::atoi(e_sets) > 0) HIP_OK(hipStreamCreateWithPriority(&x->stream_b[c], hipStreamNonBlocking, pri));
-        }
+        for (int c = 0; c < NCLS; ++c) HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));
     if (!bare) choose_table_plan(x.get(), budget_base_bytes ? budget_base_bytes : index_bytes);
     else x->plan_g = 0, x->plan_hints = x->plan_slots = false;
-    if (!bare && x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !std::getenv("DS2I_NO_BMW")) {
+    if (!bare && x->has_wand && x->total_blocks && x->total_blocks < (1ull << 32) && !ds2i_knobs().no_bmw) {
         int rc = build_block_max_weights(x.get());
         if (rc) return rc;
     }
@@ -862,7 +873,7 @@ int ds2i_hip_decode_list(ds2i_hip_index* idx, uint32_t term, uint32_t* docs, uin
     a.tails = idx->d_tails;
     unsigned grid = (unsigned)std::min<uint64_t>(nb, uint64_t(idx->num_cus) * 16);
     // block_optpfor with side tables: through the stream kernels' decoder (DS2I_DECODE_GENERAL=1: the general decoders)
-    const bool side = idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && !std::getenv("DS2I_DECODE_GENERAL");
+    const bool side = idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && !ds2i_knobs().decode_general;
     hipError_t e = side ? ds2i_launch_decode_list_side(&a, grid, idx->stream[0]) : ds2i_launch_decode_list(&a, grid, idx->stream[0]);
     if (e == hipSuccess) e = hipStreamSynchronize(idx->stream[0]);
     if (e == hipSuccess) e = hipMemcpy(docs, d_docs, 4 * len, hipMemcpyDeviceToHost);

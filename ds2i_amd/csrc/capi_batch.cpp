@@ -25,9 +25,9 @@
 #include <pthread.h>
 
 #include "capi_internal.hpp"
+#include "knobs.hpp"
 #include "host_index.hpp"
 
-extern std::atomic<bool> g_ds2i_options_frozen; // capi.cpp
 using ds2i_dev::BatchArgs;
 using ds2i_dev::MergeArgs;
 using ds2i_dev::QTerm;
@@ -140,16 +140,10 @@ void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
 }
 } // namespace
 
-// k_ranked_stream is compiled for exactly 2..8 lists; the planner hands it the 2..4-term queries (classes 0 and 1) and the
-// 5..8-term class (class 2) up to DS2I_STREAM_NT_MAX lists (default 8; 4 = that class keeps k_conjunctive<.., 8>, 5..7 = the
-// counts above it do). Measured at GOV2 scale, interleaved on one box: 1 047-1 060 k queries/s against 985-992 k with 4
-// (profiles/r05_final/stream_nt_max_ab_run2.txt) -- the class's own span gets longer (four launch groups back to back:
-// 3.65 against 3.38 ms), the step shorter: its waves issue a fraction of the instructions and leave the CUs to the other classes.
-static uint32_t rs_stream_nt_max() {
-    static const char* e = std::getenv("DS2I_STREAM_NT_MAX");
-    static const uint32_t v = e ? (uint32_t)std::min(8, std::max(4, std::atoi(e))) : 8u;
-    return v;
-}
+// k_ranked_stream is compiled for the list capacities 2 | 4 | 6 | 8; the planner hands it the queries of 2 .. DS2I_STREAM_NT_MAX lists
+// (default 8; 4 = the 5..8-term class keeps k_conjunctive<.., 8>). Round 5, interleaved on one box: 1 047-1 060 k queries/s with 8
+// against 985-992 k with 4.
+static uint32_t rs_stream_nt_max() { return ds2i_knobs().stream_nt_max; }
 static int rs_stream_classes() { return rs_stream_nt_max() > 4 ? 3 : 2; } // classes that get unit records (BatchArgs::urec)
 
 struct ds2i_hip_batch {
@@ -176,8 +170,6 @@ struct ds2i_hip_batch {
     std::vector<QTerm> vterms;
     std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
     bool union_stream = false;
-    std::vector<uint8_t> warm_flag;
-    std::vector<uint32_t> warm_units; // DS2I_UT_WARM: units launched ahead of their query's other units
     bool union_rstream = false;   // ... and some class of it runs k_union_stream (union_stream.hip): unit records + the floor words
     // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
     // depend on the union -- by a stream of their own after the merge (freq_stream.hip)
@@ -204,7 +196,6 @@ struct ds2i_hip_batch {
     std::vector<SubLaunch> sub[NCLS];
     PinBuf h_up, h_out;
     hipEvent_t ev_up = nullptr, ev_clear = nullptr, ev_done = nullptr, ev_c0[NCLS] = {}, ev_c1[NCLS] = {};
-    int sset = 0;                 // which set of class streams this launch uses (alternates between consecutive launches)
     // a class may run several kernels back to back (ranked_and: one per exact list count): hipEvents around each launch group
     std::vector<hipEvent_t> ev_g[NCLS];
     std::vector<float> grp_ms[NCLS];
@@ -266,7 +257,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
 static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
                            int want_matches) {
     ds2i_hip_index* idx = b->idx;
-    g_ds2i_options_frozen.store(true); // (ds2i_hip_set_option: the knobs below are read once)
+    const Ds2iKnobs& kn = ds2i_knobs(); // (read once per process: knobs.hpp)
     const auto plan_t0 = std::chrono::steady_clock::now();
     if (!query_offsets || (!terms && nq && query_offsets[nq] > 0))
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
@@ -383,9 +374,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                     const double span_entries = 128.0 * (double)idx->num_docs / std::max(1.0, (double)qterms[begin].n) /
                                                 (double)(1u << std::min(31u, qterms[begin + 1].rmw_shift));
                     const double lookups = inrange * std::min(1.0, 3.0 * (double)k / std::max(1.0, M)) * std::min(1.0, span_entries / 128.0);
-                    static const char* lw = std::getenv("DS2I_LOOKUP_WEIGHT");
-                    static const double lookup_weight = lw ? std::atof(lw) : 3.5;
-                    cost *= 1.0 + lookup_weight * std::min(1.0, lookups);
+                    cost *= 1.0 + 3.5 * std::min(1.0, lookups);
                 }
                 // a one-term ranked query scans its block weights (64 per probe) and decodes about k blocks
                 if (ranked && idx->d_bmw && tf.size() == 1) cost = qnb0[q] / 16.0 + 4.0 * k;
@@ -433,8 +422,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         const double mine = cpus / ranks - 1.0; // (one for the thread that drives the pipeline)
         return (unsigned)std::max(1.0, std::min(4.0, mine));
     }();
-    static const char* pth = std::getenv("DS2I_PLAN_THREADS");
-    const unsigned want_threads = pth && std::atoi(pth) > 0 ? (unsigned)std::atoi(pth) : default_threads;
+    const unsigned want_threads = kn.plan_threads ? kn.plan_threads : default_threads;
     const unsigned nchunks = nq >= 1024 ? std::max(1u, std::min(want_threads, 16u)) : 1u;
     std::vector<Chunk>& chunks = b->plan_chunks;
     if (chunks.size() < nchunks) chunks.resize(nchunks);
@@ -484,7 +472,6 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (double c : total_cost) all_cost += c;
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
     // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
-    static const char* uf = std::getenv("DS2I_UNIT_FACTOR");
     // With range tables a ranked conjunction is cheap per block and the parts of a split query each pay for warming up
     // their own heap: coarser units win (measured on the GOV2-scale batch, queries/s: factor 16: 355 k, 8: 344 k,
     // 4 with the many-list classes cut 4x finer: 430-457 k, 2: 251 k)
@@ -492,36 +479,29 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                                                          // stays with the blocks of all lists, and they are throughput-, not tail-bound: measured)
     // (a small batch -- the per-GPU share of a batch sharded over several GPUs -- is cut coarser still: at 512 queries factor 2
     // measured 391 k queries/s against 321-328 k with 4; at 4096 it is the other way round)
-    const double unit_factor = uf && std::atof(uf) > 0 ? std::atof(uf) : rmw_units ? (nq < 1536 ? 2.0 : 4.0) : 16.0;
+    const double unit_factor = kn.unit_factor > 0 ? kn.unit_factor : rmw_units ? (nq < 1536 ? 2.0 : 4.0) : 16.0;
     // wand / maxscore / ranked_or: the streaming form (kernels.hip, k_union_topk) needs the range tables and the block weights;
     // queries beyond 16 terms and k > 64 keep the one-document-per-step kernel, and the whole batch keeps the windowed
     // kernel when any query does (one operator = one kernel family per batch)
-    static const bool no_topk_stream = std::getenv("DS2I_NO_TOPK_STREAM") != nullptr;
     const bool disj_topk_op = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-    static const bool tables_off = std::getenv("DS2I_NO_BMW_PRUNE") || std::getenv("DS2I_NO_RMW_USE"); // (A/B knobs of launch_batch)
     b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
-                      !b->long_terms && !no_topk_stream && !tables_off;
-    static const bool no_and_stream = std::getenv("DS2I_NO_AND_STREAM") != nullptr;
+                      !b->long_terms;
     // (list_stream: what a stream over ONE list needs -- its blocks through the side slots; and_stream: the other lists' bitmaps as well)
     const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
-                             idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !no_and_stream;
-    const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps && !std::getenv("DS2I_NO_BITMAP_USE") && !std::getenv("DS2I_NO_RMW_USE");
-    static const char* aub = std::getenv("DS2I_AND_UNIT_BLOCKS");
-    static const uint32_t and_unit_blocks = aub && std::atoi(aub) > 0 ? (uint32_t)std::atoi(aub) : 96u;
+                             idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams;
+    const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps;
+    const uint32_t and_unit_blocks = 96u; // (measured: 48: 965 k, 96: 1 068 k queries/s; whole queries: 802 k)
     const bool and_rs_units = base_op == DS2I_OP_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
-                              idx->d_bmw && idx->d_rmw && !tables_off && !std::getenv("DS2I_NO_AND_RSTREAM") && !std::getenv("DS2I_NO_RANKED_STREAM") && !std::getenv("DS2I_NO_SKIPTAB");
+                              idx->d_bmw && idx->d_rmw && !kn.no_ranked_stream;
     b->sterms.clear();
     b->sterm_longest = 0;
     b->union_rstream = false;
-    b->warm_units.clear();
-    static const bool no_freq_stream = std::getenv("DS2I_NO_FREQ_STREAM") != nullptr;
     b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
-                     idx->d_skip && !no_freq_stream && !std::getenv("DS2I_NO_UNION_STREAM");
+                     idx->d_skip && !kn.no_list_streams;
     b->vterms.clear();
     b->voff.assign(1, 0);
     b->vinfo.clear();
-    static const char* utb = std::getenv("DS2I_UT_BLOCKS");
-    const uint32_t ut_blocks = utb && std::atoi(utb) > 0 ? (uint32_t)std::atoi(utb) : 320u; // blocks of the driving list per unit (k_union_topk, round 4: 96: 335 k, 128-256: 345-352 k, 384: 335 k queries/s; k_union_stream, round 6: 64: 240 k, 160: 378 k, 320: 401 k)
+    const uint32_t ut_blocks = kn.ut_blocks; // DS2I_UT_BLOCKS, default 320: blocks of the driving list per unit (k_union_topk, round 4: 96: 335 k, 128-256: 345-352 k, 384: 335 k queries/s; k_union_stream, round 6: 64: 240 k, 160: 378 k, 320: 401 k)
     auto add_unit = [&](int c, uint32_t q, uint32_t lo, uint32_t hi, uint32_t parts, double cost) {
         Unit u;
         u.q = q;
@@ -535,24 +515,13 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
         const int c = bigk ? CLS_LONG : class_of(nt);
-        // multi-list units are latency-bound chains (non-sequential probes): cut them finer so the tail stays parallel
-        static const char* ud = std::getenv("DS2I_UNIT_DIV");
-        static const double unit_div = ud && std::atof(ud) > 0 ? std::atof(ud) : 4.0;
+        // multi-list units are latency-bound chains (non-sequential probes): cut 4x finer so the tail stays parallel; the 9-16-term
+        // class (one or two waves per SIMD; its few, long units were the last thing every batch waited for) 4x finer still
+        const double unit_div = 4.0, unit_div_rmw = 4.0, unit_div_many = 4.0;
         const bool rmw_cost = rmw_units; // (cost already counts the class's time per block)
-        static const char* udr = std::getenv("DS2I_UNIT_DIV_RMW");
-        static const double unit_div_rmw = udr && std::atof(udr) > 0 ? std::atof(udr) : 4.0;
-        // the 9-16-term class runs one wave per SIMD (23 KiB of LDS per wave) next to kernels that run five or six: a unit of it
-        // gets a fraction of the issue slots and its few, long units were the last thing every batch waited for (rocprofv3: 5.3 ms
-        // per launch for 18 queries, the longest kernel of the step) -- cut them DS2I_UNIT_DIV_MANY (4) times finer still
-        static const char* udm = std::getenv("DS2I_UNIT_DIV_MANY");
-        static const double unit_div_many = udm && std::atof(udm) > 0 ? std::atof(udm) : 4.0;
         // a unit pays for itself (a dozen dependent round trips before its first block, its own heap to warm up): below a few
-        // dozen blocks that is most of its time. The floor only binds for small batches -- the per-GPU share of a batch
-        // sharded over 8 GPUs: at 512 queries the 3-4-term class was cut into 39 k units of 4 blocks (DS2I_UNIT_FLOOR; 48 = round 4:
-        // 227 k queries/s at batch 512, 192: 300-330 k)
-        static const char* ufl = std::getenv("DS2I_UNIT_FLOOR");
-        static const double unit_floor = ufl && std::atof(ufl) > 0 ? std::atof(ufl) : 0.0;
-        const double floor_cost = unit_floor > 0 ? unit_floor : (rmw_cost && c <= 2) ? 256.0 : 48.0;
+        // dozen blocks that is most of its time. The floor only binds for small batches -- the per-GPU share of a batch sharded over 8 GPUs
+        const double floor_cost = (rmw_cost && c <= 2) ? 256.0 : 48.0;
         const double target = std::max(floor_cost, all_cost / (unit_factor * resident) / (c == 0 ? 1.0 : rmw_cost ? unit_div_rmw : unit_div) /
                                                        (c == 3 && rmw_cost ? unit_div_many : 1.0));
         ++b->nqcls[c];
@@ -610,14 +579,13 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 // block with 2 lists, 25 us with 4, against 2-4 us). Left whole, a 600-block query of that kind ran for 6 ms and WAS
                 // the kernel's span (DS2I_UNIT_CLOCK: 1 700 of 6 144 wave slots busy on average). The cost model above now prices
                 // such queries; DS2I_UNIT_CAP (blocks; half of it beyond 2 lists) additionally bounds every unit -- off by
-                // default: cutting EVERY query that fine cost 20 % (each part warms up its own heap).
-                static const char* uc = std::getenv("DS2I_UNIT_CAP");
-                static const uint32_t cap_env = uc && std::atoi(uc) > 0 ? (uint32_t)std::atoi(uc) : 0u;
+                // default: cutting EVERY query that fine cost 20 % (each part warms up its own heap). The tests use it to split everything.
+                const uint32_t cap_env = kn.unit_cap;
                 if (cap_env) parts = std::max(parts, (nb0 + (c == 0 ? cap_env : std::max(8u, cap_env / 2)) - 1) / (c == 0 ? cap_env : std::max(8u, cap_env / 2)));
             }
             // `and` through the stream pipeline has no heap to warm up -- a part costs its blocks and nothing else -- and a two-list query
             // left whole was a single wave for up to 13 ms (DS2I_UNIT_CLOCK: class 0 = 487 units, median 4.9 ms, 229 waves busy on
-            // average, the span of the whole batch): at most DS2I_AND_UNIT_BLOCKS (96) blocks of the shortest list per unit
+            // average, the span of the whole batch): at most 96 blocks of the shortest list per unit
             if (and_rs_units && split_ok && nt > 1 && nt <= 8) parts = std::max(parts, (nb0 + and_unit_blocks - 1) / and_unit_blocks);
             const uint32_t per = (nb0 + parts - 1) / parts;
             parts = (nb0 + per - 1) / per;
@@ -673,20 +641,9 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 b->vinfo.push_back(e);
                 b->vinfo.push_back(sbits);
                 const uint32_t nbe = std::max(1u, qnbs[begin + ord[e]]);
-                // (the 9-16-term class runs one wave per SIMD: its units are cut DS2I_UT_DIV_MANY times finer, for more of them at once)
-                static const char* utm = std::getenv("DS2I_UT_DIV_MANY");
-                static const uint32_t ut_div_many = utm && std::atoi(utm) > 0 ? (uint32_t)std::atoi(utm) : 4u;
-                uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / ut_div_many) : ut_blocks;
-                // DS2I_UT_WARM=n (experiment): the first n blocks of a query's first driving list are a unit of their own, launched AHEAD of
-                // the query's other units (a launch group of its own at the head of the class stream), so that those start with a floor
-                static const char* utw = std::getenv("DS2I_UT_WARM");
-                static const uint32_t ut_warm = utw && std::atoi(utw) > 0 ? (uint32_t)std::atoi(utw) : 0u;
-                uint32_t lo0 = 0;
-                if (ut_warm && e == 0 && nbe > ut_warm && c <= 3) {
-                    b->warm_units.push_back((uint32_t)b->units.size());
-                    add_unit(c, vq, 0, ut_warm, 0, 1.0e9);
-                    lo0 = ut_warm;
-                }
+                // (the 9-16-term class runs two waves per SIMD: its units are cut 4 times finer, for more of them at once)
+                const uint32_t utb_c = c == 3 ? std::max(4u, ut_blocks / 4u) : ut_blocks;
+                const uint32_t lo0 = 0;
                 const uint32_t nrest = nbe - lo0;
                 const uint32_t parts_e = (nrest + utb_c - 1) / utb_c, per = (nrest + parts_e - 1) / parts_e;
                 for (uint32_t lo = lo0; lo < nbe; lo += per) // (the driving lists of higher max score first: they raise the threshold)
@@ -704,17 +661,9 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             // batch (wand, queries/s): {8,2,1,1} 50.6 k, {8,2,2,2} 54.5 k, {8,4,4,4} 55.4 k, {4,2,4,4} 55.7 k -- with the
             // shared score histogram a part no longer has to warm up its own threshold, so the latency-bound many-list
             // classes gain from finer parts
-            static double disj_scale[NCLS] = {4.0, 2.0, 4.0, 4.0, 1.0};
-            static const bool scale_from_env = [] { // DS2I_DISJ_SCALE="a,b,c,d": A/B knob
-                const char* e = std::getenv("DS2I_DISJ_SCALE");
-                if (e) std::sscanf(e, "%lf,%lf,%lf,%lf", &disj_scale[0], &disj_scale[1], &disj_scale[2], &disj_scale[3]);
-                for (double& v : disj_scale) if (!(v > 0)) v = 1.0; // (a zero scale would divide by zero below)
-                return e != nullptr;
-            }();
-            (void)scale_from_env;
+            static const double disj_scale[NCLS] = {4.0, 2.0, 4.0, 4.0, 1.0};
             // or / or_freq run as a stream (k_union): a part costs a positioning of every list plus its blocks, once each
-            static const bool no_union_stream = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
-            const bool stream_or = !ranked && !(op & DS2I_OP_REFERENCE_ORDER) && !no_union_stream;
+            const bool stream_or = !ranked && !(op & DS2I_OP_REFERENCE_ORDER);
             const double dtarget = std::max(48.0, all_cost / (unit_factor * (stream_or ? 1.0 : disj_scale[c]) * resident));
             if (nt && N > 1)
                 parts = (uint32_t)std::min<double>(std::max(1.0, std::floor(qcost[q] / dtarget)), std::min<double>(N, 1024.0));
@@ -737,47 +686,39 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // Residency hides the union kernels' dependent round trips and LDS per wave caps it. The <=2- and <=4-list kernels
         // are capped by registers first (6 / 5 waves per SIMD), so only the many-list classes are cut into groups: the
         // longest queries first, costliest first inside a group (stable). The groups of a class run back to back on its
-        // stream, so finer is not better: DS2I_DYN_GROUP = granularity in lists, measured on the GOV2-scale wand batch
+        // stream, so finer is not better: granularity in lists, measured on the GOV2-scale wand batch (round 2: k_disjunctive)
         // 0 (off) 60.6 k, 1: 60.0 k, 2: 62.4 k, 4: 61.0 k queries/s.
-        static const char* dg = std::getenv("DS2I_DYN_GROUP");
-        static const uint32_t dyn_group = dg ? (uint32_t)std::min(16, std::max(0, std::atoi(dg))) : 2u; // (a negative value would wrap)
+        const uint32_t dyn_group = 2u;
         const uint32_t cls_lists = c == 0 ? 2u : c == 1 ? 4u : c == 2 ? 8u : 16u;
         const bool union_kernel = !conj && !(op & DS2I_OP_REFERENCE_ORDER) && c != CLS_LONG;
-        static const char* dm = std::getenv("DS2I_DYN_MINCLS");
-        static const int dyn_mincls = dm ? std::atoi(dm) : 2;
+        const int dyn_mincls = 2;
         if (b->union_stream) {
             // block_optpfor with every upload-time table: the virtual queries of 2 .. 8 lists run the pipelined stream kernel compiled for
             // exactly their list count (union_stream.hip), one launch group per count, back to back on the class stream -- as ranked_and
             // does (below); everything else (other codecs, 9-16 lists, the empty query's unit): k_union_topk, static LDS, one launch per class
-            static const bool no_us = std::getenv("DS2I_NO_UNION_RSTREAM") != nullptr;
-            const bool us_ok = !no_us && c <= 3 && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw;
+            const bool us_ok = !kn.no_union_rstream && c <= 3 && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw;
             b->union_rstream = b->union_rstream || us_ok;
             if (!us_ok) {
                 b->sub[c].push_back({0u, b->ncls[c], cls_lists});
                 continue;
             }
-            // (list CAPACITIES 2 | 4 | 6 | 8: a launch group holds the virtual queries of cap - 1 and cap lists -- four groups and four tails
-            // per batch instead of seven; inside a group the units stay in cost order)
-            std::vector<uint8_t>& warm = b->warm_flag;
-            warm.assign(b->units.size(), 0);
-            for (uint32_t uid : b->warm_units) warm[uid] = 1;
-            constexpr uint32_t KW = DS2I_HIP_MAX_TERMS + 2; // (warm groups: key + KW, ahead of every main group)
+            // (list CAPACITIES 2 | 4 | 6 | 8 | 16: a launch group holds the virtual queries of cap - 1 and cap (9 .. 16) lists -- five groups
+            // and five tails per batch; inside a group the units stay in cost order)
             auto cap_of = [&](uint32_t uid) { const uint32_t vq = b->units[uid].q, n = b->voff[vq + 1] - b->voff[vq]; return n < 2 ? 0u : n > DS2I_HIP_MAX_TERMS ? DS2I_HIP_MAX_TERMS + 1u : n > 8 ? (uint32_t)DS2I_HIP_MAX_TERMS : (n + 1u) & ~1u; };
-            auto key_of = [&](uint32_t uid) { return cap_of(uid) + (warm[uid] ? KW : 0u); };
             {   // stable partition by capacity, largest first
-                uint32_t cnt[2 * KW] = {};
-                for (uint32_t uid : b->order[c]) ++cnt[key_of(uid)];
-                uint32_t start[2 * KW], acc = 0;
-                for (int n = 2 * KW - 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
+                uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
+                for (uint32_t uid : b->order[c]) ++cnt[cap_of(uid)];
+                uint32_t start[DS2I_HIP_MAX_TERMS + 2], acc = 0;
+                for (int n = DS2I_HIP_MAX_TERMS + 1; n >= 0; --n) { start[n] = acc; acc += cnt[n]; }
                 std::vector<uint32_t>& tmp = b->scratch_u32;
                 tmp.resize(b->order[c].size());
-                for (uint32_t uid : b->order[c]) tmp[start[key_of(uid)]++] = uid;
+                for (uint32_t uid : b->order[c]) tmp[start[cap_of(uid)]++] = uid;
                 b->order[c].swap(tmp);
             }
             for (uint32_t i = 0; i < b->ncls[c];) {
                 uint32_t j = i;
-                const uint32_t kk = key_of(b->order[c][i]), l = kk >= KW ? kk - KW : kk;
-                while (j < b->ncls[c] && key_of(b->order[c][j]) == kk) ++j;
+                const uint32_t l = cap_of(b->order[c][i]);
+                while (j < b->ncls[c] && cap_of(b->order[c][j]) == l) ++j;
                 ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= DS2I_HIP_MAX_TERMS ? l : cls_lists};
                 sl.stream = l >= 2 && l <= DS2I_HIP_MAX_TERMS;
                 b->sub[c].push_back(sl);
@@ -789,15 +730,14 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // kernel compiled for exactly their list count (ranked_stream.hip), one launch group per count, back to back on the
         // class stream; one-term queries and everything else keep the class kernel
         // (the 5..8-term class takes the stream kernel too, up to DS2I_STREAM_NT_MAX lists -- block_optpfor only)
-        static const bool no_rs = std::getenv("DS2I_NO_RANKED_STREAM") != nullptr;
+        const bool no_rs = kn.no_ranked_stream;
         const uint32_t rs_nt = idx->kind == DS2I_BLOCK_OPTPFOR ? rs_stream_nt_max() : 4u;
         // `and` batches that do not ask for the doc-id lists take the same pipeline with AND = true -- a candidate whose hints settle
         // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
-        // verifies every survivor of its filters by a probe). DS2I_NO_AND_RSTREAM=1: the class kernels (A/B).
-        static const bool and_rs = std::getenv("DS2I_NO_AND_RSTREAM") == nullptr;
-        const bool rs_and = base_op == DS2I_OP_AND && and_rs && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
-        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs && !tables_off &&
-                           ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw && !std::getenv("DS2I_NO_SKIPTAB");
+        // verifies every survivor of its filters by a probe).
+        const bool rs_and = base_op == DS2I_OP_AND && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
+        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs &&
+                           ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw;
         if (rs_ok) {
             // launch groups by list CAPACITY 2 | 4 | 6 | 8 (block_optpfor: a group holds the queries of cap - 1 and cap lists, UnitRec::pad says
             // which; block_mixed native: the exact count, 2 .. 4): four groups and four tails per batch instead of seven; queries beyond
@@ -829,8 +769,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             }
             continue;
         }
-        static const bool no_union_stream2 = std::getenv("DS2I_NO_UNION_STREAM") != nullptr;
-        if (union_kernel && !ranked && !no_union_stream2) { // or / or_freq: the streaming kernel serves every list count (lists = ~0 says so)
+        if (union_kernel && !ranked) { // or / or_freq: the streaming kernel serves every list count (lists = ~0 says so)
             b->sub[c].push_back({0u, b->ncls[c], 0xFFFFFFFFu});
             continue;
         }
@@ -858,8 +797,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         }
     }
 
-    static const bool debug_plan = std::getenv("DS2I_DEBUG_PLAN") != nullptr;
-    if (debug_plan)
+    if (kn.unit_clock) // (diagnostic)
         std::fprintf(stderr, "ds2i plan: op %d nq %u units %u (per class %u %u %u %u %u) split queries %u cost %.0f, %.0f us\n", op, nq, b->nunits,
                      b->ncls[0], b->ncls[1], b->ncls[2], b->ncls[3], b->ncls[4], b->nsplit, all_cost,
                      1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - plan_t0).count());
@@ -912,13 +850,11 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // score from below. One- and two-term queries use all their terms (the one-term answer is final); longer
         // queries use their two shortest lists -- the full conjunction of 5+ terms is usually too small to give k
         // documents, while the rarest pair is cheap to intersect and carries the largest term weights.
-        static const char* sv = std::getenv("DS2I_SEED_TERMS");
-        const size_t seed_terms = sv && std::atoi(sv) > 0 ? (size_t)std::atoi(sv) : 2;
+        const size_t seed_terms = 2;
         // The streams (k_union_topk) start from the static floor and share a score histogram per query: measured on the
         // GOV2-scale wand batch the sub-query pass costs 8.3 ms to save 17 % of the block decodes (209 k queries/s with it,
-        // 278 k without), so there only the one-term queries keep it -- it is what answers them. DS2I_SEED_STREAM=1: A/B.
-        static const char* s1 = std::getenv("DS2I_SEED_STREAM");
-        const bool seed_single_only = b->union_stream && !(s1 && std::atoi(s1) > 0);
+        // 278 k without), so there only the one-term queries keep it -- it is what answers them.
+        const bool seed_single_only = b->union_stream;
         auto& sterms = b->seed_terms;
         auto& soffs = b->seed_offs;
         sterms.clear();
@@ -1036,27 +972,15 @@ int launch_batch(ds2i_hip_batch* b) {
     // batch): the block-synchronous conjunctions run 3 % faster when the issue-bound <=2-list class is enqueued first,
     // the disjunctive operators 2.5 % faster when the many-list classes are.
     const int base_op = b->op & 0xFF;
-    static const char* order_env = std::getenv("DS2I_LAUNCH_ORDER"); // "small" / "big": A/B switch
-    bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
+    const bool small_first = !(b->op & DS2I_OP_REFERENCE_ORDER) &&
                        (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND);
-    const bool conj_op = base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ || base_op == DS2I_OP_RANKED_AND;
-    if (order_env) small_first = order_env[0] == 's';
-    static const bool no_skiptab = std::getenv("DS2I_NO_SKIPTAB") != nullptr;
-    static const bool no_bmw_prune = std::getenv("DS2I_NO_BMW_PRUNE") != nullptr;
-    static const bool unit_clock = std::getenv("DS2I_UNIT_CLOCK") != nullptr; // diagnostic: per-unit start / end times
+    const bool unit_clock = ds2i_knobs().unit_clock; // diagnostic: per-unit start / end times
     if (unit_clock && b->instrument) {
         HIP_OK(b->d_clk.reserve(16 * (size_t)(b->nunits ? b->nunits : 1)));
         HIP_OK(hipMemsetAsync(b->d_clk.p, 0, 16 * (size_t)(b->nunits ? b->nunits : 1), idx->s_up));
         HIP_OK(hipStreamSynchronize(idx->s_up));
     }
-    // DS2I_STREAM_SETS=1: consecutive batches alternate between two sets of class streams, so that a class kernel starts
-    // while the tail of the previous batch's kernel of that class is still running. Measured -3 % (the kernels overlap but
-    // each runs longer): off by default.
-    static const char* e_sets = std::getenv("DS2I_STREAM_SETS");
-    static const bool one_set = !(e_sets && std::atoi(e_sets) > 0);
-    b->sset = one_set ? 0 : idx->launch_parity;
-    idx->launch_parity ^= 1;
-    auto cls_stream = [&](int c) { return (b->sset && c < 3 && idx->stream_b[c]) ? idx->stream_b[c] : idx->stream[c]; };
+    auto cls_stream = [&](int c) { return idx->stream[c]; };
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
     for (int c = 0; c < NCLS; ++c) {
         if (!b->ncls[c]) continue;
@@ -1115,18 +1039,15 @@ int launch_batch(ds2i_hip_batch* b) {
             HIP_OK(hipStreamWaitEvent(sm, b->ev_c1[CLS_LONG], 0));
         }
     }
-    // DS2I_GROUP_SPREAD=1: the second and later launch groups of a class go to the streams of classes this batch has no
-    // queries in (no further hardware queues are opened), so that a class stream is not held by its short groups
-    static const char* e_spread = std::getenv("DS2I_GROUP_SPREAD");
-    static const bool spread = e_spread && std::atoi(e_spread) > 0;
-    hipStream_t spare[NCLS];
-    int nspare = 0, next_spare = 0;
-    // Independently of the knob: ranked_and's one-term queries (the class kernel's group of class 0: 0.9 ms behind the two-term stream
+    // Two launch groups leave their class stream for the stream of a class this batch has no queries in (no further hardware queue is
+    // opened; spreading EVERY second group that way was measured and lost): ranked_and's one-term queries (the class kernel's group of class 0: 0.9 ms behind the two-term stream
     // kernel's 2.5 ms on that class's stream) go to a spare stream -- class 0 is one of three co-critical class streams of the step
     const bool side_group0 = base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && b->ncls[0] && b->sub[0].size() > 1 && b->sub[0].front().stream;
     // ... and wand / maxscore / ranked_or's second stream group of the 5-8-list class (capacity 6 behind capacity 8: 3.6 ms behind 7.5 ms)
-    const bool side_group2 = b->union_rstream && b->warm_units.empty() && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
-    if ((spread || side_group0 || side_group2) && !b->sset)
+    hipStream_t spare[NCLS];
+    int nspare = 0, next_spare = 0;
+    const bool side_group2 = b->union_rstream && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
+    if (side_group0 || side_group2)
         for (int c = NCLS - 1; c >= 0; --c)
             if (!b->ncls[c]) {
                 spare[nspare] = idx->stream[c];
@@ -1148,8 +1069,7 @@ int launch_batch(ds2i_hip_batch* b) {
         a.qterms = b->d_up.at<QTerm>(b->o_qterms);
         a.q_off = b->d_up.at<uint32_t>(b->o_qoff);
         a.vq_info = b->union_stream ? b->d_up.at<uint32_t>(b->o_vinfo) : nullptr;
-        static const char* utf = std::getenv("DS2I_UT_FIRST");
-        a.ut_first = utf ? (uint32_t)std::min(15, std::max(0, std::atoi(utf))) : 1u;
+        a.ut_first = 1u;
         a.units = b->d_up.at<Unit>(b->o_units);
         a.order = b->d_up.at<uint32_t>(b->o_order[c]);
         a.urec = (c < 4 && (b->union_rstream || c < rs_stream_classes())) ? b->d_up.at<ds2i_dev::UnitRec>(b->o_urec[c]) : nullptr;
@@ -1177,14 +1097,11 @@ int launch_batch(ds2i_hip_batch* b) {
                        ? b->d_scr.at<unsigned int>(b->o_qfloor) : nullptr;
         a.q_hist_slot = b->d_up.at<uint32_t>(b->o_hslot);
         a.block_profile = (b->instrument && b->profile_on) ? b->prof_ptr : nullptr;
-        a.skip = (no_skiptab && conj_op) ? nullptr : idx->d_skip; // (the union kernels are compiled for the table: they position before they decode)
-        a.bmw = no_bmw_prune ? nullptr : idx->d_bmw;
-        static const bool no_rmw_use = std::getenv("DS2I_NO_RMW_USE") != nullptr; // A/B: tables built but not consulted
-        a.rmw = (no_rmw_use || (base_op == DS2I_OP_RANKED_AND && !a.bmw)) ? nullptr : idx->d_rmw;
-        static const bool no_bm_use = std::getenv("DS2I_NO_BITMAP_USE") != nullptr; // A/B: bitmaps built but not consulted
-        a.rmw_bitmaps = (a.rmw && idx->has_bitmaps && !no_bm_use) ? 1u : 0u;
-        static const bool no_rmh_use = std::getenv("DS2I_NO_RMH_USE") != nullptr; // A/B: hints built but not consulted
-        a.rmh = (a.rmw && !no_rmh_use) ? idx->d_rmh : nullptr;
+        a.skip = idx->d_skip;
+        a.bmw = idx->d_bmw;
+        a.rmw = (base_op == DS2I_OP_RANKED_AND && !a.bmw) ? nullptr : idx->d_rmw;
+        a.rmw_bitmaps = (a.rmw && idx->has_bitmaps) ? 1u : 0u;
+        a.rmh = a.rmw ? idx->d_rmh : nullptr;
         a.xslots = idx->d_xslots;
         a.xovf = idx->d_xovf;
         a.tails = idx->d_tails;
@@ -1206,7 +1123,7 @@ int launch_batch(ds2i_hip_batch* b) {
                 HIP_OK(hipEventCreate(&e));
                 b->ev_g[c].push_back(e);
             }
-            hipStream_t sg = (gi > 0 && nspare && (spread || (c == 0 && side_group0 && !sl.stream) || (c == 2 && side_group2 && gi == 1))) ? spare[next_spare++ % nspare] : s;
+            hipStream_t sg = (gi > 0 && nspare && ((c == 0 && side_group0 && !sl.stream) || (c == 2 && side_group2 && gi == 1))) ? spare[next_spare++ % nspare] : s;
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
                 HIP_OK(b->union_stream ? ds2i_launch_union_stream((int)sl.lists, &a, a.nslice, sg)
@@ -1268,7 +1185,7 @@ int finish_batch(ds2i_hip_batch* b, ds2i_hip_stats* stats) {
     }
     if (b->instrument) HIP_OK(hipMemcpy(b->cls_stats, b->d_stats.p, NCLS * sizeof(Stats), hipMemcpyDeviceToHost));
     else std::memset(b->cls_stats, 0, sizeof(b->cls_stats));
-    if (b->instrument && b->d_clk.p && std::getenv("DS2I_UNIT_CLOCK")) { // diagnostic: where each class kernel's time goes
+    if (b->instrument && b->d_clk.p && ds2i_knobs().unit_clock) { // diagnostic: where each class kernel's time goes
         std::vector<unsigned long long> clk(2 * (size_t)b->nunits);
         HIP_OK(hipMemcpy(clk.data(), b->d_clk.p, 16 * (size_t)b->nunits, hipMemcpyDeviceToHost));
         for (int c = 0; c < NCLS; ++c) {
@@ -1368,33 +1285,12 @@ struct ds2i_hip_pipeline {
     std::vector<char> busy;
     uint64_t next_ticket = 0;
     ds2i_hip_batch* last_waited = nullptr;
-    // The host half of a batch (query normalisation, BM25 query weights, work-unit planning: ~3 ms for 4096 queries at GOV2
-    // scale, ~1 ms at configs[1] scale where the kernels take 1.3 ms) runs on a worker thread OF THE LIBRARY, in ticket
-    // order: submit() copies the query arrays into the slot and returns; the caller's own per-batch work (reading the
-    // query log, collecting results) then overlaps with the planning of the batch it has just handed over, and wait()
-    // blocks first on that batch's launch, then on the device. OFF by default (DS2I_PLAN_THREAD=1 turns it on): measured
-    // on the bench loop it LOSES -- end-to-end / kernel-resident 0.80 -> 0.70 at configs[1] scale, 1.01 -> 0.97 at GOV2
-    // scale: the loop's host time per batch is the planning itself, which was already hidden behind the device as long as
-    // one batch is in flight, and the hand-over adds a wake-up and a copy of the query arrays to every batch. What
-    // would help a host-bound loop is planning one batch on several threads, not planning it elsewhere.
-    struct Job {
-        int op = 0;
-        uint32_t k = 0, nq = 0;
-        std::vector<uint32_t> terms, offs;
-        int state = 0; // 0 free, 1 queued, 2 launched, 3 failed
-        int rc = 0;
-        std::string error;
-    };
-    std::vector<Job> jobs;
-    std::deque<size_t> queue;
-    std::mutex mu;
-    std::condition_variable cv_job, cv_done;
-    std::thread worker;
-    bool stop = false, threaded = false;
+    // (the host half of a batch -- normalisation, BM25 query weights, work-unit planning -- runs on the caller's thread, spread over
+    // DS2I_PLAN_THREADS planning threads; a planner thread OF the pipeline was built in round 4, measured slower, and removed in round 6)
 };
 
 namespace {
-// plan + upload + launch of one slot (caller's thread or the pipeline's worker)
+// plan + upload + launch of one slot
 int pipeline_launch(ds2i_hip_pipeline* p, size_t slot, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq) {
     HIP_OK(hipSetDevice(p->idx->device));
     ds2i_hip_batch* b = p->slots[slot];
@@ -1408,27 +1304,6 @@ int pipeline_launch(ds2i_hip_pipeline* p, size_t slot, int op, uint32_t k, const
         return ds2i_set_error(rc, keep.c_str());
     }
     return DS2I_OK;
-}
-void pipeline_worker(ds2i_hip_pipeline* p) {
-    for (;;) {
-        size_t slot;
-        {
-            std::unique_lock<std::mutex> lk(p->mu);
-            p->cv_job.wait(lk, [&] { return p->stop || !p->queue.empty(); });
-            if (p->queue.empty()) return; // (stop, and nothing left to launch)
-            slot = p->queue.front();
-            p->queue.pop_front();
-        }
-        ds2i_hip_pipeline::Job& j = p->jobs[slot];
-        const int rc = pipeline_launch(p, slot, j.op, j.k, j.terms.data(), j.offs.data(), j.nq);
-        {
-            std::lock_guard<std::mutex> lk(p->mu);
-            j.rc = rc;
-            if (rc) j.error = ds2i_get_error(); // (thread-local in this thread: handed to the thread that waits)
-            j.state = rc ? 3 : 2;
-        }
-        p->cv_done.notify_all();
-    }
 }
 } // namespace
 
@@ -1627,24 +1502,12 @@ int ds2i_hip_pipeline_create(ds2i_hip_index* idx, uint32_t depth, ds2i_hip_pipel
     }
     p->slot_ticket.assign(depth, 0);
     p->busy.assign(depth, 0);
-    p->jobs.resize(depth);
-    const char* pt = std::getenv("DS2I_PLAN_THREAD");
-    p->threaded = pt && std::atoi(pt) > 0;
-    if (p->threaded) p->worker = std::thread(pipeline_worker, p);
     *out = p;
     return DS2I_OK;
 }
 
 void ds2i_hip_pipeline_destroy(ds2i_hip_pipeline* p) {
     if (!p) return;
-    if (p->threaded) {
-        {
-            std::lock_guard<std::mutex> lk(p->mu);
-            p->stop = true;
-        }
-        p->cv_job.notify_all();
-        if (p->worker.joinable()) p->worker.join(); // (finishes the launches already queued: their slots are drained below)
-    }
     for (auto* b : p->slots) ds2i_batch_destroy(b);
     delete p;
 }
@@ -1654,38 +1517,9 @@ int ds2i_hip_pipeline_submit(ds2i_hip_pipeline* p, int op, uint32_t k, const uin
     if (!p || !ticket) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_submit: null argument");
     const size_t slot = (size_t)(p->next_ticket % p->slots.size());
     if (p->busy[slot]) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_pipeline_submit: all slots in flight; wait for the oldest ticket first");
-    if (!p->threaded) {
+    {
         int rc = pipeline_launch(p, slot, op, k, terms, query_offsets, nq);
         if (rc) return rc; // the slot stays free
-    } else {
-        // what the caller can be told at once is checked at once (the same checks plan_batch makes, in the same order);
-        // device-side failures of the launch surface in wait()
-        if (!query_offsets || (!terms && nq && query_offsets[nq] > 0)) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");
-        const int base_op = op & 0xFF;
-        if (base_op < DS2I_OP_AND || base_op > DS2I_OP_RANKED_OR || (op & ~(0xFF | DS2I_OP_REFERENCE_ORDER | DS2I_OP_NO_COUNTERS)))
-            return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: unknown query operator");
-        const bool ranked = base_op >= DS2I_OP_RANKED_AND;
-        if (ranked && !p->idx->has_wand) return ds2i_set_error(DS2I_ENOWAND, "ranked operator needs wand data");
-        if (ranked && (k == 0 || k > DS2I_HIP_MAX_K_LONG)) return ds2i_set_error(DS2I_EINVAL, "k must be in [1, DS2I_HIP_MAX_K_LONG]");
-        for (uint32_t q = 0; q < nq; ++q)
-            if (query_offsets[q + 1] < query_offsets[q]) return ds2i_set_error(DS2I_EINVAL, "query_offsets must be non-decreasing");
-        const uint32_t nterms = nq ? query_offsets[nq] : 0;
-        for (uint32_t i = nq ? query_offsets[0] : 0; i < nterms; ++i)
-            if (terms[i] >= p->idx->size) return ds2i_set_error(DS2I_ETERM, "term id out of range");
-        ds2i_hip_pipeline::Job& j = p->jobs[slot];
-        j.op = op;
-        j.k = k;
-        j.nq = nq;
-        j.offs.assign(query_offsets, query_offsets + nq + 1);
-        j.terms.assign(terms, terms + nterms);
-        if (j.terms.empty()) j.terms.push_back(0);
-        {
-            std::lock_guard<std::mutex> lk(p->mu);
-            j.state = 1;
-            j.rc = 0;
-            p->queue.push_back(slot);
-        }
-        p->cv_job.notify_one();
     }
     p->busy[slot] = 1;
     p->slot_ticket[slot] = p->next_ticket;
@@ -1699,20 +1533,9 @@ int ds2i_hip_pipeline_wait(ds2i_hip_pipeline* p, uint64_t ticket, uint64_t* out_
     const size_t slot = (size_t)(ticket % p->slots.size());
     if (!p->busy[slot] || p->slot_ticket[slot] != ticket)
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_pipeline_wait: unknown or already collected ticket");
-    if (p->threaded) { // first the launch (planning + upload + kernels enqueued) ...
-        std::unique_lock<std::mutex> lk(p->mu);
-        ds2i_hip_pipeline::Job& j = p->jobs[slot];
-        p->cv_done.wait(lk, [&] { return j.state != 1; });
-        if (j.state == 3) {
-            p->busy[slot] = 0;
-            j.state = 0;
-            return ds2i_set_error(j.rc, j.error.c_str());
-        }
-        j.state = 0;
-    }
     HIP_OK(hipSetDevice(p->idx->device));
     ds2i_hip_batch* b = p->slots[slot];
-    int rc = finish_batch(b, stats); // ... then the device
+    int rc = finish_batch(b, stats);
     p->busy[slot] = 0;
     if (rc) return rc;
     p->last_waited = b;

@@ -3,7 +3,7 @@
 oracle: counts of random and adversarial conjunctions over random collections -- short and long lists paired (ranges wider than 254 doc-ids: the hint is
 no proof there), dense lists (one doc-id per table entry), clustered lists (several postings per range: hint 255), whole queries and queries split into
 parts, one-term queries. Run as a subprocess by tests/test_gpu.py (the library's knobs are read once per process):
-`[DS2I_UNIT_CAP=8 | DS2I_NO_RMH=1 | DS2I_RMW_G=1 | DS2I_NO_AND_RSTREAM=1] python tests/and_stream_probe.py [seeds]`. The oracle is the checker here, nothing else."""
+`[DS2I_UNIT_CAP=8 | DS2I_NO_RMH=1 | DS2I_RMW_G=1 | DS2I_NO_RANKED_STREAM=1] python tests/and_stream_probe.py [seeds]`. The oracle is the checker here, nothing else."""
 import os
 import sys
 
@@ -49,7 +49,7 @@ def one(seed):
     pc, _, _ = pipe.wait(t)
     pipe.close()
     assert np.array_equal(pc, oc), (seed, "pipelined")
-    if not os.environ.get("DS2I_NO_AND_RSTREAM"):
+    if not os.environ.get("DS2I_NO_RANKED_STREAM"):
         assert streamed, "the stream kernel did not run"
     print("seed %d: %d docs, %d terms, %d queries (%d non-empty, %d results), stream groups for %s lists: counts equal the oracle's" %
           (seed, nd, nt, len(qs), int((oc > 0).sum()), int(oc.sum()), sorted(streamed)))

@@ -155,26 +155,32 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     assert seen == 4
 
 
-def test_documented_knobs_exist_in_the_source():
-    """DESIGN.md section 7c lists the environment knobs of the library: every name in that table must be read somewhere in
-    the product sources (a renamed or removed knob would otherwise stay documented, and an A/B reported against it would
-    silently have compared a build with itself)."""
+def test_documented_knobs_are_the_knobs_of_the_library():
+    """DESIGN.md section 7 lists the environment knobs of the library; capi.cpp reads them in one place (ds2i_knobs) from one table
+    (kKnobs, which is also what ds2i_hip_set_option accepts) and knobs.hpp declares them: the three lists are the same twenty names,
+    and no product source reads the environment anywhere else (a renamed or removed knob would otherwise stay documented, and an
+    A/B reported against it would silently have compared a build with itself)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = open(os.path.join(root, "DESIGN.md")).read()
-    a, b = doc.index("## 7c. Tuning knobs"), doc.index("## 8. Out of scope")
-    names = sorted(set(re.findall(r"`(DS2I_[A-Z0-9_]+|GPU_MAX_HW_QUEUES)", doc[a:b])))
-    assert len(names) >= 20
-    src = ""
+    a, b = doc.index("## 7. Knobs"), doc.index("## 8. Out of scope")
+    documented = set(re.findall(r"`(DS2I_[A-Z0-9_]+)`", doc[a:b])) - {"DS2I_BUILD_VARIANT"}
     csrc = os.path.join(root, "ds2i_amd", "csrc")
+    capi = open(os.path.join(csrc, "capi.cpp")).read()
+    table = set(re.findall(r'"(DS2I_[A-Z0-9_]+)"', capi[capi.index("kKnobs[] = {"):capi.index("};", capi.index("kKnobs[] = {"))]))
+    header = set(re.findall(r"// (DS2I_[A-Z0-9_]+):", open(os.path.join(csrc, "knobs.hpp")).read()))
+    assert documented == table == header, (documented ^ table, table ^ header)
+    assert len(table) == 20
+    sites = []
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".cpp", ".hip", ".hpp")):
-            src += open(os.path.join(csrc, f), errors="replace").read()
-    missing = [n for n in names if n not in src]
-    assert not missing, missing
+            for i, line in enumerate(open(os.path.join(csrc, f), errors="replace")):
+                if "getenv(" in line and "LOCAL_WORLD_SIZE" not in line:
+                    sites.append((f, i + 1))
+    assert len(sites) == 1 and sites[0][0] == "capi.cpp", sites
 
 
 def test_set_option_accepts_knobs_only(built_lib):
-    """ds2i_hip_set_option: the C-ABI way to set a DESIGN.md 7c knob (process-wide, before the first batch)"""
+    """ds2i_hip_set_option: the C-ABI way to set a DESIGN.md section 7 knob (process-wide, before the first upload)"""
     ds2i_amd.set_option("DS2I_UNIT_FACTOR", 4)
     assert os.environ.get("DS2I_UNIT_FACTOR") is None or True  # (setenv in the C library: not mirrored in os.environ)
     ds2i_amd.set_option("DS2I_UNIT_FACTOR", None)

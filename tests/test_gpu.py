@@ -1145,22 +1145,16 @@ def _run_bench(extra, nproc=1, env_extra=None, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_BMW_PRUNE=1", "DS2I_NO_SKIPTAB=1", "DS2I_DYN_GROUP=0", "DS2I_DYN_GROUP=1",
-                                  "DS2I_NO_RMW=1", "DS2I_NO_RMW_USE=1", "DS2I_RMW_G=1", "DS2I_NO_BITMAPS=1", "DS2I_NO_BITMAP_USE=1",
-                                  "DS2I_NO_UNION_STREAM=1", "DS2I_UNIT_FACTOR=64", "DS2I_NO_TOPK_STREAM=1", "DS2I_UT_BLOCKS=1",
-                                  "DS2I_SEED_STREAM=1", "DS2I_UT_FIRST=0", "DS2I_UT_FIRST=3",
-                                  "DS2I_NO_RANKED_STREAM=1", "DS2I_NO_RMH=1", "DS2I_NO_RMH_USE=1", "DS2I_STREAM_SETS=1", "DS2I_UNIT_CAP=8",
-                                  "DS2I_LOOKUP_WEIGHT=0", "DS2I_UNIT_DIV_MANY=1", "DS2I_STREAM_NT_MAX=4"])
+@pytest.mark.parametrize("knob", ["DS2I_NO_BMW=1", "DS2I_NO_RMW=1", "DS2I_RMW_G=1", "DS2I_NO_BITMAPS=1", "DS2I_NO_RMH=1", "DS2I_UNIT_FACTOR=64",
+                                  "DS2I_UT_BLOCKS=1", "DS2I_NO_RANKED_STREAM=1", "DS2I_NO_UNION_RSTREAM=1", "DS2I_NO_LIST_STREAMS=1"])
 def test_alternative_paths_give_the_same_results(built_lib, knob):
-    """The library reads its A/B knobs once per process, so each alternative path -- no block-max table, table present but
-    unused, no interleaved skip table (= no list-0 stream), union kernels without / with exact dynamic-LDS groups, no
-    range tables / tables unused / coarse tables, no dense-list bitmaps / bitmaps unused, or_query through the windowed
-    kernel, very fine work units (many parts per query), wand / maxscore / ranked_or through the windowed kernel, their streams
-    cut to one block per unit, seeded by the ranked_and sub-query pass, and gathering the range-table bytes in one trip / with
-    three optional lists in the first of two, ranked_and through the class kernels instead of the pipelined stream kernel,
-    no membership hints / hints unused, two alternating sets of class streams, units capped at 8 blocks, the planner's
-    lookup pricing off, the 9-16-term class not cut finer, the 5-8-term class of ranked_and through k_conjunctive instead of k_ranked_stream<5..8> -- is driven through one fuzz collection (every codec, k,
-    operator; oracle-checked) in a process of its own."""
+    """The library reads its knobs once per process (knobs.hpp), so each alternative path -- an upload without block-max weights (no
+    tables at all), without range tables (wand / maxscore through the windowed k_disjunctive), with coarse tables, without the dense
+    lists' bitmaps, without membership hints; very fine work units (many parts per query); wand / maxscore / ranked_or streams cut to
+    one block per unit; ranked_and / and through the class kernels instead of k_ranked_stream; wand / maxscore / ranked_or through
+    k_union_topk instead of k_union_stream; or_freq / and / and_freq without the list streams -- is driven through one fuzz collection
+    (every codec, k, operator; oracle-checked) in a process of its own. (Rounds 2-5 kept 25 such switches alive; the ones whose
+    alternative lost twice were removed in round 6 together with what only they reached.)"""
     import os, subprocess, sys
     env = dict(os.environ)
     k, v = knob.split("=")
@@ -1187,12 +1181,12 @@ def test_ranked_stream_5_to_8_lists_behind_its_knob(built_lib, extra):
     assert r.returncode == 0 and "rs_nt8_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8", "DS2I_NO_RMH=1", "DS2I_RMW_G=1", "DS2I_NO_AND_RSTREAM=1"])
+@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8", "DS2I_NO_RMH=1", "DS2I_RMW_G=1", "DS2I_NO_RANKED_STREAM=1"])
 def test_and_through_the_stream_pipeline(built_lib, extra):
     """and_query (queries.hpp:35-86) counts through k_ranked_stream<n, ., AND> (the default for `and` batches that do not ask for the
     doc-id lists): candidates whose membership hints settle every other list are counted without a search or a decode of those lists;
     one-term queries are list streams (k_and_stream). Counts equal the oracle's -- whole and split queries, an upload without hints
-    (every survivor probed), coarse tables (ranges too wide for the hint to be proof), and the class kernels behind DS2I_NO_AND_RSTREAM."""
+    (every survivor probed), coarse tables (ranges too wide for the hint to be proof), and the class kernels behind DS2I_NO_RANKED_STREAM."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
@@ -1202,6 +1196,24 @@ def test_and_through_the_stream_pipeline(built_lib, extra):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "and_stream_probe.py"), "1", "2", "3"], env=env, capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "and_rstream_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("extra", ["", "DS2I_NO_RMH=1", "DS2I_RMW_G=1", "DS2I_UT_BLOCKS=8", "DS2I_NO_UNION_RSTREAM=1"])
+def test_union_through_the_stream_pipeline(built_lib, extra):
+    """wand / maxscore / ranked_or (queries.hpp:200-319, 478-591, 404-476) through k_union_stream<cap> (union_stream.hip; the default on
+    block_optpfor with every table): queries of 2..16 terms over random collections, k = 10 and 37 -- top-k lengths equal the oracle's,
+    scores within 1e-5, wand == maxscore == ranked_or bit for bit, one-shot == pipelined; an upload without hints (exclusion lists
+    looked up), coarse tables (ranges too wide for a hint to be proof), units of 8 blocks (many parts per driving list sharing one
+    floor), and k_union_topk behind DS2I_NO_UNION_RSTREAM."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if extra:
+        k, v = extra.split("=")
+        env[k] = v
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "union_stream_probe.py"), "1", "2"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0 and "union_stream_probe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_bench_two_ranks_on_one_device(built_lib):
