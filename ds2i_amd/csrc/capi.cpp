@@ -277,15 +277,16 @@ static uint64_t range_table_bytes_at(const ds2i_hip_index* x, double G) {
 // DS2I_TABLE_BUDGET in bytes ("<bytes>" or "<factor>x" of the CALLER's image -- for a transcoded upload the image handed to
 // ds2i_hip_index_open, not its re-encoded form), 0 = none
 static uint64_t table_budget_bytes(size_t image_bytes) {
-    const char* eb = ds2i_knobs().table_budget;
-    if (!eb || !*eb) return 0;
+    const Ds2iKnobs kn = ds2i_knobs();
+    const char* eb = kn.table_budget;
+    if (!*eb) return 0;
     char* end = nullptr;
     const double v = std::strtod(eb, &end);
     if (!(v > 0)) return 0;
     return (end && (*end == 'x' || *end == 'X')) ? (uint64_t)(v * (double)image_bytes) : (uint64_t)v;
 }
 static void choose_table_plan(ds2i_hip_index* x, size_t image_bytes) {
-    const Ds2iKnobs& kn = ds2i_knobs();
+    const Ds2iKnobs kn = ds2i_knobs();
     x->plan_g = kn.rmw_g;
     if (!(x->plan_g > 0) || kn.no_rmw) x->plan_g = 0;
     x->plan_hints = !kn.no_rmh;
@@ -427,46 +428,54 @@ const char* ds2i_hip_last_error(void) { return ds2i_get_error(); }
 // before the runtime initialises; an explicit setting of the user wins.
 __attribute__((constructor)) static void ds2i_hip_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
-// The knobs (knobs.hpp) are read once, by the first ds2i_hip_index_open or the first batch; setting one afterwards would be silently
-// ignored, so it is refused.
-static std::atomic<bool> g_ds2i_knobs_read{false};
+// The knobs (knobs.hpp) are read from the environment by every ds2i_hip_index_open -- the one place the library reads it -- and hold
+// for that index and for every batch planned until the next upload; ds2i_hip_set_option sets one without the environment.
 namespace {
 const char* const kKnobs[] = {"DS2I_RMW_G", "DS2I_NO_RMW", "DS2I_NO_RMH", "DS2I_NO_BITMAPS", "DS2I_NO_BMW", "DS2I_NO_XSLOTS", "DS2I_RMW_REQUIRE", "DS2I_MIXED_NATIVE",
                               "DS2I_PEF_NATIVE", "DS2I_TABLE_BUDGET", "DS2I_PLAN_THREADS", "DS2I_UNIT_FACTOR", "DS2I_UNIT_CAP", "DS2I_UT_BLOCKS", "DS2I_STREAM_NT_MAX",
                               "DS2I_NO_RANKED_STREAM", "DS2I_NO_UNION_RSTREAM", "DS2I_NO_LIST_STREAMS", "DS2I_DECODE_GENERAL", "DS2I_UNIT_CLOCK"};
+Ds2iKnobs g_knobs{};
+std::mutex g_knobs_mu;
+bool g_knobs_loaded = false;
+void load_knobs_locked() {
+    auto env = [](const char* n) -> const char* { return std::getenv(n); }; // (the one place the library reads its knobs)
+    auto on = [&](const char* n) { return env(n) != nullptr; };
+    auto num = [&](const char* n, double dflt) { const char* e = env(n); return e && std::atof(e) > 0 ? std::atof(e) : dflt; };
+    Ds2iKnobs v{};
+    v.rmw_g_set = on("DS2I_RMW_G");
+    v.rmw_g = v.rmw_g_set ? std::atof(env("DS2I_RMW_G")) : 4.0;
+    v.no_rmw = on("DS2I_NO_RMW");
+    v.no_rmh = on("DS2I_NO_RMH");
+    v.no_bitmaps = on("DS2I_NO_BITMAPS");
+    v.no_bmw = on("DS2I_NO_BMW");
+    v.no_xslots = on("DS2I_NO_XSLOTS");
+    v.rmw_require = on("DS2I_RMW_REQUIRE");
+    v.mixed_native = on("DS2I_MIXED_NATIVE");
+    v.pef_native = on("DS2I_PEF_NATIVE");
+    if (env("DS2I_TABLE_BUDGET")) std::snprintf(v.table_budget, sizeof v.table_budget, "%s", env("DS2I_TABLE_BUDGET"));
+    v.plan_threads = (unsigned)num("DS2I_PLAN_THREADS", 0);
+    v.unit_factor = num("DS2I_UNIT_FACTOR", 0);
+    v.unit_cap = (uint32_t)num("DS2I_UNIT_CAP", 0);
+    v.ut_blocks = (uint32_t)num("DS2I_UT_BLOCKS", 320);
+    v.stream_nt_max = (uint32_t)std::min(8.0, std::max(2.0, num("DS2I_STREAM_NT_MAX", 8)));
+    v.no_ranked_stream = on("DS2I_NO_RANKED_STREAM");
+    v.no_union_rstream = on("DS2I_NO_UNION_RSTREAM");
+    v.no_list_streams = on("DS2I_NO_LIST_STREAMS");
+    v.decode_general = on("DS2I_DECODE_GENERAL");
+    v.unit_clock = on("DS2I_UNIT_CLOCK");
+    g_knobs = v;
+    g_knobs_loaded = true;
+}
 }
 
-extern "C++" const Ds2iKnobs& ds2i_knobs() {
-    static const Ds2iKnobs k = [] {
-        g_ds2i_knobs_read.store(true);
-        auto env = [](const char* n) -> const char* { return std::getenv(n); }; // (the one place the library reads its knobs)
-        auto on = [&](const char* n) { return env(n) != nullptr; };
-        auto num = [&](const char* n, double dflt) { const char* e = env(n); return e && std::atof(e) > 0 ? std::atof(e) : dflt; };
-        Ds2iKnobs v{};
-        v.rmw_g_set = on("DS2I_RMW_G");
-        v.rmw_g = v.rmw_g_set ? std::atof(env("DS2I_RMW_G")) : 4.0;
-        v.no_rmw = on("DS2I_NO_RMW");
-        v.no_rmh = on("DS2I_NO_RMH");
-        v.no_bitmaps = on("DS2I_NO_BITMAPS");
-        v.no_bmw = on("DS2I_NO_BMW");
-        v.no_xslots = on("DS2I_NO_XSLOTS");
-        v.rmw_require = on("DS2I_RMW_REQUIRE");
-        v.mixed_native = on("DS2I_MIXED_NATIVE");
-        v.pef_native = on("DS2I_PEF_NATIVE");
-        v.table_budget = env("DS2I_TABLE_BUDGET");
-        v.plan_threads = (unsigned)num("DS2I_PLAN_THREADS", 0);
-        v.unit_factor = num("DS2I_UNIT_FACTOR", 0);
-        v.unit_cap = (uint32_t)num("DS2I_UNIT_CAP", 0);
-        v.ut_blocks = (uint32_t)num("DS2I_UT_BLOCKS", 320);
-        v.stream_nt_max = (uint32_t)std::min(8.0, std::max(2.0, num("DS2I_STREAM_NT_MAX", 8)));
-        v.no_ranked_stream = on("DS2I_NO_RANKED_STREAM");
-        v.no_union_rstream = on("DS2I_NO_UNION_RSTREAM");
-        v.no_list_streams = on("DS2I_NO_LIST_STREAMS");
-        v.decode_general = on("DS2I_DECODE_GENERAL");
-        v.unit_clock = on("DS2I_UNIT_CLOCK");
-        return v;
-    }();
-    return k;
+extern "C++" Ds2iKnobs ds2i_knobs() {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs_loaded) load_knobs_locked();
+    return g_knobs;
+}
+static void ds2i_reload_knobs() {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    load_knobs_locked();
 }
 
 int ds2i_hip_set_option(const char* name, const char* value) {
@@ -476,7 +485,6 @@ int ds2i_hip_set_option(const char* name, const char* value) {
     bool known = false;
     for (const char* k : kKnobs) known = known || std::strcmp(k, name) == 0;
     if (!known) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_set_option: unknown knob (DESIGN.md 7 lists them)");
-    if (g_ds2i_knobs_read.load()) return ds2i_set_error(DS2I_EBUSY, "ds2i_hip_set_option: the knobs have been read already (set them before the first upload)");
     if (value) setenv(name, value, 1); else unsetenv(name);
     return DS2I_OK;
 }
@@ -588,7 +596,7 @@ int ds2i_hip_index_open(int device, int kind, const void* index_image, size_t in
     if (!out || !index_image) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: null argument");
     if (kind < DS2I_BLOCK_OPTPFOR || kind > DS2I_UNIFORM) return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_index_open: unknown index kind");
     if (device < 0 || device >= ds2i_hip_device_count()) return ds2i_set_error(DS2I_EDEVICE, "ds2i_hip_index_open: no such HIP device");
-    // (the knobs are read -- once -- by the first upload that has a device to go to)
+    ds2i_reload_knobs(); // (every upload re-reads the knobs: they hold for this index and the batches planned until the next upload)
     const bool transcode = (kind == DS2I_BLOCK_MIXED && !ds2i_knobs().mixed_native) ||
                            (kind >= DS2I_OPT && kind <= DS2I_UNIFORM && !ds2i_knobs().pef_native);
     if (transcode) {

@@ -257,7 +257,7 @@ int plan_batch(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, con
 static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t* terms, const uint32_t* query_offsets, uint32_t nq,
                            int want_matches) {
     ds2i_hip_index* idx = b->idx;
-    const Ds2iKnobs& kn = ds2i_knobs(); // (read once per process: knobs.hpp)
+    const Ds2iKnobs kn = ds2i_knobs(); // (as the last upload read them: knobs.hpp)
     const auto plan_t0 = std::chrono::steady_clock::now();
     if (!query_offsets || (!terms && nq && query_offsets[nq] > 0))
         return ds2i_set_error(DS2I_EINVAL, "ds2i_hip_batch_prepare: null argument");

@@ -1,6 +1,6 @@
 // Every environment knob of libds2i_hip.so, read in ONE place (capi.cpp: ds2i_knobs). Twenty of them: what an upload builds, how a
-// batch is cut and which kernel family answers it, diagnostics. Read once per process, on the first ds2i_hip_index_open or the first
-// batch, whichever comes first; ds2i_hip_set_option(name, value) sets one without the environment and fails with DS2I_EBUSY afterwards.
+// batch is cut and which kernel family answers it, diagnostics. (Re-)read by every ds2i_hip_index_open; they hold for that index and for
+// the batches planned until the next upload. ds2i_hip_set_option(name, value) sets one without the environment.
 // (Rounds 2-5 accumulated fifty A/B switches; the ones whose alternative lost twice are gone together with what only they reached --
 // CHANGELOG.md has the measurements.)
 #pragma once
@@ -8,7 +8,7 @@
 
 struct Ds2iKnobs {
     // ---- upload (ds2i_hip_index_open)
-    double rmw_g;        // DS2I_RMW_G: range-table entries per posting, a power of two (default 2; 4 was round 3-5's default at +10 GB)
+    double rmw_g;        // DS2I_RMW_G: range-table entries per posting, a power of two (default 4; 2 = 10 GB less at GOV2 scale, -4 % ranked_and, -8 % wand)
     bool rmw_g_set;      //   ... set explicitly (a DS2I_TABLE_BUDGET then does not override it)
     bool no_rmw;         // DS2I_NO_RMW: no doc-id-range tables (ranked kernels fall back to block-max pruning only; wand to k_disjunctive)
     bool no_rmh;         // DS2I_NO_RMH: no membership hints
@@ -18,7 +18,7 @@ struct Ds2iKnobs {
     bool rmw_require;    // DS2I_RMW_REQUIRE: an upload that cannot afford its tables fails (DS2I_ENOMEM) instead of running without
     bool mixed_native;   // DS2I_MIXED_NATIVE: block_mixed images are queried as they are (no transcoding at upload)
     bool pef_native;     // DS2I_PEF_NATIVE: opt / ef / single / uniform images are queried as they are
-    const char* table_budget; // DS2I_TABLE_BUDGET: "<bytes>" or "<factor>x" (of the caller's image), or null
+    char table_budget[32];    // DS2I_TABLE_BUDGET: "<bytes>" or "<factor>x" (of the caller's image); empty = none
     // ---- batches (planner / launcher)
     unsigned plan_threads;    // DS2I_PLAN_THREADS: host threads planning a batch (0 = default: up to 4, the process's CPU share)
     double unit_factor;       // DS2I_UNIT_FACTOR: work units per resident wave (0 = default per operator)
@@ -31,4 +31,4 @@ struct Ds2iKnobs {
     bool decode_general;      // DS2I_DECODE_GENERAL: ds2i_hip_decode_list through the on-disk decoders although side slots exist
     bool unit_clock;          // DS2I_UNIT_CLOCK: instrumented runs record every unit's start / end and print where a class's time went
 };
-const Ds2iKnobs& ds2i_knobs();
+Ds2iKnobs ds2i_knobs(); // (a copy: an upload on another thread may be re-reading them)

@@ -146,6 +146,14 @@ DS2I_DEV void rs_fetch_word(const unsigned int* g, uint32_t lds) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(0u), "s"(g), "s"(uniform(lds)) : "memory");
 }
+// (i'') the same through this CU's L1: a stale copy is a LOWER floor, which is still a valid one (floors only rise), and the L1 of a CU
+// running these kernels turns over within microseconds -- thousands of waves polling one word per query past the L1 every block made
+// the word's L2 line the slowest load of every prefetch group
+DS2I_DEV void rs_fetch_word_cached(const unsigned int* g, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(0u), "s"(g), "s"(uniform(lds)) : "memory");
+}
 // (ii) range-table bytes: LDS-DMA as well -- tab[off] of every lane lands, zero-extended, in the dword at LDS byte offset
 // lds + 4 * lane (measured with the same probe). A hand-issued load into a VGPR is not an option: for the compiler the
 // destination is written when the statement ends, and under register pressure it did copy the still-pending register

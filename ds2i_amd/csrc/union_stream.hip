@@ -309,7 +309,11 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                 const uint8_t* const g = rs_uniform_ptr(data0 + N.ep); // (full blocks of a block_optpfor list are dword aligned; a partial last block is not read from here)
                 rs_prefetch_blk((const uint8_t*)((uintptr_t)g & ~(uintptr_t)3), st_base + bufN * (STAGE_DW * 4u), rs_uniform_ptr(xs0 + (size_t)XSLOT_DW * N.blk),
                                 xs_base + bufN * (XSLOT_DW * 4u), voff);
+#ifdef DS2I_US_FW_SC1
                 if (shared_floor) rs_fetch_word(fwp, fw_base);
+#else
+                if (shared_floor) rs_fetch_word_cached(fwp, fw_base);
+#endif
             }
             PT(PH_STREAM);
             if (haveA) {

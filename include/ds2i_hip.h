@@ -93,10 +93,10 @@ typedef struct ds2i_hip_stats {
 } ds2i_hip_stats;
 
 int ds2i_hip_device_count(void);
-/* Tuning knobs without the environment: name = one of the documented DS2I_* variables, value = what the
- * variable would hold (NULL = unset). Process-wide like the variables themselves, and read once: knobs that the upload reads
- * must be set before ds2i_hip_index_open, the others before the first batch is planned -- afterwards the call fails with
- * DS2I_EBUSY. Unknown names fail with DS2I_EINVAL. */
+/* Tuning knobs without the environment: name = one of the twenty documented DS2I_*
+ * variables, value = what the variable would hold (NULL = unset). Process-wide like the variables themselves; every
+ * ds2i_hip_index_open re-reads them, and they hold for that index and the batches planned until the next upload. Unknown names
+ * fail with DS2I_EINVAL. */
 int ds2i_hip_set_option(const char* name, const char* value);
 const char* ds2i_hip_last_error(void);
 

@@ -200,11 +200,11 @@ def test_table_budget(coll, queries, images, budget, monkeypatch):
 def test_decode_list_through_both_decoders(coll, images, monkeypatch):
     """ds2i_hip_decode_list on an index WITH side slots: the slot decoder (default) and, with DS2I_DECODE_GENERAL=1, the
     decoder of the on-disk bytes -- the same postings both ways"""
-    idx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])
-    assert idx.info()["has_side_tables"]
     for general in (False, True):
         if general:
             monkeypatch.setenv("DS2I_DECODE_GENERAL", "1")
+        idx = d.Index("block_optpfor", images[0]["block_optpfor"], images[1])  # (the knobs are read by the upload)
+        assert idx.info()["has_side_tables"]
         for t, (docs, freqs) in enumerate(coll.lists):
             dd, ff = idx[t]
             assert np.array_equal(dd, docs) and np.array_equal(ff, freqs), (general, t)
