@@ -39,7 +39,7 @@ hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned 
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
 hipError_t ds2i_launch_freq_stream(const void* args, unsigned longest, unsigned nqterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_and_stream(const void* args, int with_freqs, unsigned longest, unsigned nterms, hipStream_t s); // freq_stream.hip
-hipError_t ds2i_launch_and_rstream(int nt, const void* args, unsigned grid, hipStream_t s);       // ranked_stream.hip (AND = true)
+hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, unsigned grid, hipStream_t s);       // ranked_stream.hip (AND = true)
 hipError_t ds2i_launch_union_stream(int nt, const void* args, unsigned grid, hipStream_t s);     // union_stream.hip (wand / maxscore / ranked_or)
 hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
@@ -491,7 +491,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                              idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams;
     const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps;
     const uint32_t and_unit_blocks = 96u; // (measured: 48: 965 k, 96: 1 068 k queries/s; whole queries: 802 k)
-    const bool and_rs_units = base_op == DS2I_OP_AND && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
+    const bool and_rs_units = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
                               idx->d_bmw && idx->d_rmw && !kn.no_ranked_stream;
     b->sterms.clear();
     b->sterm_longest = 0;
@@ -735,7 +735,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // `and` batches that do not ask for the doc-id lists take the same pipeline with AND = true -- a candidate whose hints settle
         // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
         // verifies every survivor of its filters by a probe).
-        const bool rs_and = base_op == DS2I_OP_AND && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
+        const bool rs_and = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
         const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw;
         if (rs_ok) {
@@ -1127,7 +1127,7 @@ int launch_batch(ds2i_hip_batch* b) {
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
                 HIP_OK(b->union_stream ? ds2i_launch_union_stream((int)sl.lists, &a, a.nslice, sg)
-                       : base_op == DS2I_OP_AND ? ds2i_launch_and_rstream((int)sl.lists, &a, a.nslice, sg)
+                       : (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) ? ds2i_launch_and_rstream((int)sl.lists, base_op == DS2I_OP_AND_FREQ ? 1 : 0, &a, a.nslice, sg)
                        : idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
             else HIP_OK(ds2i_launch_batch(b->freq_stream ? (int)DS2I_OP_OR : (b->op & (0xFF | DS2I_OP_REFERENCE_ORDER)), c, &a, a.nslice, sg));
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));

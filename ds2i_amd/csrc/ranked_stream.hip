@@ -75,8 +75,12 @@ struct LdsRS {
 // a result iff every other list holds it. The membership hints settle that exactly wherever a range holds one posting and is at
 // most 254 doc-ids wide (rmh_code is injective there): such a candidate is counted without list j ever being searched or decoded;
 // only candidates in ranges with several postings (hint 255), in wider ranges, or of an upload without hints are probed.
-template <int NT, bool STATS, bool AND = false>
+// FREQS (with AND): and_query<with_freqs> -- the freq of every list is touched for every document of the intersection (queries.hpp:62-84;
+// here: summed into the query's checksum). The hints still rule out every candidate that is in no intersection without a search; what
+// passes them is looked up in every list (a member's freq is in that list's block), list 0's freq came with its doc-id.
+template <int NT, bool STATS, bool AND = false, bool FREQS = false>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
+    static_assert(AND || !FREQS, "FREQS is a variant of AND");
     static_assert(NT >= 2 && NT <= 8, "list capacities 2..8");
     static_assert((NT - 2) * 9 + 8 < 64, "the per-list constants of lists 1.. are parked in the lanes of one VGPR");
     __shared__ LdsRS<NT> L;
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         TopK tk;
         tk.init(a->k);
         unsigned long long and_count = 0; // (AND: results of this unit)
+        unsigned long long and_fsum = 0;  // (FREQS: this lane's share of the unit's freq checksum)
         // ---- list 0: the stream
         const uint32_t n0 = uniform(qt[0].n), nb0 = (n0 + 127u) >> 7;
         const uint32_t vl0 = 1u + (n0 >= (1u << 7)) + (n0 >= (1u << 14)) + (n0 >= (1u << 21)) + (n0 >= (1u << 28));
@@ -350,6 +355,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 if constexpr (!AND) {
                     boA0 = qw0 * rs_dtw_bound(fv0 + 1u, min_nl);
                     boA1 = qw0 * rs_dtw_bound(fv1 + 1u, min_nl);
+                }
+                if constexpr (!AND || FREQS) {
                     L.stage[bufA][lane] = fv0 + 1u; // (same lanes write and read: no fence needed before stage C's read an iteration later)
                     L.stage[bufA][lane + 64] = fv1 + 1u;
                 }
@@ -455,6 +462,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         rs_for<1, NT>(nm);
                         need1 = need0;
                     }
+                    if constexpr (FREQS) need0 = need1 = (1u << nt) - 2u; // (a member's freq has to be fetched from every list)
                 }
                 float r0 = rest_of(gP0, 0), r1 = rest_of(gP1, 0);
                 ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
@@ -488,6 +496,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     // (AND: nothing is scored -- no norm_lens, no freqs -- and list 1 is searched only if somebody needs it: no rows ahead)
                     Rows rows1{make_uint2(0xFFFFFFFFu, 0u), 0.f};
                     float nl0 = 1.f, nl1 = 1.f, pa0 = 0.f, pa1 = 0.f;
+                    uint32_t fs0 = 0, fs1 = 0; // (FREQS: the candidate's freqs so far, list 0's first)
+                    if constexpr (FREQS) { fs0 = L.stage[bufB][lane]; fs1 = L.stage[bufB][lane + 64]; }
                     if constexpr (!AND) {
                         rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
                         nl0 = ok0 ? norm_lens[dB0] : 1.f;
@@ -625,6 +635,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             if constexpr (AND) {
                                 mem0 = mem0 | m0;
                                 mem1 = mem1 | m1;
+                                if constexpr (FREQS) {
+                                    if (m0) fs0 += fj[q0];
+                                    if (m1) fs1 += fj[q1];
+                                }
                             } else {
                                 if (m0) { pa0 = pa0 + qwj * doc_term_weight(fj[q0], nl0); mem0 = true; }
                                 if (m1) { pa1 = pa1 + qwj * doc_term_weight(fj[q1], nl1); mem1 = true; }
@@ -646,6 +660,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     }
                     else rs_for<1, NT>(probe);
                     if constexpr (AND) and_count += (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1))); // documents of the intersection
+                    if constexpr (FREQS) and_fsum += (unsigned long long)(ok0 ? fs0 : 0u) + (unsigned long long)(ok1 ? fs1 : 0u);
                     // pa0 / pa1 are complete scores of documents of the intersection now
                     uint32_t inserted = 0;
                     for (int half = 0; !AND && half < 2; ++half) {
@@ -715,9 +730,10 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
             if (clk && lane == 0) clk[2ull * uid + 1] = wall_clock64();
         }
         if constexpr (AND) { // and_query returns the size of the intersection (queries.hpp:85); the parts of a split query are summed by k_merge
+            if constexpr (FREQS) for (int o = 32; o; o >>= 1) and_fsum += __shfl_xor(and_fsum, o);
             if (lane == 0) {
-                if (whole) { r->out_count[q] = and_count; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }
-                else { r->unit_count[uid] = and_count; r->unit_freq_sum[uid] = 0; }
+                if (whole) { r->out_count[q] = and_count; if (r->out_freq_sum) r->out_freq_sum[q] = and_fsum; }
+                else { r->unit_count[uid] = and_count; r->unit_freq_sum[uid] = and_fsum; }
             }
         } else if (whole) {
             if (lane == 0) { r->out_count[q] = tk.n; if (r->out_freq_sum) r->out_freq_sum[q] = 0; }
@@ -764,12 +780,15 @@ hipError_t ds2i_launch_ranked_stream(int cap, const void* args, unsigned grid, h
 #undef DS2I_RS_CASE
     return hipGetLastError();
 }
-// and_query (count only) through the same pipeline (k_ranked_stream<cap, ., AND = true>); same preconditions
-hipError_t ds2i_launch_and_rstream(int cap, const void* args, unsigned grid, hipStream_t s) {
+// and_query (counts; with_freqs: counts + the freq checksum) through the same pipeline (k_ranked_stream<cap, ., AND = true, FREQS>); same preconditions
+hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
     const dim3 g(grid), b(64);
     const bool st = a.stats != nullptr;
-#define DS2I_AND_CASE(N) case N: if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, true>), g, b, 0, s, a); break;
+#define DS2I_AND_CASE(N) case N: \
+        if (with_freqs) { if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, true, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, true, true>), g, b, 0, s, a); } \
+        else { if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, true>), g, b, 0, s, a); } \
+        break;
     switch (cap) {
     DS2I_AND_CASE(2) DS2I_AND_CASE(4) DS2I_AND_CASE(6) DS2I_AND_CASE(8)
     default: return hipErrorInvalidValue;

@@ -97,6 +97,7 @@ public:
     // reference signature: ranked operators are constructed (wand_data const&, k); the wand data already
     // lives next to the index in HBM, so it is accepted and ignored
     template <class WandData> gpu_query_op(WandData const&, uint64_t k) : m_k((uint32_t)k) {}
+    void prefer_latency(bool) {} // (set_query<OP>'s ticket policy; one index has no tickets)
 
     // queries.cpp:26-28 -- one query (a batch of one)
     uint64_t operator()(gpu_index const& index, term_id_vec const& terms) {
@@ -347,12 +348,18 @@ public:
         m_pipes_of = 0;
     }
     static constexpr bool ranked() { return OP >= DS2I_OP_RANKED_AND; }
-    // queries per ticket: about eight tickets per replica, never fewer than 64 queries (a ticket is a kernel launch)
-    static size_t ticket_size(size_t n, size_t parts) { return std::max<size_t>(64, (n + parts * 8 - 1) / (parts * 8)); }
+    // Queries per ticket. A ticket is a set of kernel launches, and what a small one costs is span, not work: on one MI355X batches of
+    // 512 / 1024 / 2048 queries run at 0.4-0.6 / 0.55-0.75 / 0.75 of the 4096-query rate, so a throughput caller gets about two
+    // tickets per replica and never fewer than 512 queries; prefer_latency(true) restores the fine cut (about eight per replica, >= 64)
+    // for callers that want the first answers early.
+    void prefer_latency(bool on) { m_latency = on; }
+    size_t ticket_size(size_t n, size_t parts) const {
+        return m_latency ? std::max<size_t>(64, (n + parts * 8 - 1) / (parts * 8)) : std::max<size_t>(512, (n + parts * 2 - 1) / (parts * 2));
+    }
 
 private:
     uint64_t m_k;
-    bool m_counters = false;
+    bool m_counters = false, m_latency = false;
     std::vector<gpu_query_op<OP>> m_ops;
     std::vector<std::unique_ptr<gpu_pipeline>> m_pipes;
     uint64_t m_pipes_of = 0; // gpu_index_set::id() the pipelines belong to (0 = none)

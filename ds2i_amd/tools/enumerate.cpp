@@ -34,6 +34,7 @@ int main(int argc, const char** argv) {
             std::vector<ds2i_hip::term_id_vec> bad = good;
             bad[bad.size() / 2].push_back((uint32_t)set.size() + 5); // term id out of range: DS2I_ETERM for its ticket
             ds2i_hip::set_query<DS2I_OP_AND> op;
+            op.prefer_latency(true); // (1200 queries: fine tickets, so that all replicas' pipelines are in play)
             bool threw = false;
             try { op(set, bad); } catch (std::exception const&) { threw = true; }
             const std::vector<uint64_t> got = op(set, good); // (poisoned pipelines would say DS2I_EBUSY here)

@@ -28,6 +28,8 @@ void op_perftest(Index const& index, Op&& op, std::vector<term_id_vec> const& qu
         tool::logger("---- " + type + " " + query_type + ": empty query log, nothing to do");
         return;
     }
+    // (a log too short to give every replica a throughput-sized ticket is cut fine, so that every replica takes part)
+    if (queries.size() < 1024 * gpus) op.prefer_latency(true);
     double total = 0, kernel_ms = 0;
     for (size_t run = 0; run <= runs; ++run) {
         double tick = tool::get_time_usecs();

@@ -11,7 +11,7 @@ prefix = sys.argv[4] if len(sys.argv) > 4 else "r05"
 per = {}
 for line in open(d + "/counters_fetch.txt"):
     k, name, disp, mean = line.rstrip("\n").split("\t")
-    if ", true>(" in k or re.search(r"k_ranked_stream<\d, true", k):  # the instrumented instantiations (one launch per bench run): not what a step runs
+    if ", true>(" in k or re.search(r"k_(ranked|union)_stream<\d+, true", k):  # the instrumented instantiations (one launch per bench run): not what a step runs
         continue
     if name != "FETCH_SIZE" or not re.search(r"k_ranked_stream|k_conjunctive|k_union|k_disjunctive|k_daat|k_merge|k_freq_stream|k_and_stream", k):
         continue
@@ -20,7 +20,9 @@ for line in open(d + "/counters_fetch.txt"):
         continue
     args = [a.strip() for a in m.group(2).split(",")]
     if m.group(1) == "k_ranked_stream":
-        short = "k_ranked_stream<%s>" % args[0]
+        short = "k_ranked_stream<%s%s>" % (args[0], ",AND" if len(args) > 2 and args[2] == "true" else "")
+    elif m.group(1) == "k_union_stream":
+        short = "k_union_stream<%s>" % args[0]
     elif m.group(1) == "k_ranked_stream_mixed":
         short = "k_ranked_stream_mixed<%s>" % args[0]
     elif m.group(1) == "k_conjunctive":
@@ -37,7 +39,7 @@ tcc = d + "/counters_tcc1.txt"
 if os.path.exists(tcc):
     for line in open(tcc):
         k, name, disp, mean = line.rstrip("\n").split("\t")
-        if re.search(r"k_ranked_stream|k_conjunctive|k_union|k_disjunctive|k_daat|k_freq_stream|k_and_stream", k) and ", true>(" not in k:
+        if re.search(r"k_ranked_stream|k_conjunctive|k_union|k_disjunctive|k_daat|k_freq_stream|k_and_stream", k) and ", true>(" not in k and not re.search(r"k_(ranked|union)_stream<\d+, true", k):
             req[name] = req.get(name, 0.0) + float(mean.split("=")[1])
     out["l2_fabric_read_requests_per_step"] = {k: int(v) for k, v in sorted(req.items())}
     out["l2_fabric_note"] = ("TCC_EA0_RDREQ = read requests the L2s sent to the fabric, all of them 128-byte (TCC_EA0_RDREQ_32B = 0; _DRAM_32B = 4 x) and all "

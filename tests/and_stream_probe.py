@@ -35,23 +35,26 @@ def one(seed):
     img = d.build_index("block_optpfor", nd, lists)
     gidx = d.Index("block_optpfor", img, wand)
     oidx = o.Index("block_optpfor", img, wand)
-    oc, _, _, _, _ = oidx.query_batch("and", qs)
-    b = d.Batch(gidx, "and", qs)
-    b.run()
-    gc, _, _, _ = b.fetch()
     streamed = set()
-    for c in range(3):
-        streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
-    b.close()
-    assert np.array_equal(gc, oc), (seed, np.argwhere(gc != oc)[:5], gc[gc != oc][:5], oc[gc != oc][:5])
-    pipe = d.Pipeline(gidx, depth=2)
-    t = pipe.submit("and", qs)
-    pc, _, _ = pipe.wait(t)
-    pipe.close()
-    assert np.array_equal(pc, oc), (seed, "pipelined")
+    for op in ("and", "and_freq"):
+        oc, _, _, ofs, _ = oidx.query_batch(op, qs)
+        b = d.Batch(gidx, op, qs)
+        b.run()
+        gc, _, _, gfs = b.fetch()
+        for c in range(3):
+            streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
+        b.close()
+        assert np.array_equal(gc, oc), (seed, op, np.argwhere(gc != oc)[:5], gc[gc != oc][:5], oc[gc != oc][:5])
+        if op == "and_freq":
+            assert np.array_equal(gfs, ofs), (seed, "freq checksum", np.argwhere(gfs != ofs)[:5], gfs[gfs != ofs][:5], ofs[gfs != ofs][:5])
+        pipe = d.Pipeline(gidx, depth=2)
+        t = pipe.submit(op, qs)
+        pc, _, _ = pipe.wait(t)
+        pipe.close()
+        assert np.array_equal(pc, oc), (seed, op, "pipelined")
     if not os.environ.get("DS2I_NO_RANKED_STREAM"):
         assert streamed, "the stream kernel did not run"
-    print("seed %d: %d docs, %d terms, %d queries (%d non-empty, %d results), stream groups for %s lists: counts equal the oracle's" %
+    print("seed %d: %d docs, %d terms, %d queries (%d non-empty, %d results), stream groups for %s lists: and / and_freq counts (+ freq checksums) equal the oracle's" %
           (seed, nd, nt, len(qs), int((oc > 0).sum()), int(oc.sum()), sorted(streamed)))
 
 
