@@ -28,7 +28,7 @@ def _newer(target, deps):
 
 
 def _headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     inc = os.path.join(HERE, "..", "include")
     hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     return hs
