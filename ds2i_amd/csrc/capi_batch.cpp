@@ -491,7 +491,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                              idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams;
     const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps;
     const uint32_t and_unit_blocks = 96u; // (measured: 48: 965 k, 96: 1 068 k queries/s; whole queries: 802 k)
-    const bool and_rs_units = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
+    const bool and_rs_units = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
                               idx->d_bmw && idx->d_rmw && !kn.no_ranked_stream;
     b->sterms.clear();
     b->sterm_longest = 0;
@@ -735,7 +735,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // `and` batches that do not ask for the doc-id lists take the same pipeline with AND = true -- a candidate whose hints settle
         // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
         // verifies every survivor of its filters by a probe).
-        const bool rs_and = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !b->want_matches && idx->kind == DS2I_BLOCK_OPTPFOR;
+        const bool rs_and = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && idx->kind == DS2I_BLOCK_OPTPFOR; // (with or without the doc-id lists)
         const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw;
         if (rs_ok) {

@@ -139,6 +139,13 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         tk.init(a->k);
         unsigned long long and_count = 0; // (AND: results of this unit)
         unsigned long long and_fsum = 0;  // (FREQS: this lane's share of the unit's freq checksum)
+        // (AND, batches prepared with want_matches: the doc-ids of the intersection, in order, into the unit's segment of the match
+        // buffer -- 128 slots per block of list 0 from the query's offset, compacted by ds2i_hip_batch_fetch_matches)
+        uint32_t* and_out = nullptr;
+        if constexpr (AND) {
+            uint32_t* const om = a->out_matches;
+            if (om) and_out = om + rs_uniform64(a->match_off[q]) + 128ull * blk_begin;
+        }
         // ---- list 0: the stream
         const uint32_t n0 = uniform(qt[0].n), nb0 = (n0 + 127u) >> 7;
         const uint32_t vl0 = 1u + (n0 >= (1u << 7)) + (n0 >= (1u << 14)) + (n0 >= (1u << 21)) + (n0 >= (1u << 28));
@@ -659,7 +666,17 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         for (uint32_t j = 1; j < nt; ++j) probe(j);
                     }
                     else rs_for<1, NT>(probe);
-                    if constexpr (AND) and_count += (uint32_t)(__builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1))); // documents of the intersection
+                    if constexpr (AND) {
+                        const uint64_t m0 = ballot(ok0), m1 = ballot(ok1);
+                        if (and_out) { // (value i of the block sits in lane i & 63, slot i >> 6: slot 0 first keeps the doc-ids ascending)
+                            const uint64_t below = (1ull << lane) - 1ull;
+                            const unsigned long long at0 = and_count + (unsigned long long)__builtin_popcountll(m0 & below);
+                            const unsigned long long at1 = and_count + (unsigned long long)__builtin_popcountll(m0) + (unsigned long long)__builtin_popcountll(m1 & below);
+                            if (ok0) and_out[at0] = dB0;
+                            if (ok1) and_out[at1] = dB1;
+                        }
+                        and_count += (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1)); // documents of the intersection
+                    }
                     if constexpr (FREQS) and_fsum += (unsigned long long)(ok0 ? fs0 : 0u) + (unsigned long long)(ok1 ? fs1 : 0u);
                     // pa0 / pa1 are complete scores of documents of the intersection now
                     uint32_t inserted = 0;

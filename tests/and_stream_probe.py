@@ -47,6 +47,15 @@ def one(seed):
         assert np.array_equal(gc, oc), (seed, op, np.argwhere(gc != oc)[:5], gc[gc != oc][:5], oc[gc != oc][:5])
         if op == "and_freq":
             assert np.array_equal(gfs, ofs), (seed, "freq checksum", np.argwhere(gfs != ofs)[:5], gfs[gfs != ofs][:5], ofs[gfs != ofs][:5])
+        bm = d.Batch(gidx, op, qs, want_matches=True)  # the doc-id lists through the same kernels
+        bm.run()
+        mc, _, _, mfs = bm.fetch()
+        got = bm.fetch_matches(mc)
+        bm.close()
+        assert np.array_equal(mc, oc) and (op == "and" or np.array_equal(mfs, ofs)), (seed, op, "want_matches counts")
+        for i in range(0, len(qs), 7):
+            exp = oidx.query("and", qs[i], want_matches=True)["matches"]
+            assert np.array_equal(got[i], exp), (seed, op, qs[i], len(got[i]), len(exp))
         pipe = d.Pipeline(gidx, depth=2)
         t = pipe.submit(op, qs)
         pc, _, _ = pipe.wait(t)
