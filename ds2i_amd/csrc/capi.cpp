@@ -457,7 +457,7 @@ void load_knobs_locked() {
     v.unit_factor = num("DS2I_UNIT_FACTOR", 0);
     v.unit_cap = (uint32_t)num("DS2I_UNIT_CAP", 0);
     v.ut_blocks = (uint32_t)num("DS2I_UT_BLOCKS", 320);
-    v.stream_nt_max = (uint32_t)std::min(8.0, std::max(2.0, num("DS2I_STREAM_NT_MAX", 8)));
+    v.stream_nt_max = (uint32_t)std::min(16.0, std::max(2.0, num("DS2I_STREAM_NT_MAX", 16)));
     v.no_ranked_stream = on("DS2I_NO_RANKED_STREAM");
     v.no_union_rstream = on("DS2I_NO_UNION_RSTREAM");
     v.no_list_streams = on("DS2I_NO_LIST_STREAMS");

@@ -144,7 +144,7 @@ void ds2i_plan_pool_run(unsigned n, const std::function<void(unsigned)>& f) {
 // (default 8; 4 = the 5..8-term class keeps k_conjunctive<.., 8>). Round 5, interleaved on one box: 1 047-1 060 k queries/s with 8
 // against 985-992 k with 4.
 static uint32_t rs_stream_nt_max() { return ds2i_knobs().stream_nt_max; }
-static int rs_stream_classes() { return rs_stream_nt_max() > 4 ? 3 : 2; } // classes that get unit records (BatchArgs::urec)
+static int rs_stream_classes() { return rs_stream_nt_max() > 8 ? 4 : rs_stream_nt_max() > 4 ? 3 : 2; } // classes that get unit records (BatchArgs::urec)
 
 struct ds2i_hip_batch {
     ds2i_hip_index* idx = nullptr;
@@ -586,7 +586,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             // `and` through the stream pipeline has no heap to warm up -- a part costs its blocks and nothing else -- and a two-list query
             // left whole was a single wave for up to 13 ms (DS2I_UNIT_CLOCK: class 0 = 487 units, median 4.9 ms, 229 waves busy on
             // average, the span of the whole batch): at most 96 blocks of the shortest list per unit
-            if (and_rs_units && split_ok && nt > 1 && nt <= 8) parts = std::max(parts, (nb0 + and_unit_blocks - 1) / and_unit_blocks);
+            if (and_rs_units && split_ok && nt > 1 && nt <= rs_stream_nt_max()) parts = std::max(parts, (nb0 + and_unit_blocks - 1) / and_unit_blocks);
             const uint32_t per = (nb0 + parts - 1) / parts;
             parts = (nb0 + per - 1) / per;
             if (parts > 1) b->split_queries.push_back(q);
@@ -736,7 +736,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
         // verifies every survivor of its filters by a probe).
         const bool rs_and = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && idx->kind == DS2I_BLOCK_OPTPFOR; // (with or without the doc-id lists)
-        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 4 ? 2 : 1) && !no_rs &&
+        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 8 ? 3 : rs_nt > 4 ? 2 : 1) && !no_rs &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw;
         if (rs_ok) {
             // launch groups by list CAPACITY 2 | 4 | 6 | 8 (block_optpfor: a group holds the queries of cap - 1 and cap lists, UnitRec::pad says
@@ -746,7 +746,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
             auto cap_of = [&](uint32_t uid) {
                 const uint32_t n = nt_of(uid);
-                return n < 2 ? n : n > rs_nt ? DS2I_HIP_MAX_TERMS + 1u : exact ? n : (n + 1u) & ~1u;
+                return n < 2 ? n : n > rs_nt ? DS2I_HIP_MAX_TERMS + 1u : exact ? n : n > 8 ? (uint32_t)DS2I_HIP_MAX_TERMS : (n + 1u) & ~1u;
             };
             {   // stable partition by capacity, largest first
                 uint32_t cnt[DS2I_HIP_MAX_TERMS + 2] = {};
@@ -763,7 +763,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                 const uint32_t l = cap_of(b->order[c][i]);
                 while (j < b->ncls[c] && cap_of(b->order[c][j]) == l) ++j;
                 ds2i_hip_batch::SubLaunch sl{i, j, l >= 2 && l <= DS2I_HIP_MAX_TERMS ? l : cls_lists};
-                sl.stream = l >= 2 && l <= 8;
+                sl.stream = l >= 2 && l <= DS2I_HIP_MAX_TERMS;
                 b->sub[c].push_back(sl);
                 i = j;
             }
@@ -1043,10 +1043,10 @@ int launch_batch(ds2i_hip_batch* b) {
     // opened; spreading EVERY second group that way was measured and lost): ranked_and's one-term queries (the class kernel's group of class 0: 0.9 ms behind the two-term stream
     // kernel's 2.5 ms on that class's stream) go to a spare stream -- class 0 is one of three co-critical class streams of the step
     const bool side_group0 = base_op == DS2I_OP_RANKED_AND && !(b->op & DS2I_OP_REFERENCE_ORDER) && b->ncls[0] && b->sub[0].size() > 1 && b->sub[0].front().stream;
-    // ... and wand / maxscore / ranked_or's second stream group of the 5-8-list class (capacity 6 behind capacity 8: 3.6 ms behind 7.5 ms)
+    // ... and the second stream group of the 5-8-list class (capacity 6 behind capacity 8; wand: 3.6 ms behind 7.5 ms, and: 1.3 behind 1.8)
     hipStream_t spare[NCLS];
     int nspare = 0, next_spare = 0;
-    const bool side_group2 = b->union_rstream && b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
+    const bool side_group2 = b->ncls[2] && b->sub[2].size() > 1 && b->sub[2][0].stream && b->sub[2][1].stream;
     if (side_group0 || side_group2)
         for (int c = NCLS - 1; c >= 0; --c)
             if (!b->ncls[c]) {

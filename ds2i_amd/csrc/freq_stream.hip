@@ -150,6 +150,13 @@ __global__ void __launch_bounds__(64, 8) k_and_stream(AndStreamArgs a) {
     if (b0 >= b1) return;
     const uint32_t vl = 1u + (n >= (1u << 7)) + (n >= (1u << 14)) + (n >= (1u << 21)) + (n >= (1u << 28));
     const uint32_t bb = uniform(st->blk_base), nother = uniform(st->nother), counts = uniform(st->counts);
+    if (!WITH_FREQS && nother == 0u) {
+        // and_query of ONE term (queries.hpp:58-84 walks the list and counts it): the answer is the list's length, which its header
+        // holds -- nothing is decoded. (424 of the 4096 queries of the GOV2-scale batch; decoding their 5.3 M blocks to count them
+        // was the longest kernel of the `and` step, 2.3 ms.) and_query<with_freqs> still streams the list: it needs every freq.
+        if (b0 == 0u && lane == 0 && counts) atomicAdd(a.out_count + uniform(st->q), (unsigned long long)n);
+        return;
+    }
     const unsigned long long list_off = ((unsigned long long)uniform((uint32_t)(st->list_off >> 32)) << 32) | uniform((uint32_t)st->list_off);
     const uint8_t* const data = a.arena + list_off + vl + 4ull * nb + 4ull * (nb - 1);
     const uint2* const tab = (const uint2*)a.skip + bb;

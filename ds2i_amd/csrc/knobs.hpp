@@ -24,7 +24,7 @@ struct Ds2iKnobs {
     double unit_factor;       // DS2I_UNIT_FACTOR: work units per resident wave (0 = default per operator)
     uint32_t unit_cap;        // DS2I_UNIT_CAP: at most this many blocks of the shortest list per unit of a ranked conjunction (0 = off)
     uint32_t ut_blocks;       // DS2I_UT_BLOCKS: blocks of the driving list per unit of wand / maxscore / ranked_or (default 320)
-    uint32_t stream_nt_max;   // DS2I_STREAM_NT_MAX: ranked_and / and queries of up to this many lists run k_ranked_stream (default 8)
+    uint32_t stream_nt_max;   // DS2I_STREAM_NT_MAX: ranked_and / and queries of up to this many lists run k_ranked_stream (default 16)
     bool no_ranked_stream;    // DS2I_NO_RANKED_STREAM: ranked_and / and through the class kernels (k_conjunctive)
     bool no_union_rstream;    // DS2I_NO_UNION_RSTREAM: wand / maxscore / ranked_or through k_union_topk instead of k_union_stream
     bool no_list_streams;     // DS2I_NO_LIST_STREAMS: no k_freq_stream (or_freq) / k_and_stream (and / and_freq of one-term and all-dense queries)

@@ -50,7 +50,7 @@ namespace {
 #endif
 // 5..8 lists: what fits -- one more decoded block (1 KB of LDS) and nine more parked scalars per list:
 // 7 936 .. 11 008 bytes of LDS per wave
-#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 6 ? 4 : 3)
+#define RS_WAVES(NT) ((NT) <= 2 ? DS2I_RS_OCC2 : (NT) <= 4 ? DS2I_RS_OCC4 : (NT) <= 6 ? 4 : (NT) <= 8 ? 3 : 2)
 
 template <int NT>
 struct LdsRS {
@@ -81,8 +81,7 @@ struct LdsRS {
 template <int NT, bool STATS, bool AND = false, bool FREQS = false>
 __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
     static_assert(AND || !FREQS, "FREQS is a variant of AND");
-    static_assert(NT >= 2 && NT <= 8, "list capacities 2..8");
-    static_assert((NT - 2) * 9 + 8 < 64, "the per-list constants of lists 1.. are parked in the lanes of one VGPR");
+    static_assert(NT >= 2 && NT <= 16, "list capacities 2..16");
     __shared__ LdsRS<NT> L;
     const uint32_t lane = lane_id();
     typename std::conditional<STATS, uint32_t, NullCounter>::type s_docs_blocks, s_freqs_blocks, s_bm_examined, s_scored, s_rounds;
@@ -189,10 +188,28 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // touches them: they live in the lanes of one VGPR (v_readlane / v_writelane at a constant lane).
         // Together with the list's geometry (postings, first row in the per-block tables, arena offset, query weight): read once
         // per unit, here, so that stage C starts with its first memory request instead of a dependent read of the QTerm.
-        uint32_t cold = 0xFFFFFFFFu;
+        // (nine lanes per list: one VGPR up to 8 lists, three for 16)
+        constexpr int NCOLD = ((NT - 1) * 9 + 63) / 64;
+        uint32_t cold[NCOLD];
+#pragma unroll
+        for (int i = 0; i < NCOLD; ++i) cold[i] = 0xFFFFFFFFu;
+        auto cold_get = [&](uint32_t l) __attribute__((always_inline)) -> uint32_t { // l wave-uniform (a constant wherever the list index is one)
+            uint32_t v = cold[0];
+            if constexpr (NCOLD > 1) { if (l >= 64u) v = cold[1]; }
+            if constexpr (NCOLD > 2) { if (l >= 128u) v = cold[2]; }
+            return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(l & 63u));
+        };
+        auto cold_set_at = [&](uint32_t l, uint32_t v) __attribute__((always_inline)) { // l known at run time only
+            if constexpr (NCOLD == 1) rs_writelane_at(cold[0], v, l);
+            else {
+                if (l < 64u) rs_writelane_at(cold[0], v, l);
+                else if (NCOLD == 2 || l < 128u) rs_writelane_at(cold[1], v, l & 63u);
+                else rs_writelane_at(cold[NCOLD - 1], v, l & 63u);
+            }
+        };
         enum { C_CUR = 0, C_BMAX = 1, C_N = 2, C_BB = 3, C_LOLO = 4, C_LOHI = 5, C_QW = 6, C_TLLO = 7, C_TLHI = 8, C_PER = 9 };
-#define cget(l) ((uint32_t)__builtin_amdgcn_readlane((int)cold, (l)))
-#define cset(l, v) rs_writelane<(l)>(cold, (v))
+#define cget(l) cold_get((uint32_t)(l))
+#define cset(l, v) rs_writelane<((l) & 63)>(cold[(l) >> 6], (v))
         {
             auto park = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
@@ -314,7 +331,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         float boA0 = 0.f, boA1 = 0.f, boB0 = 0.f, boB1 = 0.f;                                  // freq-only bound of the list-0 term score
         // range-table weight bytes of a lane's two candidates, packed: byte j - 1 = list j (v_cvt_f32_ubyteN unpacks for free);
         // one dword holds lists 1..4, six and more lists take a pair
-        using GP = typename std::conditional<(NT > 5), unsigned long long, uint32_t>::type;
+        using GP = typename std::conditional<(NT > 9), unsigned __int128, typename std::conditional<(NT > 5), unsigned long long, uint32_t>::type>::type;
         auto gbyte = [](GP g, int j) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(g >> (8 * (j - 1))) & 255u; };
         // staging buffers of list 0 (LDS byte offsets): the block in stage B/C, the block in stage A, the block on its way in
         const uint32_t st_base = rs_lds_offset(&L.stage[0][0]), gb_base = rs_lds_offset(&L.gb[0][0]), xs_base = rs_lds_offset(&L.xs[0][0]);
@@ -598,8 +615,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 curj = fb.blk;
                                 bmj = fb.bmax;
                                 if constexpr (RT) {
-                                    rs_writelane_at(cold, curj, CB + C_CUR);
-                                    rs_writelane_at(cold, bmj, CB + C_BMAX);
+                                    cold_set_at(CB + C_CUR, curj);
+                                    cold_set_at(CB + C_BMAX, bmj);
                                 } else {
                                     cset((decltype(jc)::value - 1) * C_PER + C_CUR, curj);
                                     cset((decltype(jc)::value - 1) * C_PER + C_BMAX, bmj);
@@ -782,7 +799,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 } // namespace
 
 extern "C" {
-// cap = list capacity of the launch (2, 4, 6, 8): every query of it has cap - 1 or cap distinct terms (UnitRec::pad = the count; the
+// cap = list capacity of the launch (2, 4, 6, 8, 16): every query of it has cap - 1 or cap (16: 9 .. 16) distinct terms (UnitRec::pad = the count; the
 // planner's DS2I_STREAM_NT_MAX caps it); the caller has checked that the index is block_optpfor with skip table, block weights, range
 // tables and side slots, and that k <= 64
 hipError_t ds2i_launch_ranked_stream(int cap, const void* args, unsigned grid, hipStream_t s) {
@@ -791,7 +808,7 @@ hipError_t ds2i_launch_ranked_stream(int cap, const void* args, unsigned grid, h
     const bool st = a.stats != nullptr;
 #define DS2I_RS_CASE(N) case N: if (st) hipLaunchKernelGGL((k_ranked_stream<N, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false>), g, b, 0, s, a); break;
     switch (cap) {
-    DS2I_RS_CASE(2) DS2I_RS_CASE(4) DS2I_RS_CASE(6) DS2I_RS_CASE(8)
+    DS2I_RS_CASE(2) DS2I_RS_CASE(4) DS2I_RS_CASE(6) DS2I_RS_CASE(8) DS2I_RS_CASE(16)
     default: return hipErrorInvalidValue;
     }
 #undef DS2I_RS_CASE
@@ -807,7 +824,7 @@ hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, un
         else { if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, true>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, true>), g, b, 0, s, a); } \
         break;
     switch (cap) {
-    DS2I_AND_CASE(2) DS2I_AND_CASE(4) DS2I_AND_CASE(6) DS2I_AND_CASE(8)
+    DS2I_AND_CASE(2) DS2I_AND_CASE(4) DS2I_AND_CASE(6) DS2I_AND_CASE(8) DS2I_AND_CASE(16)
     default: return hipErrorInvalidValue;
     }
 #undef DS2I_AND_CASE

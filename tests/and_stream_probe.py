@@ -25,7 +25,7 @@ def one(seed):
     sizes = d.synth_doc_sizes(p)
     wand = d.build_wand(sizes, lists)
     qs = []
-    for n in range(2, 9):
+    for n in list(range(2, 9)) + [9, 12, 16]:
         qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(40)]   # anywhere in the vocabulary: short lists among them
         qs += [[int(x) for x in rng.permutation(min(nt, 14))[:n]] for _ in range(40)]              # the densest lists
         qs += [[int(x) for x in rng.permutation(nt)[-min(nt, 20):][:n]] for _ in range(20)]        # only short lists (wide ranges)
@@ -41,7 +41,7 @@ def one(seed):
         b = d.Batch(gidx, op, qs)
         b.run()
         gc, _, _, gfs = b.fetch()
-        for c in range(3):
+        for c in range(4):
             streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
         b.close()
         assert np.array_equal(gc, oc), (seed, op, np.argwhere(gc != oc)[:5], gc[gc != oc][:5], oc[gc != oc][:5])

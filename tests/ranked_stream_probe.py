@@ -26,9 +26,9 @@ def one(seed):
         sizes = np.where(rng.random(nd) < 0.1, 1, sizes).astype(np.uint32)
     wand = d.build_wand(sizes, lists)
     qs = []
-    for n in range(2, 9):  # every list count: terms anywhere in the vocabulary (mostly empty intersections, early exits) ...
+    for n in list(range(2, 9)) + [9, 11, 13, 16]:  # every list count up to 8, a few beyond: terms anywhere in the vocabulary (mostly empty intersections, early exits) ...
         qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(40)]
-        qs += [[int(x) for x in rng.permutation(min(nt, 14))[:n]] for _ in range(60)]  # ... and among the densest lists (big intersections)
+        qs += [[int(x) for x in rng.permutation(min(nt, 14 if n <= 8 else 22))[:n]] for _ in range(60 if n <= 8 else 15)]  # ... and among the densest lists (big intersections)
     qs += [list(range(8)), list(range(7, -1, -1)), [0, 1, 2, 3, 4], [nt - 1, 0, 1, 2, 3, 4]]
     img = d.build_index("block_optpfor", nd, lists)
     gidx = d.Index("block_optpfor", img, wand)
@@ -40,7 +40,7 @@ def one(seed):
         b = d.Batch(gidx, "ranked_and", qs, k=k)
         b.run()
         gc, gtopk, gtlen, _ = b.fetch()
-        for c in range(3):
+        for c in range(4):
             streamed |= set(g["lists"] for g in b.class_groups(c) if g["pipelined_stream"])
         b.close()
         assert np.array_equal(gc, oc) and np.array_equal(gtlen, otlen), (seed, k, np.argwhere(gc != oc)[:3])
@@ -50,7 +50,7 @@ def one(seed):
         assert np.array_equal(ptopk, otopk), (seed, k, "pipelined")
     pipe.close()
     # launch groups by list capacity (2 | 3-4 | 5-6 | 7-8)
-    want = {2, 4, 6, 8} if int(os.environ.get("DS2I_STREAM_NT_MAX", "8")) >= 8 else {2, 4}
+    want = {2, 4, 6, 8, 16} if int(os.environ.get("DS2I_STREAM_NT_MAX", "16")) > 8 else {2, 4, 6, 8} if int(os.environ.get("DS2I_STREAM_NT_MAX", "16")) > 4 else {2, 4}
     assert streamed == want, (streamed, want)
     nonempty = int((oc > 0).sum())
     print("seed %d: %d docs, %d terms, %d queries (%d with results), stream kernels for %s lists: bit-identical to the oracle" %

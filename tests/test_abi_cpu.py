@@ -97,7 +97,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     # the four translation units that issue loads by hand: the stream kernels of ranked_and / and (block_optpfor; block_mixed), of
     # wand / maxscore / ranked_or, and the list streams of or_freq / and. (minimum kernels, minimum hand-issued loads per kernel)
     texts = {}
-    for src, min_kernels, min_dma in (("ranked_stream.hip", 24, 6), ("union_stream.hip", 8, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 3, 3)):
+    for src, min_kernels, min_dma in (("ranked_stream.hip", 30, 6), ("union_stream.hip", 10, 6), ("ranked_stream_mixed.hip", 3, 4), ("freq_stream.hip", 3, 3)):
         out = str(tmp_path / (src + ".s"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
                                "-o", out, os.path.join(root, "ds2i_amd", "csrc", src)], stderr=subprocess.DEVNULL)
@@ -116,7 +116,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
                     assert "_lds_" in t.split()[0], (name, t)
                     dma += 1
             # (the AND instantiations of k_ranked_stream have no shared floor word to fetch: one hand-issued load fewer)
-            assert dma >= (min_dma - 1 if re.search(r"k_ranked_streamILi\dELb\dELb1ELb\dEE", name) else min_dma), (src, name)
+            assert dma >= (min_dma - 1 if re.search(r"k_ranked_streamILi\d+ELb\dELb1ELb\dEE", name) else min_dma), (src, name)
             assert asm_audit.audit(lines) == [], (src, name)
     # Register budget of the shipped (uninstrumented block_optpfor) instantiations of k_ranked_stream, from the code-object
     # metadata of the same listing: capacity 2 / 4 at 6 waves per SIMD (80 VGPRs), 6 / 8 at 4 / 3. With two lists nothing is
@@ -128,31 +128,31 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     for blk in re.split(r"\n  - \.agpr_count:", text)[1:]:
         nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
         meta[nm] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "private_segment_fixed_size")}
-    budget = {2: (80, 0, 0, 64), 4: (80, 12, 48, 110), 6: (128, 0, 0, 150), 8: (168, 0, 0, 190)}
+    budget = {2: (80, 0, 0, 64), 4: (80, 12, 48, 110), 6: (128, 0, 0, 150), 8: (168, 0, 0, 190), 16: (256, 0, 0, 340)}
     seen = 0
     for nm, m in meta.items():
-        mm = re.search(r"k_ranked_streamILi(\d)ELb0ELb0ELb0EE", nm)  # (capacity, STATS = false, AND = false: the shipped ranked_and instantiations)
+        mm = re.search(r"k_ranked_streamILi(\d+)ELb0ELb0ELb0EE", nm)  # (capacity, STATS = false, AND = false: the shipped ranked_and instantiations)
         if not mm:
             continue
         seen += 1
         vg, vs, ps, ss = budget[int(mm.group(1))]
         assert m["vgpr_count"] <= vg and m["vgpr_spill_count"] <= vs and m["private_segment_fixed_size"] <= ps and m["sgpr_spill_count"] <= ss, (nm, m)
-    assert seen == 4
+    assert seen == 5
     # ... and of k_union_stream (wand / maxscore / ranked_or): nothing in scratch beyond one register of capacity 4
     umeta = {}
     for blk in re.split(r"\n  - \.agpr_count:", texts["union_stream.hip"])[1:]:
         nm = re.search(r"\.name:\s+(\S+)", blk).group(1)
         umeta[nm] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "private_segment_fixed_size")}
-    ubudget = {2: (80, 0, 0, 64), 4: (96, 2, 8, 140), 6: (128, 0, 0, 200), 8: (168, 0, 0, 270)}
+    ubudget = {2: (80, 0, 0, 64), 4: (96, 2, 8, 140), 6: (128, 0, 0, 200), 8: (168, 0, 0, 270), 16: (256, 0, 0, 540)}
     seen = 0
     for nm, m in umeta.items():
-        mm = re.search(r"k_union_streamILi(\d)ELb0EE", nm)
+        mm = re.search(r"k_union_streamILi(\d+)ELb0EE", nm)
         if not mm:
             continue
         seen += 1
         vg, vs, ps, ss = ubudget[int(mm.group(1))]
         assert m["vgpr_count"] <= vg and m["vgpr_spill_count"] <= vs and m["private_segment_fixed_size"] <= ps and m["sgpr_spill_count"] <= ss, (nm, m)
-    assert seen == 4
+    assert seen == 5
 
 
 def test_documented_knobs_are_the_knobs_of_the_library():

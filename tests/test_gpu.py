@@ -1164,15 +1164,15 @@ def test_alternative_paths_give_the_same_results(built_lib, knob):
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8"])
-def test_ranked_stream_5_to_8_lists_behind_its_knob(built_lib, extra):
-    """DS2I_STREAM_NT_MAX=8 (the default since the end of round 5; pinned here): the 5..8-term class of a ranked_and batch on block_optpfor runs
-    k_ranked_stream<5..8> instead of k_conjunctive<true, true, 8> (queries.hpp:322-401 for any number of terms). Same
-    results, bit for bit, whole queries and -- with units capped at 8 blocks -- queries split into many parts that share
-    their floor; the probe also asserts that the stream kernel did run for every list count 2..8 (launch groups)."""
+@pytest.mark.parametrize("extra", ["", "DS2I_UNIT_CAP=8", "DS2I_STREAM_NT_MAX=8", "DS2I_STREAM_NT_MAX=4"])
+def test_ranked_and_through_the_stream_pipeline(built_lib, extra):
+    """The 2..16-term queries of a ranked_and batch on block_optpfor run k_ranked_stream<cap>, cap = the list capacity 2 | 4 | 6 | 8 | 16 of
+    their launch group (queries.hpp:322-401 for any number of terms). Same results, bit for bit, whole queries and -- with units
+    capped at 8 blocks -- queries split into many parts that share their floor; DS2I_STREAM_NT_MAX = 8 / 4 leaves the longer queries
+    to the class kernels; the probe also asserts that the stream kernel did run for every capacity (launch groups)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DS2I_STREAM_NT_MAX="8")
+    env = dict(os.environ)
     if extra:
         k, v = extra.split("=")
         env[k] = v
