@@ -322,6 +322,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                 uint32_t v0, v1, fv0, fv1, consA, consF;
                 if (__builtin_expect(szA == 128u, 1)) rs_decode_full(L.stage[bufA], L.xs[bufA], data0 + A.ep, rs_args()->xovf, v0, v1, fv0, fv1, consA, consF);
                 else rs_tail(rs_args()->tails, rs_uniform64(qt[0].aux1), szA, v0, v1, fv0, fv1, consA, consF);
+                PT(PH_PROLOG);
                 const uint32_t g0 = (lane < szA) ? v0 + 1u : 0u, g1 = (lane + 64 < szA) ? v1 + 1u : 0u;
                 const uint32_t i0 = wave_incl_scan(g0);
                 const uint32_t i1 = wave_incl_scan(g1) + bcast(i0, 63);

@@ -11,7 +11,7 @@ img, wand, n = d.synth_build(p, "block_optpfor", os.cpu_count())
 idx = d.Index("block_optpfor", img, wand)
 queries = d.synth_queries(0x51E21 + 7919 * 3, p.num_terms, 4096)
 names = [("unit", "unit setup"), ("prefetch", "WAIT: block bytes + side slot of A"), ("stream", "floor word + select next block + prefetch issue"),
-         ("docs", "stage A: decode docs + freqs, prefix sums, own bounds"), ("topk", "WAIT: list 1's bytes of B"), ("member", "stage B: list 1 + further lists' bytes"),
+         ("prolog", "stage A: decode of docs + freqs (optpfor_decode_pair / tail)"), ("docs", "stage A: prefix sums, own bounds, freqs parked"), ("topk", "WAIT: list 1's bytes of B"), ("member", "stage B: list 1 + further lists' bytes"),
          ("freqs", "stage B: bound test + optional lists' hints"), ("score", "stage C: norm_len + exact driver score"), ("probe", "stage C: lists 1.. (search / decode / membership)"),
          ("insert", "heap inserts + floor publication"), ("find", "rotate + alive test + gather issue"), ("total", "unit epilogue")]
 counts = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2,3,4,6,8").split(",")]
