@@ -528,6 +528,11 @@ def main():
     # when a counter pass is committed -- how many bytes of 128-byte lines the fabric moved per byte of it
     own = int(sum(cls_stats[c][0].algorithmic_bytes for c in range(NCLS)))
     out["roofline"]["own_traversal_bytes_per_step"] = own
+    if info["transcoded_from"] >= 0:
+        # A_skip (algorithmic_bytes, achieved, frac, step_frac) prices the reference traversal of the CALLER's image; the kernels that ran
+        # decode its block_optpfor re-encoding -- own_traversal_bytes_per_step is what THEY decoded. Neither frac is a utilisation
+        # figure of the native (partitioned Elias-Fano / mixed-codec) kernels: DS2I_PEF_NATIVE=1 / DS2I_MIXED_NATIVE=1 run those.
+        out["roofline"]["bytes_priced_on"] = "the caller's %s image (reference traversal); the kernels ran on its block_optpfor transcoding" % args.codec
     out["roofline"]["lines_per_useful_byte"] = (traffic_step / own) if (traffic_step and own) else None
     if out.get("a_skip_bytes_per_step"):
         out["roofline"]["step_algorithmic_bytes"] = int(out["a_skip_bytes_per_step"])

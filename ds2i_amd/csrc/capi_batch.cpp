@@ -169,6 +169,11 @@ struct ds2i_hip_batch {
     // wand / maxscore / ranked_or as streams (k_union_topk): the virtual queries (query, driving list) their units belong to
     std::vector<QTerm> vterms;
     std::vector<uint32_t> voff, vinfo; // vinfo: {real query, exclusion lists, float bits of the query's score bound} per virtual query
+    // prepared batches (ds2i_hip_batch_prepare) keep their query arrays: enabling the block profile re-plans the batch without the list
+    // streams (k_and_stream / k_freq_stream count no block decodes -- ADVICE r5)
+    std::vector<uint32_t> keep_terms, keep_offs;
+    int keep_want_matches = 0;
+    bool no_list_streams = false;
     bool union_stream = false;
     bool union_rstream = false;   // ... and some class of it runs k_union_stream (union_stream.hip): unit records + the floor words
     // or_freq on a block_optpfor index with the side tables: the union's size by the `or` kernels, the freqs -- which do not
@@ -488,7 +493,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                       !b->long_terms;
     // (list_stream: what a stream over ONE list needs -- its blocks through the side slots; and_stream: the other lists' bitmaps as well)
     const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
-                             idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams;
+                             idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams && !b->no_list_streams;
     const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps;
     const uint32_t and_unit_blocks = 96u; // (measured: 48: 965 k, 96: 1 068 k queries/s; whole queries: 802 k)
     const bool and_rs_units = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
@@ -497,7 +502,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     b->sterm_longest = 0;
     b->union_rstream = false;
     b->freq_stream = base_op == DS2I_OP_OR_FREQ && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails &&
-                     idx->d_skip && !kn.no_list_streams;
+                     idx->d_skip && !kn.no_list_streams && !b->no_list_streams;
     b->vterms.clear();
     b->voff.assign(1, 0);
     b->vinfo.clear();
@@ -1321,6 +1326,13 @@ int ds2i_hip_batch_prepare(ds2i_hip_index* idx, int op, uint32_t k, const uint32
     if (!rc) rc = upload_batch(b.get());
     if (rc) return rc;
     HIP_OK(hipEventSynchronize(b->ev_up));
+    try {
+        b->keep_offs.assign(query_offsets, query_offsets + nq + 1);
+        b->keep_terms.assign(terms, terms + (nq ? query_offsets[nq] : 0));
+        b->keep_want_matches = want_matches;
+    } catch (std::bad_alloc const&) {
+        return ds2i_set_error(DS2I_ENOMEM, "out of host memory preparing the batch");
+    }
     *out = b.release();
     return DS2I_OK;
 }
@@ -1353,6 +1365,16 @@ int ds2i_hip_batch_enable_block_profile(ds2i_hip_batch* b) {
     const size_t bytes = 8 * (size_t)(idx->total_blocks ? idx->total_blocks : 1);
     HIP_OK(b->d_prof.reserve(bytes));
     HIP_OK(hipMemset(b->d_prof.p, 0, bytes));
+    if ((!b->sterms.empty() || b->freq_stream) && !b->keep_offs.empty()) {
+        // queries answered by list streams have no work units and their kernels count nothing: plan the batch again without them, so
+        // that every block decode of the batch shows in the profile (the input of the block_mixed optimiser)
+        b->no_list_streams = true;
+        HIP_OK(hipDeviceSynchronize());
+        int rc = plan_batch(b, b->op, b->k, b->keep_terms.empty() ? nullptr : b->keep_terms.data(), b->keep_offs.data(), b->nq, b->keep_want_matches);
+        if (!rc) rc = upload_batch(b);
+        if (rc) return rc;
+        HIP_OK(hipEventSynchronize(b->ev_up));
+    }
     b->profile_on = true;
     b->prof_ptr = (unsigned int*)b->d_prof.p; // the seed pass decodes blocks too: launch_batch hands it the same buffer
     return DS2I_OK;

@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 acc = acc + rsc[j] * (float)best;
             };
             rs_for_down<NT, 1>(one_list);
+            rs_settle_vm(); // (once per 63 blocks: no compiler-visible load stays "possibly pending" on the hot path, stream_common.hpp)
             s_rest = acc;
             if constexpr (AND) s_ub = (dead || !row) ? -1.0f : 0.0f; // (a live row: some posting of every other list lies in the block's span)
             else s_ub = (dead || !row) ? -1.0f : (qw0 * s_w + acc) * BOUND_SLACK; // (scores are >= 0: -1 never enters)
@@ -434,6 +435,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                                 }
                             };
                             rs_for<2, NT>(htest);
+                            rs_settle_vm();
                         }
                     }
                     if (!AND && (ballot(ok0) | ballot(ok1))) { // every list's weight byte for what is left (AND: nothing to weigh)
@@ -444,6 +446,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             LC(PH_FREQS, lines_of(rt[j] + (dB0 >> rsh[j]), ok0, 1u) + lines_of(rt[j] + (dB1 >> rsh[j]), ok1, 1u));
                         };
                         rs_for<1, NT>(wload);
+                        rs_settle_vm();
                     }
                 } else if constexpr (NT > 2) {
                     // lists 2.. : their bytes only for the candidates list 1's byte lets through (list maxima for the others)
@@ -467,6 +470,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             ok1 = ok1 & (gbyte(gP1, j) != 0u);
                         };
                         rs_for<2, NT>(test_one);
+                        rs_settle_vm();
                     }
                 }
                 // what the lists after list `after` can add to this lane's two candidates, from their own bytes (summed from the
@@ -507,6 +511,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                         ok1 = ok1 & ((h1 == 255u) | (h1 == rmh_code(dB1, rsh[j])));
                     };
                     rs_for<1, NT>(hint_one);
+                    rs_settle_vm();
                 }
                 LC(PH_C_SURV2, __builtin_popcountll(ballot(ok0)) + __builtin_popcountll(ballot(ok1)));
                 PT(PH_MEMBER);
@@ -719,6 +724,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                             if (f > tk.floor) { tk.floor = f; refresh(); }
                         }
                     }
+                    rs_settle_vm(); // (stage C is over: its loads are settled for the compiler too)
                 }
             }
             PT(PH_SCORE);

@@ -178,6 +178,14 @@ DS2I_DEV void rs_writelane_at(uint32_t& dst, uint32_t v, uint32_t lane) {
 }
 template <int N> DS2I_DEV void rs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// A wait the COMPILER sees (the builtin, not inline asm): placed where a rare path that issued compiler-visible loads joins the hot
+// path again. hipcc's wait-count pass keeps every such load "possibly pending" on the joined path until a wait it knows about, and
+// the next instruction of the hot path that merely REUSES one of their destination registers then gets an s_waitcnt vmcnt(0) -- which
+// also drains the hand-issued prefetch that was meant to stay in flight. (Found in round 6: every iteration of k_ranked_stream /
+// k_union_stream waited out the next block's prefetch right in front of its decode's first LDS read, because the general side-slot
+// decoder -- one block in 10^4 -- loads through registers. 0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched, gfx9 encoding.)
+DS2I_DEV void rs_settle_vm() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // stage C: the 512 bytes from g (dword aligned) and the 256-byte side slot at gx -> LDS, by plain loads
 DS2I_DEV void rs_stage_block(const uint32_t* g, const uint32_t* gx, uint32_t* st, uint32_t* xs) {
     const uint32_t lane = lane_id();
@@ -202,6 +210,7 @@ DS2I_DEV void rs_tail(const uint32_t* tails, unsigned long long entry, uint32_t 
     f1 = b1;
     cons_d = uniform(c0);
     cons_f = uniform(c1);
+    rs_settle_vm();
 }
 // docs (gaps-1) and freqs-1 of a full block staged at st / slot: the branch-free pair decoder, or -- a block in 10^4: raw parts,
 // parts beyond the staged bytes, adds in the overflow area -- the general side-slot decoder part by part. gblk = the block's
@@ -216,6 +225,7 @@ DS2I_DEV void rs_decode_full(const uint32_t* st, const uint32_t* slot, const uin
         cons_d = optpfor_decode_side(st, STAGE_DW, slot, gblk, xovf, 0u, 0u, d0, d1, &nd);
         const uint32_t skip_dw = cons_d >> 2;
         cons_f = optpfor_decode_side(st + skip_dw, skip_dw < STAGE_DW ? STAGE_DW - skip_dw : 0u, slot, gblk + cons_d, xovf, 1u, nd, f0, f1);
+        rs_settle_vm();
     }
 }
 

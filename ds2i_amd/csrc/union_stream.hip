@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
             s_rest = acc;
             s_mask = mask;
             s_ub = row ? (qw0 * s_w + acc) * BOUND_SLACK : -1.0f; // (scores are >= 0: -1 never enters)
+            rs_settle_vm(); // (once per 63 blocks: no compiler-visible load stays "possibly pending" on the hot path, stream_common.hpp)
         };
         // a block of the driver on its way through the stages (w = its block weight x the driver's query weight)
         struct Blk { uint32_t blk, base, ep, mask; float w, rest; };
@@ -402,6 +403,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                             }
                         };
                         rs_for<2, NT>(use_one);
+                        rs_settle_vm();
                     }
                 }
                 PT(PH_MEMBER);
@@ -429,6 +431,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                         if (!((h1[j] == 255u) | (h1[j] == rmh_code(dB1, rsh[j])))) gP1 &= keep;
                     };
                     rs_for<1, NT>(htest);
+                    rs_settle_vm();
                     r0 = rest_of(gP0, 0);
                     r1 = rest_of(gP1, 0);
                     ok0 = ok0 & enters((boB0 + r0) * BOUND_SLACK);
@@ -601,6 +604,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
                             if (f > tk.floor) { tk.floor = f; refresh(); }
                         }
                     }
+                    rs_settle_vm(); // (stage C is over: its loads are settled for the compiler too)
                 }
             }
             PT(PH_INSERT);
