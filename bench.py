@@ -521,6 +521,14 @@ def main():
                        "launches_timed": n_timed, "algorithmic_bytes": int(a_skip_dom), "bytes_source": src,
                        "device_counted_bytes_of_class": int(cls_stats[dom][0].algorithmic_bytes),
                        "queries_in_kernel": nq_dom, "per_kernel": per_kernel, "per_class": per_class}
+    # beside the dominant kernel BY TIME (above: the longest launch among the kernels that answer >= 10 % of the step's bytes -- since
+    # the launch groups became capacities that is the 3-4-list group) the kernel that answers the MOST bytes, priced the same way
+    kb = [k for k in per_kernel if k.get("algorithmic_bytes") and k.get("ms_per_launch")]
+    if kb:
+        big = max(kb, key=lambda k: k["algorithmic_bytes"])
+        gbs = big["algorithmic_bytes"] / (big["ms_per_launch"] * 1e-3) / 1e9
+        out["roofline"]["largest_kernel"] = {"kernel": big["kernel"], "queries": big["queries"], "kernel_ms": big["ms_per_launch"],
+                                             "algorithmic_bytes": int(big["algorithmic_bytes"]), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
     # the class kernels of a batch (and of the neighbouring batches) overlap, so one kernel's launch duration stretches
     # when another class is given more of the GPU; the whole step is the figure that cannot: every class's algorithmic
     # bytes over the wall time of a step

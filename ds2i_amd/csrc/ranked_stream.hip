@@ -78,9 +78,14 @@ struct LdsRS {
 // FREQS (with AND): and_query<with_freqs> -- the freq of every list is touched for every document of the intersection (queries.hpp:62-84;
 // here: summed into the query's checksum). The hints still rule out every candidate that is in no intersection without a search; what
 // passes them is looked up in every list (a member's freq is in that list's block), list 0's freq came with its doc-id.
-template <int NT, bool STATS, bool AND = false, bool FREQS = false>
-__global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_unused) {
+// NK > 1 (ranked_and with k > 64; topk_queue has no limit, queries.hpp:152-197): NK scores per lane (TopKBig<NK>: k <= 64 NK) at the
+// price of NK registers and NK times the work per heap insert -- fewer waves per SIMD. These instantiations also take one-term
+// queries (nt = 1 in a capacity-4 launch: no list 1, every test on it passes), which otherwise keep their class kernel.
+#define RS_WAVES_K(NT, NK) ((NK) == 1 ? RS_WAVES(NT) : (RS_WAVES(NT) < ((NK) <= 4 ? 4 : 3) ? RS_WAVES(NT) : ((NK) <= 4 ? 4 : 3)))
+template <int NT, bool STATS, bool AND = false, bool FREQS = false, int NK = 1>
+__global__ void __launch_bounds__(64, RS_WAVES_K(NT, NK)) k_ranked_stream(BatchArgs a_unused) {
     static_assert(AND || !FREQS, "FREQS is a variant of AND");
+    static_assert(NK == 1 || !AND, "the big heap is ranked_and's");
     static_assert(NT >= 2 && NT <= 16, "list capacities 2..16");
     __shared__ LdsRS<NT> L;
     const uint32_t lane = lane_id();
@@ -133,8 +138,9 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
         // NT is the list CAPACITY of the instantiation (2, 4, 6, 8); the query has nt <= NT lists (UnitRec::pad; two lists: always 2).
         // A list slot j >= nt does not exist: its bytes are never loaded, count as zero, and no test looks at them.
         const uint32_t nt = NT == 2 ? 2u : uniform(u.pad);
+        const bool has1 = NT == 2 || nt > 1u; // (a one-term query in a capacity-4 launch, NK > 1 only: there is no list 1)
         const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(u.qt_off)); // nt terms
-        TopK tk;
+        typename std::conditional<NK == 1, TopK, TopKBig<NK>>::type tk;
         tk.init(a->k);
         unsigned long long and_count = 0; // (AND: results of this unit)
         unsigned long long and_fsum = 0;  // (FREQS: this lane's share of the unit's freq checksum)
@@ -396,7 +402,8 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                 // those of the prefetch above
                 if (haveN) { if (shared_floor) rs_wait_vm<PF_LOADS + 1>(); else rs_wait_vm<PF_LOADS>(); } else rs_wait_vm<0>();
                 PT(PH_TOPK);
-                const uint32_t x0 = L.gb[0][lane], x1 = L.gb[1][lane]; // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists)
+                // the byte fetched ahead: list 1's weight (2 lists) or hint (3, 4 lists); without a list 1: "several postings", which passes every test
+                const uint32_t x0 = has1 ? L.gb[0][lane] : 255u, x1 = has1 ? L.gb[1][lane] : 255u;
                 GP gP0 = x0, gP1 = x1;
                 // (the threshold only rises: a candidate alive now was alive when the gathers were issued, so its byte is there)
                 bool ok0 = (dB0 != 0xFFFFFFFFu) & enters((boB0 + B.rest) * BOUND_SLACK) & (x0 != 0u);
@@ -528,7 +535,7 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
                     uint32_t fs0 = 0, fs1 = 0; // (FREQS: the candidate's freqs so far, list 0's first)
                     if constexpr (FREQS) { fs0 = L.stage[bufB][lane]; fs1 = L.stage[bufB][lane + 64]; }
                     if constexpr (!AND) {
-                        rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
+                        if (has1) rows1 = rows_load((const uint2*)rs_args()->skip + cget(C_BB), rs_args()->bmw + cget(C_BB), (cget(C_N) + 127u) >> 7, cget(C_CUR) + 1u);
                         nl0 = ok0 ? norm_lens[dB0] : 1.f;
                         nl1 = ok1 ? norm_lens[dB1] : 1.f;
                         LC(PH_SCORE, lines_of(norm_lens + dB0, ok0, 4u) + lines_of(norm_lens + dB1, ok1, 4u));
@@ -805,6 +812,25 @@ __global__ void __launch_bounds__(64, RS_WAVES(NT)) k_ranked_stream(BatchArgs a_
 } // namespace
 
 extern "C" {
+#ifdef DS2I_RS_BIGK_TU
+// ranked_and with 64 < k <= 1024 (compiled as a translation unit of its own: -DDS2I_RS_BIGK_TU, ds2i_amd/build.py): k <= 256 keeps four
+// scores per lane, beyond that sixteen; cap as below, one-term queries ride in the capacity-4 launch
+hipError_t ds2i_launch_ranked_stream_bigk(int cap, const void* args, unsigned grid, hipStream_t s) {
+    const BatchArgs& a = *(const BatchArgs*)args;
+    const dim3 g(grid), b(64);
+    const bool st = a.stats != nullptr;
+#define DS2I_RSK_CASE(N) case N: \
+        if (a.k <= 256) { if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, false, false, 4>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, false, false, 4>), g, b, 0, s, a); } \
+        else { if (st) hipLaunchKernelGGL((k_ranked_stream<N, true, false, false, 16>), g, b, 0, s, a); else hipLaunchKernelGGL((k_ranked_stream<N, false, false, false, 16>), g, b, 0, s, a); } \
+        break;
+    switch (cap) {
+    DS2I_RSK_CASE(2) DS2I_RSK_CASE(4) DS2I_RSK_CASE(6) DS2I_RSK_CASE(8) DS2I_RSK_CASE(16)
+    default: return hipErrorInvalidValue;
+    }
+#undef DS2I_RSK_CASE
+    return hipGetLastError();
+}
+#else
 // cap = list capacity of the launch (2, 4, 6, 8, 16): every query of it has cap - 1 or cap (16: 9 .. 16) distinct terms (UnitRec::pad = the count; the
 // planner's DS2I_STREAM_NT_MAX caps it); the caller has checked that the index is block_optpfor with skip table, block weights, range
 // tables and side slots, and that k <= 64
@@ -820,6 +846,8 @@ hipError_t ds2i_launch_ranked_stream(int cap, const void* args, unsigned grid, h
 #undef DS2I_RS_CASE
     return hipGetLastError();
 }
+#endif
+#ifndef DS2I_RS_BIGK_TU
 // and_query (counts; with_freqs: counts + the freq checksum) through the same pipeline (k_ranked_stream<cap, ., AND = true, FREQS>); same preconditions
 hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, unsigned grid, hipStream_t s) {
     const BatchArgs& a = *(const BatchArgs*)args;
@@ -836,4 +864,5 @@ hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, un
 #undef DS2I_AND_CASE
     return hipGetLastError();
 }
+#endif
 }

@@ -89,6 +89,14 @@ DS2I_DEV void store_topk_rs(float* topk, uint32_t* topk_len, uint32_t k, uint32_
     if (lane < k) topk[(size_t)slot * k + lane] = tk.v;
     if (lane == 0) topk_len[slot] = tk.n;
 }
+template <int NK>
+DS2I_DEV void store_topk_rs(float* topk, uint32_t* topk_len, uint32_t k, uint32_t slot, const TopKBig<NK>& tk) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < NK; ++r)
+        if ((uint32_t)r * 64u + lane < k) topk[(size_t)slot * k + (uint32_t)r * 64u + lane] = tk.v[r];
+    if (lane == 0) topk_len[slot] = tk.n;
+}
 
 template <int I, int N, class F>
 DS2I_DEV void rs_for(F& f) {
