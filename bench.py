@@ -299,7 +299,9 @@ def main():
 
     # ---------------------------------------------------------------- oracle legs (rank 0 only; the only place this file touches oracle/)
     cls_of = lambda n: 0 if n <= 2 else 1 if n <= 4 else 2 if n <= 8 else 3 if n <= 16 else 4
-    if args.k > 64:  # the whole batch runs the big-heap kernel of the last class (ds2i_hip.h: DS2I_HIP_MAX_K)
+    if args.k > 64 and not any(batch.class_groups(c) for c in range(NCLS - 1)):
+        # k > 64 with a query of more than 16 lists (or a natively queried block_mixed image): the whole batch runs the big-heap kernel of
+        # the last class (ds2i_hip.h: DS2I_HIP_MAX_K). Otherwise k <= 1024 stays on the stream kernels, 4 or 16 scores per lane.
         cls_of = lambda n: NCLS - 1
     nterms = [len(set(q)) for q in queries]
     a_skip_q = [None] * NCLS  # reference-traversal bytes per query of each class (SURVEY.md §8(d) A_skip)

@@ -14,7 +14,7 @@ ARCH = "gfx950"
 # ranked_stream.hip holds the pipelined ranked_and kernels of the benchmark configuration;
 # kernels.hip is compiled six times: once per list-count class (-DDS2I_TU_TMAX=n: the query kernels of that class; 0 = the
 # long class) and once for everything else; encode_kernels.hip holds the index encoder; all units are built in parallel
-DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", []), ("ranked_stream.hip", "ranked_stream.hip", []), ("ranked_stream_mixed.hip", "ranked_stream_mixed.hip", []), ("freq_stream.hip", "freq_stream.hip", []), ("union_stream.hip", "union_stream.hip", []), ("encode_kernels.hip", "encode_kernels.hip", [])]
+DEVICE_UNITS = [("kernels.hip", "kernels_t%d.hip" % t, ["-DDS2I_TU_TMAX=%d" % t]) for t in (2, 4, 8, 16, 0)] + [("kernels.hip", "kernels.hip", []), ("ranked_stream.hip", "ranked_stream.hip", []), ("ranked_stream.hip", "ranked_stream_bigk.hip", ["-DDS2I_RS_BIGK_TU"]), ("ranked_stream_mixed.hip", "ranked_stream_mixed.hip", []), ("freq_stream.hip", "freq_stream.hip", []), ("union_stream.hip", "union_stream.hip", []), ("union_stream.hip", "union_stream_bigk.hip", ["-DDS2I_US_BIGK_TU"]), ("encode_kernels.hip", "encode_kernels.hip", [])]
 HOST_SRCS = ["capi.cpp", "capi_batch.cpp", "capi_build.cpp", "capi_encode.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

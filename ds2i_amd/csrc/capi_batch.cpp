@@ -37,10 +37,12 @@ using ds2i_dev::Unit;
 extern "C" {
 hipError_t ds2i_launch_batch(int op, int tmax_class, const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_ranked_stream(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip
+hipError_t ds2i_launch_ranked_stream_bigk(int cap, const void* args, unsigned grid, hipStream_t s); // ranked_stream.hip compiled with -DDS2I_RS_BIGK_TU (k > 64)
 hipError_t ds2i_launch_freq_stream(const void* args, unsigned longest, unsigned nqterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_and_stream(const void* args, int with_freqs, unsigned longest, unsigned nterms, hipStream_t s); // freq_stream.hip
 hipError_t ds2i_launch_and_rstream(int cap, int with_freqs, const void* args, unsigned grid, hipStream_t s);       // ranked_stream.hip (AND = true)
 hipError_t ds2i_launch_union_stream(int nt, const void* args, unsigned grid, hipStream_t s);     // union_stream.hip (wand / maxscore / ranked_or)
+hipError_t ds2i_launch_union_stream_bigk(int cap, const void* args, unsigned grid, hipStream_t s); // union_stream.hip compiled with -DDS2I_US_BIGK_TU (k > 64)
 hipError_t ds2i_launch_ranked_stream_mixed(int nt, const void* args, unsigned grid, hipStream_t s); // ranked_stream_mixed.hip
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s);
 hipError_t ds2i_launch_copy_seed(const uint32_t* queries, uint32_t n, uint32_t k, const float* seed_topk, const uint32_t* seed_len,
@@ -56,6 +58,7 @@ struct PlanChunk {
     std::vector<uint32_t> qnbs;
     double total_cost[NCLS] = {};
     uint32_t long_terms = 0;
+    bool over16 = false; // some query of the range has more than DS2I_HIP_MAX_TERMS distinct terms
     int rc = 0;
     const char* err = nullptr;
 };
@@ -276,6 +279,20 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     // k > 64 (one score per lane no longer suffices): every query takes the one-document-per-step kernel with a 16-scores-
     // per-lane heap and its enumerator state in global scratch -- slower, same results (the reference has no limit on k)
     const bool bigk = ranked && k > DS2I_HIP_MAX_K;
+    // ... except ranked_and on block_optpfor with every table: k_ranked_stream is compiled with 4 / 16 scores per lane too, and those
+    // instantiations also take the one-term queries -- every query of 1 .. DS2I_STREAM_NT_MAX terms stays on the pruned stream path
+    const bool bigk_stream = bigk && base_op == DS2I_OP_RANKED_AND && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots &&
+                             idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw && !kn.no_ranked_stream && kn.stream_nt_max >= 4;
+    // ... and wand / maxscore / ranked_or there (k_union_stream with the same heaps; their one-term queries are answered by the ranked_and seed pass)
+    bool bigk_union = bigk && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR) && !(op & DS2I_OP_REFERENCE_ORDER) &&
+                            idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && idx->d_bmw && idx->d_rmw && !kn.no_union_rstream &&
+                            !kn.no_ranked_stream && kn.stream_nt_max >= 4;
+    auto goes_long = [&](size_t nterms) {
+        if (!bigk) return nterms > DS2I_HIP_MAX_TERMS;
+        if (bigk_stream) return !(nterms >= 1 && nterms <= kn.stream_nt_max);
+        if (bigk_union) return nterms > DS2I_HIP_MAX_TERMS; // (an empty query: the empty virtual query's unit, as for k <= 64)
+        return true;
+    };
     if (!ranked) k = 1; // and / or return counts only: k is ignored, no top-k is produced or copied
 
     b->op = op;
@@ -408,8 +425,9 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         }
         qoff[q + 1] = (uint32_t)(qterms.size() - begin); // (terms of this query: turned into offsets once the ranges are joined)
         qcost[q] = cost;
-        ch.total_cost[bigk ? CLS_LONG : class_of(tf.size())] += cost;
-        if (bigk || tf.size() > DS2I_HIP_MAX_TERMS) ch.long_terms = std::max<uint32_t>(ch.long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
+        ch.total_cost[goes_long(tf.size()) ? CLS_LONG : class_of(tf.size())] += cost;
+        if (tf.size() > DS2I_HIP_MAX_TERMS) ch.over16 = true;
+        if (goes_long(tf.size())) ch.long_terms = std::max<uint32_t>(ch.long_terms, (uint32_t)std::max<size_t>(1, tf.size()));
         }
     };
     // default: 4, but never more than this process's share of the CPUs it may use -- one rank per GPU under torchrun
@@ -435,12 +453,23 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         chunks[c].q0 = (uint32_t)((uint64_t)nq * c / nchunks);
         chunks[c].q1 = (uint32_t)((uint64_t)nq * (c + 1) / nchunks);
         chunks[c].rc = 0;
-        chunks[c].long_terms = 0;
-        for (double& v : chunks[c].total_cost) v = 0;
     }
-    ds2i_plan_pool_run(nchunks, [&](unsigned c) { plan_range(chunks[c]); });
-    for (unsigned c = 0; c < nchunks; ++c)
-        if (chunks[c].rc) return ds2i_set_error(chunks[c].rc, chunks[c].err);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (unsigned c = 0; c < nchunks; ++c) {
+            chunks[c].long_terms = 0;
+            chunks[c].over16 = false;
+            for (double& v : chunks[c].total_cost) v = 0;
+        }
+        ds2i_plan_pool_run(nchunks, [&](unsigned c) { plan_range(chunks[c]); });
+        for (unsigned c = 0; c < nchunks; ++c)
+            if (chunks[c].rc) return ds2i_set_error(chunks[c].rc, chunks[c].err);
+        // k > 64 through the union streams needs the whole batch on them (the kernels see virtual queries; k_daat_long does not): a
+        // query beyond 16 terms sends the batch back to the one-document-per-step kernels -- planned again, once
+        bool over = false;
+        for (unsigned c = 0; c < nchunks; ++c) over = over || chunks[c].over16;
+        if (!(bigk_union && over)) break;
+        bigk_union = false;
+    }
     {
         size_t total = 0;
         for (unsigned c = 0; c < nchunks; ++c) total += chunks[c].qterms.size();
@@ -471,7 +500,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     for (int c = 0; c < NCLS; ++c) b->nqcls[c] = 0;
     // ranked_or takes the seed only in its block-synchronous form: its reference-order traversal stays the unpruned
     // exhaustive OR of queries.hpp:404-476 (the oracle the reference tests wand / maxscore against)
-    const bool seeded = nq && !bigk && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
+    const bool seeded = nq && (!bigk || bigk_union) && (base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE ||
                                         (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
@@ -489,7 +518,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     // queries beyond 16 terms and k > 64 keep the one-document-per-step kernel, and the whole batch keeps the windowed
     // kernel when any query does (one operator = one kernel family per batch)
     const bool disj_topk_op = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
-    b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
+    b->union_stream = disj_topk_op && !(op & DS2I_OP_REFERENCE_ORDER) && (!bigk || bigk_union) && idx->d_rmw && idx->d_bmw && idx->d_skip_or_pef() &&
                       !b->long_terms;
     // (list_stream: what a stream over ONE list needs -- its blocks through the side slots; and_stream: the other lists' bitmaps as well)
     const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
@@ -519,7 +548,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     };
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t nt = qoff[q + 1] - qoff[q];
-        const int c = bigk ? CLS_LONG : class_of(nt);
+        const int c = goes_long(nt) ? CLS_LONG : class_of(nt);
         // multi-list units are latency-bound chains (non-sequential probes): cut 4x finer so the tail stays parallel; the 9-16-term
         // class (one or two waves per SIMD; its few, long units were the last thing every batch waited for) 4x finer still
         const double unit_div = 4.0, unit_div_rmw = 4.0, unit_div_many = 4.0;
@@ -741,7 +770,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
         // its membership in every other list is counted without any of them being searched or decoded (k_conjunctive<false, ...>
         // verifies every survivor of its filters by a probe).
         const bool rs_and = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && idx->kind == DS2I_BLOCK_OPTPFOR; // (with or without the doc-id lists)
-        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && !bigk && c <= (rs_nt > 8 ? 3 : rs_nt > 4 ? 2 : 1) && !no_rs &&
+        const bool rs_ok = (base_op == DS2I_OP_RANKED_AND || rs_and) && !(op & DS2I_OP_REFERENCE_ORDER) && (!bigk || bigk_stream) && c <= (rs_nt > 8 ? 3 : rs_nt > 4 ? 2 : 1) && !no_rs &&
                            ((idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots) || idx->kind == DS2I_BLOCK_MIXED) && idx->d_skip && idx->d_bmw && idx->d_rmw;
         if (rs_ok) {
             // launch groups by list CAPACITY 2 | 4 | 6 | 8 (block_optpfor: a group holds the queries of cap - 1 and cap lists, UnitRec::pad says
@@ -751,6 +780,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             auto nt_of = [&](uint32_t uid) { const uint32_t q = b->units[uid].q; return qoff[q + 1] - qoff[q]; };
             auto cap_of = [&](uint32_t uid) {
                 const uint32_t n = nt_of(uid);
+                if (n == 1 && bigk_stream) return 4u; // (k > 64: the one-term queries ride in the capacity-4 launch)
                 return n < 2 ? n : n > rs_nt ? DS2I_HIP_MAX_TERMS + 1u : exact ? n : n > 8 ? (uint32_t)DS2I_HIP_MAX_TERMS : (n + 1u) & ~1u;
             };
             {   // stable partition by capacity, largest first
@@ -1131,9 +1161,10 @@ int launch_batch(ds2i_hip_batch* b) {
             hipStream_t sg = (gi > 0 && nspare && ((c == 0 && side_group0 && !sl.stream) || (c == 2 && side_group2 && gi == 1))) ? spare[next_spare++ % nspare] : s;
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi], sg));
             if (sl.stream && !a.block_profile && a.skip && a.bmw && a.rmw)
-                HIP_OK(b->union_stream ? ds2i_launch_union_stream((int)sl.lists, &a, a.nslice, sg)
+                HIP_OK(b->union_stream ? (b->k > DS2I_HIP_MAX_K ? ds2i_launch_union_stream_bigk((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_union_stream((int)sl.lists, &a, a.nslice, sg))
                        : (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) ? ds2i_launch_and_rstream((int)sl.lists, base_op == DS2I_OP_AND_FREQ ? 1 : 0, &a, a.nslice, sg)
-                       : idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
+                       : idx->kind == DS2I_BLOCK_MIXED ? ds2i_launch_ranked_stream_mixed((int)sl.lists, &a, a.nslice, sg)
+                       : b->k > DS2I_HIP_MAX_K ? ds2i_launch_ranked_stream_bigk((int)sl.lists, &a, a.nslice, sg) : ds2i_launch_ranked_stream((int)sl.lists, &a, a.nslice, sg));
             else HIP_OK(ds2i_launch_batch(b->freq_stream ? (int)DS2I_OP_OR : (b->op & (0xFF | DS2I_OP_REFERENCE_ORDER)), c, &a, a.nslice, sg));
             HIP_OK(hipEventRecord(b->ev_g[c][2 * gi + 1], sg));
             if (sg != s) HIP_OK(hipStreamWaitEvent(sm, b->ev_g[c][2 * gi + 1], 0));

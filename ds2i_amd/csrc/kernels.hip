@@ -206,7 +206,9 @@ hipError_t ds2i_launch_list_top_bmw(const float* bmw, const void* lists, uint32_
 
 hipError_t ds2i_launch_merge(const void* args, unsigned grid, hipStream_t s) {
     const MergeArgs& a = *(const MergeArgs*)args;
-    hipLaunchKernelGGL(k_merge, dim3(grid), dim3(64), 0, s, a);
+    if (a.ranked && a.k > 256) hipLaunchKernelGGL((k_merge_big<16>), dim3(grid), dim3(64), 0, s, a);
+    else if (a.ranked && a.k > 64) hipLaunchKernelGGL((k_merge_big<4>), dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_merge, dim3(grid), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

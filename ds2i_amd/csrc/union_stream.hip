@@ -65,8 +65,10 @@ struct LdsUS {
 // instruction cache two CUs share -- and ran 63 queries in the time the 5-list kernel ran 334)
 enum { LS_CUR = 0, LS_BMAX, LS_N, LS_BB, LS_LOLO, LS_LOHI, LS_QW, LS_TLLO, LS_TLHI, LS_RSC };
 
-template <int NT, bool STATS>
-__global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_unused) {
+// NK > 1 (k > 64; topk_queue has no limit, queries.hpp:152-197): NK scores per lane (TopKBig<NK>: k <= 64 NK), fewer waves per SIMD
+#define US_WAVES_K(NT, NK) ((NK) == 1 ? US_WAVES(NT) : (US_WAVES(NT) < ((NK) <= 4 ? 4 : 3) ? US_WAVES(NT) : ((NK) <= 4 ? 4 : 3)))
+template <int NT, bool STATS, int NK = 1>
+__global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchArgs a_unused) {
     static_assert(NT >= 2 && NT <= 16, "list capacities 2..16");
     __shared__ LdsUS<NT> L;
     const uint32_t lane = lane_id();
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
         const uint32_t nt = NT == 2 ? 2u : uniform(u.pad) >> 8; // lists of this virtual query (2 .. NT)
         const bool whole = uniform(u.nparts) == 1u;
         const QTerm* const qt = rs_uniform_ptr(a->qterms + uniform(u.qt_off)); // nt terms
-        TopK tk;
+        typename std::conditional<NK == 1, TopK, TopKBig<NK>>::type tk;
         tk.init(a->k);
         // ---- list 0: the driver
         const uint32_t n0 = uniform(qt[0].n), nb0 = (n0 + 127u) >> 7;
@@ -670,6 +672,25 @@ __global__ void __launch_bounds__(64, US_WAVES(NT)) k_union_stream(BatchArgs a_u
 } // namespace
 
 extern "C" {
+#ifdef DS2I_US_BIGK_TU
+// wand / maxscore / ranked_or with 64 < k <= 1024 (a translation unit of its own: -DDS2I_US_BIGK_TU, ds2i_amd/build.py): k <= 256 keeps
+// four scores per lane, beyond that sixteen; cap as below
+hipError_t ds2i_launch_union_stream_bigk(int cap, const void* args, unsigned grid, hipStream_t s) {
+    const BatchArgs& a = *(const BatchArgs*)args;
+    const dim3 g(grid), b(64);
+    const bool st = a.stats != nullptr;
+#define DS2I_USK_CASE(N) case N: \
+        if (a.k <= 256) { if (st) hipLaunchKernelGGL((k_union_stream<N, true, 4>), g, b, 0, s, a); else hipLaunchKernelGGL((k_union_stream<N, false, 4>), g, b, 0, s, a); } \
+        else { if (st) hipLaunchKernelGGL((k_union_stream<N, true, 16>), g, b, 0, s, a); else hipLaunchKernelGGL((k_union_stream<N, false, 16>), g, b, 0, s, a); } \
+        break;
+    switch (cap) {
+    DS2I_USK_CASE(2) DS2I_USK_CASE(4) DS2I_USK_CASE(6) DS2I_USK_CASE(8) DS2I_USK_CASE(16)
+    default: return hipErrorInvalidValue;
+    }
+#undef DS2I_USK_CASE
+    return hipGetLastError();
+}
+#else
 // cap = list capacity of the launch (2, 4, 6, 8, 16): every virtual query of it has cap - 1 or cap (16: 9 .. 16) lists (driver + exclusions + optional
 // lists; UnitRec::pad = exclusion lists | lists << 8); the caller has checked that the index is block_optpfor with skip table, block
 // weights, range tables and side slots, that k <= 64, and has filled BatchArgs::urec and BatchArgs::q_floor
@@ -685,4 +706,5 @@ hipError_t ds2i_launch_union_stream(int cap, const void* args, unsigned grid, hi
 #undef DS2I_US_CASE
     return hipGetLastError();
 }
+#endif
 }

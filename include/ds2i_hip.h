@@ -71,8 +71,10 @@ enum ds2i_hip_error {
 #define DS2I_HIP_MAX_TERMS_LONG 1024 /* beyond 16 distinct terms a query runs the one-document-per-step traversal with
                                         its enumerator state in global memory (the reference has no limit, queries.hpp:35-86) */
 #define DS2I_HIP_MAX_K 64            /* top-k kept one score per lane (the fast kernels) */
-#define DS2I_HIP_MAX_K_LONG 1024     /* beyond 64 a ranked batch runs the one-document-per-step kernel with 16 scores per
-                                        lane (the reference's topk_queue has no limit, queries.hpp:152-197) */
+#define DS2I_HIP_MAX_K_LONG 1024     /* beyond 64 the same stream kernels run with 4 (k <= 256) or 16 scores per lane; only a
+                                        batch that also holds a query of more than 16 terms, or a natively queried block_mixed
+                                        image, falls to the one-document-per-step kernel (the reference's topk_queue has no
+                                        limit, queries.hpp:152-197) */
 
 typedef struct ds2i_hip_index ds2i_hip_index;
 typedef struct ds2i_hip_batch ds2i_hip_batch;

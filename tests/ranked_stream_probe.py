@@ -29,13 +29,13 @@ def one(seed):
     for n in list(range(2, 9)) + [9, 11, 13, 16]:  # every list count up to 8, a few beyond: terms anywhere in the vocabulary (mostly empty intersections, early exits) ...
         qs += [sorted(set(int(x) for x in rng.integers(0, nt, n + 2)))[:n] for _ in range(40)]
         qs += [[int(x) for x in rng.permutation(min(nt, 14 if n <= 8 else 22))[:n]] for _ in range(60 if n <= 8 else 15)]  # ... and among the densest lists (big intersections)
-    qs += [list(range(8)), list(range(7, -1, -1)), [0, 1, 2, 3, 4], [nt - 1, 0, 1, 2, 3, 4]]
+    qs += [list(range(8)), list(range(7, -1, -1)), [0, 1, 2, 3, 4], [nt - 1, 0, 1, 2, 3, 4], [0], [nt - 1], [3, 3], []]
     img = d.build_index("block_optpfor", nd, lists)
     gidx = d.Index("block_optpfor", img, wand)
     oidx = o.Index("block_optpfor", img, wand)
     pipe = d.Pipeline(gidx, depth=2)
     streamed = set()
-    for k in (1, 10, 64):
+    for k in (1, 10, 64, 100, 700):  # (beyond 64: the 4- and 16-scores-per-lane instantiations, which also take the one-term queries)
         oc, otopk, otlen, _, _ = oidx.query_batch("ranked_and", qs, k=k)
         b = d.Batch(gidx, "ranked_and", qs, k=k)
         b.run()

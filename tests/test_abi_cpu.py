@@ -116,12 +116,12 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
                     assert "_lds_" in t.split()[0], (name, t)
                     dma += 1
             # (the AND instantiations of k_ranked_stream have no shared floor word to fetch: one hand-issued load fewer)
-            assert dma >= (min_dma - 1 if re.search(r"k_ranked_streamILi\d+ELb\dELb1ELb\dEE", name) else min_dma), (src, name)
+            assert dma >= (min_dma - 1 if re.search(r"k_ranked_streamILi\d+ELb\dELb1ELb\dELi1EE", name) else min_dma), (src, name)
             assert asm_audit.audit(lines) == [], (src, name)
     # Two blocks in flight: between the hand-issued prefetch of block i+2 and the first LDS read of block i+1's decode the compiler must
     # not have put a wait that drains it. (Round 6 found an `s_waitcnt vmcnt(0)` there in every iteration -- the rare general side-slot
     # decoder's loads stayed "possibly pending" for hipcc's wait-count pass on the hot path; rs_settle_vm(), stream_common.hpp.)
-    for src, pat in (("ranked_stream.hip", r"k_ranked_streamILi\d+ELb0ELb0ELb0EE"), ("union_stream.hip", r"k_union_streamILi\d+ELb0EE")):
+    for src, pat in (("ranked_stream.hip", r"k_ranked_streamILi\d+ELb0ELb0ELb0ELi1EE"), ("union_stream.hip", r"k_union_streamILi\d+ELb0ELi1EE")):
         checked = 0
         for name, lines in asm_audit.kernels(texts[src]).items():
             if not re.search(pat, name):
@@ -149,7 +149,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     budget = {2: (80, 0, 0, 64), 4: (80, 24, 80, 110), 6: (128, 0, 0, 150), 8: (168, 0, 0, 190), 16: (256, 0, 0, 340)}
     seen = 0
     for nm, m in meta.items():
-        mm = re.search(r"k_ranked_streamILi(\d+)ELb0ELb0ELb0EE", nm)  # (capacity, STATS = false, AND = false: the shipped ranked_and instantiations)
+        mm = re.search(r"k_ranked_streamILi(\d+)ELb0ELb0ELb0ELi1EE", nm)  # (capacity, STATS = false, AND = false: the shipped ranked_and instantiations)
         if not mm:
             continue
         seen += 1
@@ -164,7 +164,7 @@ def test_hand_issued_loads_have_no_register_destination(tmp_path):
     ubudget = {2: (80, 0, 0, 64), 4: (96, 2, 8, 140), 6: (128, 0, 0, 200), 8: (168, 0, 0, 270), 16: (256, 0, 0, 540)}
     seen = 0
     for nm, m in umeta.items():
-        mm = re.search(r"k_union_streamILi(\d+)ELb0EE", nm)
+        mm = re.search(r"k_union_streamILi(\d+)ELb0ELi1EE", nm)
         if not mm:
             continue
         seen += 1

@@ -471,13 +471,14 @@ def test_topk_other_k(coll, queries, images):
 
 
 def test_topk_beyond_64(coll, queries, images):
-    """k up to DS2I_HIP_MAX_K_LONG: the reference's topk_queue has no limit (queries.hpp:152-197). Beyond 64 the batch
+    """k up to DS2I_HIP_MAX_K_LONG: the reference's topk_queue has no limit (queries.hpp:152-197). Beyond 64 ranked_and on block_optpfor
+    stays on the stream kernels (4 / 16 scores per lane; the fuzz of it: test_ranked_and_through_the_stream_pipeline); everything else
     runs the one-document-per-step kernels with a 16-scores-per-lane heap."""
     sub = queries[:60] + [[], [5], [0, 1, 2], list(range(20))]
     for codec in ("block_optpfor", "opt"):
         gidx = d.Index(codec, images[0][codec], images[1])
         oidx = o.Index(codec, images[0][codec], images[1])
-        for k in (65, 200, 1024):
+        for k in (65, 100, 200, 1024):
             for op in ("ranked_and", "ranked_or", "wand", "maxscore"):
                 _check_against_oracle(gidx, oidx, op, sub, k=k)
     with pytest.raises(d.Ds2iError):

@@ -2,8 +2,8 @@
 """wand / maxscore / ranked_or through the stream pipeline (k_union_stream<cap>, list capacities 2 | 4 | 6 | 8 | 16: union_stream.hip) against the oracle's
 reference-order traversals (queries.hpp:200-319, 404-476, 478-591): random collections -- short and long lists paired (ranges wider than
 128 doc-ids: an exclusion list's hint is no proof there), dense lists (one doc-id per table entry), clustered lists (several postings per
-range: hint 255) -- queries of 2..16 terms anywhere in the vocabulary, among the densest lists, among the shortest; k = 10 and a k larger
-than most unions. Checked: top-k lengths equal, scores within 1e-5 relative of the oracle's, wand == maxscore == ranked_or bit for bit,
+range: hint 255) -- queries of 2..16 terms anywhere in the vocabulary, among the densest lists, among the shortest; k = 10, a k larger
+than most small unions, and k beyond one score per lane (100, 300). Checked: top-k lengths equal, scores within 1e-5 relative of the oracle's, wand == maxscore == ranked_or bit for bit,
 the pipelined ABI gives the same bits. Run as a subprocess by tests/test_gpu.py (the library's knobs are read once per process):
 `[DS2I_NO_RMH=1 | DS2I_RMW_G=1 | DS2I_NO_UNION_RSTREAM=1] python tests/union_stream_probe.py [seeds]`. The oracle is the checker, nothing else."""
 import os
@@ -37,7 +37,7 @@ def one(seed):
     gidx = d.Index("block_optpfor", img, wand)
     oidx = o.Index("block_optpfor", img, wand)
     streamed = set()
-    for k in (10, 37):
+    for k in (10, 37, 100, 300):  # (beyond 64: the 4- and 16-scores-per-lane instantiations)
         _, otopk, olen, _, _ = oidx.query_batch("wand", qs, k=k)
         got = {}
         for op in ("wand", "maxscore", "ranked_or"):
