@@ -1016,11 +1016,14 @@ int launch_batch(ds2i_hip_batch* b) {
         HIP_OK(hipStreamSynchronize(idx->s_up));
     }
     auto cls_stream = [&](int c) { return idx->stream[c]; };
-    // every class stream first waits for the upload + cleared buffers, and for the seed pass when there is one
+    // every class stream first waits for the upload + cleared buffers, and for the seed pass when its floors feed the kernels. (In the
+    // union decomposition the seed pass only ANSWERS the one-term queries -- copied into the result block on the merge stream below --
+    // and the kernels of the longer queries start beside it: waiting cost the wand batch the one-term kernel's 1.2 ms in series.)
+    const bool seed_feeds = b->use_seed && !b->union_stream;
     for (int c = 0; c < NCLS; ++c) {
         if (!b->ncls[c]) continue;
         HIP_OK(hipStreamWaitEvent(cls_stream(c), b->ev_clear, 0));
-        if (b->use_seed) HIP_OK(hipStreamWaitEvent(cls_stream(c), b->seed->ev_done, 0));
+        if (seed_feeds) HIP_OK(hipStreamWaitEvent(cls_stream(c), b->seed->ev_done, 0));
     }
     HIP_OK(hipStreamWaitEvent(sm, b->ev_clear, 0));
     if (b->use_seed) HIP_OK(hipStreamWaitEvent(sm, b->seed->ev_done, 0));
@@ -1087,7 +1090,7 @@ int launch_batch(ds2i_hip_batch* b) {
             if (!b->ncls[c]) {
                 spare[nspare] = idx->stream[c];
                 HIP_OK(hipStreamWaitEvent(spare[nspare], b->ev_clear, 0));
-                if (b->use_seed) HIP_OK(hipStreamWaitEvent(spare[nspare], b->seed->ev_done, 0));
+                if (seed_feeds) HIP_OK(hipStreamWaitEvent(spare[nspare], b->seed->ev_done, 0));
                 ++nspare;
             }
     for (int ci = NCLS - 1; ci >= 0; --ci) {
@@ -1124,8 +1127,8 @@ int launch_batch(ds2i_hip_batch* b) {
         a.unit_topk = b->d_scr.at<float>(b->o_unit_topk);
         a.unit_topk_len = b->d_scr.at<uint32_t>(b->o_unit_topk_len);
         a.unit_freq_sum = b->d_scr.at<unsigned long long>(b->o_unit_freq_sum);
-        a.seed_topk = b->use_seed ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
-        a.seed_len = b->use_seed ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
+        a.seed_topk = seed_feeds ? b->seed->d_out.at<float>(b->seed->o_topk) : nullptr;
+        a.seed_len = seed_feeds ? b->seed->d_out.at<uint32_t>(b->seed->o_topk_len) : nullptr;
         const bool disj_topk = base_op == DS2I_OP_WAND || base_op == DS2I_OP_MAXSCORE || base_op == DS2I_OP_RANKED_OR;
         a.q_floor = (base_op == DS2I_OP_RANKED_AND || b->union_rstream) ? b->d_scr.at<unsigned int>(b->o_qfloorw) : nullptr;
         a.q_hist = (!(b->op & DS2I_OP_REFERENCE_ORDER) && b->nsplit && ((base_op == DS2I_OP_RANKED_AND && idx->d_bmw) || disj_topk))

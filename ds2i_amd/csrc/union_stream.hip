@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
         // block asked every table, 1-2 survived their bytes) and one bit per list: some posting of list j lies in the block's doc-id
         // span at all (a clear bit: nobody of this block is in list j -- its table is not asked, for an exclusion list the verdict is in)
         uint32_t s_first = 0, s_valid = 0, s_mask = 0;
+        GP s_g = 0; // ... and, three and more lists: the OPTIONAL lists' span maxima themselves, byte j - 1 = list j (0: exclusion list / nobody there)
         uint2 s_e2 = make_uint2(0xFFFFFFFFu, 0u);
         float s_ub = -1.f, s_w = 0.f, s_rest = 0.f;
         auto s_fill = [&](uint32_t first) __attribute__((always_inline)) {
@@ -235,6 +236,7 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
             const uint32_t b2 = row ? base : 0u, t2 = row ? top : 0u; // branch-free: a lane without a row reads entry 0 and discards it
             float acc = 0.f;
             uint32_t mask = 0;
+            GP gmax = 0;
             auto one_list = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 if ((uint32_t)j >= nt) return;
@@ -247,16 +249,25 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
                 const uint32_t m = max_of_bytes16(rt[j] + loff + (fits ? lo : 0u), fits ? hi - lo + 1u : 1u);
                 const uint32_t best = (row && fits) ? m : 255u; // (255 = the list maximum)
                 mask |= best != 0u ? 1u << j : 0u;
-                if ((uint32_t)j > nexcl) acc = acc + rsc[j] * (float)best; // (an exclusion list adds nothing)
+                if ((uint32_t)j > nexcl) { // (an exclusion list adds nothing)
+                    acc = acc + rsc[j] * (float)best;
+                    if constexpr (NT > 2) gmax |= (GP)best << (8 * (j - 1));
+                }
             };
             rs_for_down<NT, 1>(one_list);
             s_rest = acc;
             s_mask = mask;
+            s_g = gmax;
             s_ub = row ? (qw0 * s_w + acc) * BOUND_SLACK : -1.0f; // (scores are >= 0: -1 never enters)
             rs_settle_vm(); // (once per 63 blocks: no compiler-visible load stays "possibly pending" on the hot path, stream_common.hpp)
         };
         // a block of the driver on its way through the stages (w = its block weight x the driver's query weight)
-        struct Blk { uint32_t blk, base, ep, mask; float w, rest; };
+        struct Blk { uint32_t blk, base, ep, mask; float w, rest; GP g; };
+        auto bcast_gp = [](GP v, uint32_t src) __attribute__((always_inline)) -> GP {
+            GP r = 0;
+            for (int i = 0; i < (int)(sizeof(GP) / 4); ++i) r |= (GP)bcast((uint32_t)(v >> (32 * i)), src) << (32 * i);
+            return r;
+        };
         auto select = [&](uint32_t from, Blk& o) __attribute__((always_inline)) -> uint32_t { // first block >= from worth a visit
             for (;;) {
                 if (from >= blk_end) return 0u;
@@ -270,6 +281,7 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
                     o.w = qw0 * __uint_as_float(bcast(__float_as_uint(s_w), f));
                     o.rest = __uint_as_float(bcast(__float_as_uint(s_rest), f));
                     o.mask = bcast(s_mask, f);
+                    if constexpr (NT > 2) o.g = bcast_gp(s_g, f);
                     return 1u;
                 }
                 if (s_valid && s_first + 64u >= blk_end) return 0u;
@@ -368,24 +380,34 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
                         ok = ok & !((x != 0u) & exact);
                     }
                 };
+                // Three and more lists: a candidate's word starts from the block's own span maxima (what list j can add to ANY posting of
+                // this block) and every byte is replaced by the candidate's own as it arrives; the bound is re-tested after list 1 and
+                // after every round of further lists, and a round asks only those still alive. (Round 5/6 asked every further list about
+                // every candidate list 1 let through, against list MAXIMA: 37 GB of the wand step's 54 GB of lines went to the 245
+                // queries of five and more lists, one 128-byte line per candidate and list.) Every intermediate bound is >= the final
+                // one term by term (same summation chain, larger bytes), so nobody the final test admits is dropped on the way.
+                if constexpr (NT > 2) { gP0 = B.g; gP1 = B.g; }
                 const bool in1 = (B.mask & 2u) != 0u; // (list 1 has a posting in this block's span: its bytes were fetched)
                 if (!in1) {
-                    // nobody of this block is in list 1: not excluded by it, nothing added by it
+                    // nobody of this block is in list 1: not excluded by it, nothing added by it (its byte of B.g is zero)
                 } else if (ex1) {
                     excl_byte(x0, dB0, rsh[1], ok0, need0, 2u);
                     excl_byte(x1, dB1, rsh[1], ok1, need1, 2u);
+                } else if constexpr (NT > 2) {
+                    gP0 = (gP0 & ~(GP)255u) | (GP)x0;
+                    gP1 = (gP1 & ~(GP)255u) | (GP)x1;
+                    ok0 = ok0 & enters((boB0 + rest_of(gP0, 0)) * BOUND_SLACK);
+                    ok1 = ok1 & enters((boB1 + rest_of(gP1, 0)) * BOUND_SLACK);
                 } else {
                     gP0 = x0;
                     gP1 = x1;
-                    if constexpr (NT > 2) { // the further lists are asked only about candidates list 1's weight lets through (list maxima for them)
-                        const float rest = rest_of(g_ff, 1);
-                        ok0 = ok0 & enters((boB0 + (rest + rsc[1] * (float)x0)) * BOUND_SLACK);
-                        ok1 = ok1 & enters((boB1 + (rest + rsc[1] * (float)x1)) * BOUND_SLACK);
-                    }
                 }
                 if constexpr (NT > 2) {
-                    if (ballot(ok0) | ballot(ok1)) { // lists 2..: every list's byte requested before any is tested
-                        uint32_t y0[NT] = {}, y1[NT] = {};
+                    auto round = [&](auto ja_c, auto jb_c) __attribute__((always_inline)) { // lists [JA, JB): requested together, then tested
+                        constexpr int JA = decltype(ja_c)::value, JB = decltype(jb_c)::value;
+                        if ((uint32_t)JA >= nt) return;
+                        if (!(ballot(ok0) | ballot(ok1))) return;
+                        uint32_t y0[JB] = {}, y1[JB] = {};
                         auto load_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             const uint8_t* const tj = ((uint32_t)j <= nexcl && hdelta != 0) ? rt[j] + hdelta : rt[j];
@@ -393,20 +415,29 @@ __global__ void __launch_bounds__(64, US_WAVES_K(NT, NK)) k_union_stream(BatchAr
                             y0[j] = (ok0 & inj) ? (uint32_t)tj[dB0 >> rsh[j]] : 0u;
                             y1[j] = (ok1 & inj) ? (uint32_t)tj[dB1 >> rsh[j]] : 0u;
                         };
-                        rs_for<2, NT>(load_one);
+                        rs_for<JA, JB>(load_one);
                         auto use_one = [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             if ((uint32_t)j <= nexcl) {
                                 excl_byte(y0[j], dB0, rsh[j], ok0, need0, 1u << j);
                                 excl_byte(y1[j], dB1, rsh[j], ok1, need1, 1u << j);
                             } else {
-                                gP0 |= (GP)y0[j] << (8 * (j - 1));
-                                gP1 |= (GP)y1[j] << (8 * (j - 1));
+                                const GP keep = ~((GP)255u << (8 * (j - 1)));
+                                gP0 = (gP0 & keep) | ((GP)y0[j] << (8 * (j - 1)));
+                                gP1 = (gP1 & keep) | ((GP)y1[j] << (8 * (j - 1)));
                             }
                         };
-                        rs_for<2, NT>(use_one);
+                        rs_for<JA, JB>(use_one);
                         rs_settle_vm();
-                    }
+                        ok0 = ok0 & enters((boB0 + rest_of(gP0, 0)) * BOUND_SLACK);
+                        ok1 = ok1 & enters((boB1 + rest_of(gP1, 0)) * BOUND_SLACK);
+                    };
+                    using std::integral_constant;
+                    round(integral_constant<int, 2>{}, integral_constant<int, (NT < 4 ? NT : 4)>{});
+                    if constexpr (NT > 4) round(integral_constant<int, 4>{}, integral_constant<int, (NT < 6 ? NT : 6)>{});
+                    if constexpr (NT > 6) round(integral_constant<int, 6>{}, integral_constant<int, (NT < 8 ? NT : 8)>{});
+                    if constexpr (NT > 8) round(integral_constant<int, 8>{}, integral_constant<int, (NT < 12 ? NT : 12)>{});
+                    if constexpr (NT > 12) round(integral_constant<int, 12>{}, integral_constant<int, NT>{});
                 }
                 PT(PH_MEMBER);
                 float r0 = rest_of(gP0, 0), r1 = rest_of(gP1, 0);

@@ -51,7 +51,10 @@ def one(seed):
             f = np.isfinite(otopk)
             np.testing.assert_allclose(topk[f], otopk[f], rtol=1e-5, err_msg="seed %d %s k %d" % (seed, op, k))
             got[op] = topk
-        assert np.array_equal(got["wand"], got["maxscore"], equal_nan=True) and np.array_equal(got["wand"], got["ranked_or"], equal_nan=True), (seed, k)
+        # (the three operators share the union decomposition and its summation order; behind DS2I_NO_UNION_RSTREAM a k beyond 64 runs
+        # each operator's own one-document-per-step traversal instead: within 1e-5 of the oracle above, not bit-equal to each other)
+        if k <= 64 or not os.environ.get("DS2I_NO_UNION_RSTREAM"):
+            assert np.array_equal(got["wand"], got["maxscore"], equal_nan=True) and np.array_equal(got["wand"], got["ranked_or"], equal_nan=True), (seed, k)
         pipe = d.Pipeline(gidx, depth=2)
         t = pipe.submit("wand", qs, k=k)
         _, ptopk, plen = pipe.wait(t)
