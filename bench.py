@@ -187,20 +187,25 @@ def main():
         for i in range(first, first + n):
             if len(tickets) == args.depth:
                 reap()
+            ts = time.perf_counter()
             tickets.append(pipe.submit(args.op, flat[i], k=args.k))
+            host_s[0] += time.perf_counter() - ts
         while tickets:
             reap()
         return results, cls_ms
 
     done_at = []
     grp_ms = {}
+    host_s = [0.0]  # seconds the caller's thread spent inside ds2i_hip_pipeline_submit (normalisation + planning + H2D + launches)
     _, warm_ms = run_stream(0, args.warmup, True)
     warm_grp_ms = grp_ms
     barrier()
     t0 = time.perf_counter()
     done_at = []
     grp_ms = {}
+    host_s[0] = 0.0
     results, cls_ms = run_stream(args.warmup, args.steps, True)
+    host_submit_ms = 1e3 * host_s[0] / max(1, args.steps)
     timed_grp_ms = grp_ms
     barrier()
     elapsed = time.perf_counter() - t0
@@ -285,6 +290,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
         "timing": "end-to-end over %d distinct batches through ds2i_hip_pipeline_submit/wait (host planning + H2D + kernels + D2H), "
                   "%d in flight" % (args.steps, args.depth),
+        "host_submit_ms_per_step": host_submit_ms,  # the caller's thread inside submit: when this approaches ms_per_step the step is host-bound
         "first_batch_checksum": checksum,
         "kernel_resident_qps": per_rank_q * world / resident_s,  # one prepared batch re-run (rank 0's rate x ranks)
         "end_to_end_over_resident": qps / (per_rank_q * world / resident_s),

@@ -83,6 +83,7 @@ void free_index(ds2i_hip_index* x) {
     if (x->d_tails) (void)hipFree(x->d_tails);
     if (x->d_ticket) (void)hipFree(x->d_ticket);
     for (auto& s : x->stream) if (s) (void)hipStreamDestroy(s);
+    for (auto& s : x->stream_alt) if (s) (void)hipStreamDestroy(s);
     if (x->s_up) (void)hipStreamDestroy(x->s_up);
     if (x->s_merge) (void)hipStreamDestroy(x->s_merge);
     delete x;
@@ -792,6 +793,7 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
         int lo_pri = 0, hi_pri = 0; // numerically lower = higher priority
         HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
         for (int c = 0; c < NCLS; ++c) HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
+        for (int c = 0; c < NCLS; ++c) HIP_OK(hipStreamCreateWithPriority(&x->stream_alt[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));

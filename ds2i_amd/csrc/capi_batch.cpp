@@ -155,6 +155,8 @@ struct ds2i_hip_batch {
     uint32_t k = 0, nq = 0;
     bool want_matches = false;
     bool instrument = true;           // collect ds2i_hip_stats counters (instrumented kernel instantiations)
+    uint32_t pool_batches = 1;        // batches the caller keeps in flight beside this one (pipeline depth): unit sizing
+    bool alt_streams = false;         // launch on the index's second set of class streams (pipeline: odd slots of small batches)
     bool use_seed = false;            // wand / maxscore / ranked_or: `seed` holds this batch's ranked_and pass
     ds2i_hip_batch* seed = nullptr;   // ranked_and pass over the same queries (pruning floor); the slot is kept for reuse
     bool profile_on = false;          // block access profile requested (d_prof)
@@ -504,6 +506,12 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
                                         (base_op == DS2I_OP_RANKED_OR && !(op & DS2I_OP_REFERENCE_ORDER)));
     double all_cost = 0;
     for (double c : total_cost) all_cost += c;
+    // A pipeline keeps several batches in flight: a small batch shares the wave slots with its neighbours, so its units are sized as if
+    // two or three of them were one batch. Sized against its own cost alone a 512-query batch was cut into 20 k units -- three and a half
+    // full rounds of the wave slots, each unit paying its window fill and its heap's warm-up. Measured at GOV2 scale (queries/s with the
+    // multiplier 1 | 1.5 | 2 | 3 | depth): 256 queries 305 k | 349 k | 376 k | 414 k | 359 k; 512: 438 k | 474 k | 522 k | 552 k | 343 k;
+    // 1024: 695 k | 784 k | 844 k | 687 k | 591 k; 2048 (two in 4096): 780 k | 944 k | 990 k.
+    all_cost *= std::min<double>(std::min<double>(nq <= 512 ? 3.0 : 2.0, std::max<uint32_t>(1u, b->pool_batches)), std::max(1.0, 4096.0 / std::max(1u, nq)));
     const double resident = idx->num_cus * 24.0; // waves the concurrent kernels share
     // units per resident wave (tuning knob, DS2I_UNIT_FACTOR): more = better tail balance, more per-unit overhead
     // With range tables a ranked conjunction is cheap per block and the parts of a split query each pay for warming up
@@ -917,6 +925,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
             b->seed = new ds2i_hip_batch;
             b->seed->idx = idx;
         }
+        b->seed->pool_batches = b->pool_batches;
         int rc = plan_batch(b->seed, DS2I_OP_RANKED_AND, k, sterms.data(), soffs.data(), nq, 0);
         if (rc) return rc;
     }
@@ -992,6 +1001,7 @@ int launch_batch(ds2i_hip_batch* b) {
         b->seed->instrument = b->instrument;
         b->seed->profile_on = b->profile_on;
         b->seed->prof_ptr = b->prof_ptr;
+        b->seed->alt_streams = b->alt_streams;
         int rc = launch_batch(b->seed);
         if (rc) return rc;
     }
@@ -1015,7 +1025,8 @@ int launch_batch(ds2i_hip_batch* b) {
         HIP_OK(hipMemsetAsync(b->d_clk.p, 0, 16 * (size_t)(b->nunits ? b->nunits : 1), idx->s_up));
         HIP_OK(hipStreamSynchronize(idx->s_up));
     }
-    auto cls_stream = [&](int c) { return idx->stream[c]; };
+    hipStream_t* const cstreams = b->alt_streams ? idx->stream_alt : idx->stream;
+    auto cls_stream = [&](int c) { return cstreams[c]; };
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when its floors feed the kernels. (In the
     // union decomposition the seed pass only ANSWERS the one-term queries -- copied into the result block on the merge stream below --
     // and the kernels of the longer queries start beside it: waiting cost the wand batch the one-term kernel's 1.2 ms in series.)
@@ -1038,7 +1049,7 @@ int launch_batch(ds2i_hip_batch* b) {
         g.out_count = b->d_out.at<unsigned long long>(b->o_count);
         g.out_freq_sum = base_op == DS2I_OP_AND_FREQ ? b->d_out.at<unsigned long long>(b->o_freq_sum) : nullptr;
         const bool own = b->ncls[CLS_LONG] == 0;
-        hipStream_t sf = own ? idx->stream[CLS_LONG] : sm;
+        hipStream_t sf = own ? cstreams[CLS_LONG] : sm;
         if (own) HIP_OK(hipStreamWaitEvent(sf, b->ev_clear, 0));
         for (size_t t0 = 0; t0 < b->sterms.size(); t0 += 32768) { // (grid.y is limited to 65535)
             g.terms = b->d_up.at<ds2i_dev::StreamTerm>(b->o_sterms) + t0;
@@ -1053,7 +1064,7 @@ int launch_batch(ds2i_hip_batch* b) {
         // beside the union kernels, on the stream of the >16-term class when the batch has no such query (else on the merge
         // stream, ahead of the merge): nobody else writes the checksums (the union kernels and k_merge get no pointer to them)
         const bool own = b->ncls[CLS_LONG] == 0;
-        hipStream_t sf = own ? idx->stream[CLS_LONG] : sm;
+        hipStream_t sf = own ? cstreams[CLS_LONG] : sm;
         if (own) HIP_OK(hipStreamWaitEvent(sf, b->ev_clear, 0));
         ds2i_dev::FreqArgs f{};
         f.arena = idx->d_arena;
@@ -1088,7 +1099,7 @@ int launch_batch(ds2i_hip_batch* b) {
     if (side_group0 || side_group2)
         for (int c = NCLS - 1; c >= 0; --c)
             if (!b->ncls[c]) {
-                spare[nspare] = idx->stream[c];
+                spare[nspare] = cstreams[c];
                 HIP_OK(hipStreamWaitEvent(spare[nspare], b->ev_clear, 0));
                 if (seed_feeds) HIP_OK(hipStreamWaitEvent(spare[nspare], b->seed->ev_done, 0));
                 ++nspare;
@@ -1333,6 +1344,10 @@ namespace {
 int pipeline_launch(ds2i_hip_pipeline* p, size_t slot, int op, uint32_t k, const uint32_t* terms, const uint32_t* offs, uint32_t nq) {
     HIP_OK(hipSetDevice(p->idx->device));
     ds2i_hip_batch* b = p->slots[slot];
+    // (capi_internal.hpp, stream_alt; with the pool-sized units above, GOV2 scale: 512 queries 536 k against 367 k queries/s on one set,
+    // 1024: 833 k against 601 k, wand 512: 265 k against 181 k)
+    b->alt_streams = (slot & 1) != 0 && nq < 2048;
+    b->pool_batches = (uint32_t)p->slots.size();
     int rc = plan_batch(b, op, k, terms, offs, nq, 0);
     if (rc) return rc; // (nothing enqueued yet)
     rc = upload_batch(b);

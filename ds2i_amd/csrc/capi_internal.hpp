@@ -122,11 +122,10 @@ struct ds2i_hip_index {
     // class kernels of consecutive batches queue up on the class streams; uploads and merges / result copies have
     // their own streams so that the next batch's H2D never waits behind the previous batch's merge
     hipStream_t stream[NCLS] = {};
-    // Consecutive batches alternate between two sets of class streams (classes 0..2; the rare classes share one), so that the
-    // class kernel of batch i+1 starts while the last, longest units of batch i's kernel of the same class are still running
-    // -- on one stream the whole GPU would wait for that tail (DS2I_STREAM_SETS=1; off by default: measured -3 %).
-    hipStream_t stream_b[3] = {};
-    int launch_parity = 0;
+    // Small batches (a rank's share of a batch sharded over several GPUs): the pipeline's odd slots launch on a second set of class
+    // streams, so that the class kernels of batch i+1 run beside those of batch i -- a 512-query batch fills a tenth of the wave slots
+    // and its two-list kernel's span (its longest unit) was the whole step. Full batches keep one set (two sets: measured -3 % at 4096).
+    hipStream_t stream_alt[NCLS] = {};
     hipStream_t s_up = nullptr, s_merge = nullptr;
     unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
     ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)
