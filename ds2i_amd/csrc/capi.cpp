@@ -793,7 +793,6 @@ static int index_open_impl(int device, int kind, const void* index_image, size_t
         int lo_pri = 0, hi_pri = 0; // numerically lower = higher priority
         HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
         for (int c = 0; c < NCLS; ++c) HIP_OK(hipStreamCreateWithPriority(&x->stream[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
-        for (int c = 0; c < NCLS; ++c) HIP_OK(hipStreamCreateWithPriority(&x->stream_alt[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
     }
     HIP_OK(hipStreamCreateWithFlags(&x->s_up, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&x->s_merge, hipStreamNonBlocking));

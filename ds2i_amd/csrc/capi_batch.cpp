@@ -1025,6 +1025,15 @@ int launch_batch(ds2i_hip_batch* b) {
         HIP_OK(hipMemsetAsync(b->d_clk.p, 0, 16 * (size_t)(b->nunits ? b->nunits : 1), idx->s_up));
         HIP_OK(hipStreamSynchronize(idx->s_up));
     }
+    if (b->alt_streams) { // (capi_internal.hpp: the second set exists from the first small batch on)
+        std::lock_guard<std::mutex> lk(idx->stream_alt_mu);
+        if (!idx->stream_alt[0]) {
+            int lo_pri = 0, hi_pri = 0;
+            HIP_OK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+            for (int c = NCLS - 1; c >= 0; --c) // (slot 0 last: it is the "set exists" mark)
+                if (!idx->stream_alt[c]) HIP_OK(hipStreamCreateWithPriority(&idx->stream_alt[c], hipStreamNonBlocking, (lo_pri + hi_pri) / 2));
+        }
+    }
     hipStream_t* const cstreams = b->alt_streams ? idx->stream_alt : idx->stream;
     auto cls_stream = [&](int c) { return cstreams[c]; };
     // every class stream first waits for the upload + cleared buffers, and for the seed pass when its floors feed the kernels. (In the

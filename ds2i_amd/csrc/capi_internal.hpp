@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ds2i_hip.h"
@@ -125,7 +126,10 @@ struct ds2i_hip_index {
     // Small batches (a rank's share of a batch sharded over several GPUs): the pipeline's odd slots launch on a second set of class
     // streams, so that the class kernels of batch i+1 run beside those of batch i -- a 512-query batch fills a tenth of the wave slots
     // and its two-list kernel's span (its longest unit) was the whole step. Full batches keep one set (two sets: measured -3 % at 4096).
+    // Created by the first small batch that wants them (every stream in use is a hardware queue; two ranks sharing one device with twelve
+    // streams each ran at half speed).
     hipStream_t stream_alt[NCLS] = {};
+    std::mutex stream_alt_mu;
     hipStream_t s_up = nullptr, s_merge = nullptr;
     unsigned int* d_ticket = nullptr; // scratch word(s) for the calibration kernel
     ds2i_hip_batch* oneshot = nullptr; // cached slot of ds2i_hip_query_batch (buffers are reused between calls)
