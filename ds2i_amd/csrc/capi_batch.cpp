@@ -532,7 +532,7 @@ static int plan_batch_impl(ds2i_hip_batch* b, int op, uint32_t k, const uint32_t
     const bool list_stream = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && !b->want_matches &&
                              idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_tails && idx->d_skip && !kn.no_list_streams && !b->no_list_streams;
     const bool and_stream = list_stream && idx->d_rmw && idx->has_bitmaps;
-    const uint32_t and_unit_blocks = 96u; // (measured: 48: 965 k, 96: 1 068 k queries/s; whole queries: 802 k)
+    const uint32_t and_unit_blocks = 96u; // (measured, `and`: 48: 965 k, 96: 1 068 k, 192: 1 190 k against 1 360 k of the same build, whole queries: 802 k; and_freq: 24 | 48 | 96 all 334-337 k)
     const bool and_rs_units = (base_op == DS2I_OP_AND || base_op == DS2I_OP_AND_FREQ) && !(op & DS2I_OP_REFERENCE_ORDER) && idx->kind == DS2I_BLOCK_OPTPFOR && idx->d_xslots && idx->d_skip &&
                               idx->d_bmw && idx->d_rmw && !kn.no_ranked_stream;
     b->sterms.clear();
