@@ -29,7 +29,11 @@ if [ $PART = opt ]; then
   bench gov2_opt_wand --workload gov2 --codec opt --op wand --steps 30 --warmup 3 --no-cpu-baseline
   DS2I_PEF_NATIVE=1 bench gov2_opt_native --workload gov2 --codec opt --steps 30 --warmup 3 --no-cpu-baseline
   DS2I_TABLE_BUDGET=3x bench gov2_opt_budget3x --workload gov2 --codec opt --steps 30 --warmup 3 --no-cpu-baseline
+  bench gov2_b256 --batch 256 --depth 8 --steps 200 --warmup 80 --no-cpu-baseline --no-oracle
   bench gov2_b512 --batch 512 --depth 8 --steps 160 --warmup 80 --no-cpu-baseline
+  bench gov2_wand_b512 --op wand --batch 512 --depth 8 --steps 100 --warmup 40 --no-cpu-baseline --no-oracle
+  bench gov2_wand_k100 --op wand --k 100 --steps 20 --warmup 3 --no-cpu-baseline --no-oracle
+  bench gov2_k100 --k 100 --steps 30 --warmup 3 --no-cpu-baseline
   bench gov2_b1024 --batch 1024 --depth 6 --steps 120 --warmup 40 --no-cpu-baseline
   bench gov2_b2048 --batch 2048 --depth 4 --steps 80 --warmup 20 --no-cpu-baseline
 fi
