@@ -407,7 +407,7 @@ int build_side_tables(ds2i_hip_index* x) {
         unsigned long long res[2] = {0, 0};
         HIP_OK(hipMemcpy(res, d_cursor, 16, hipMemcpyDeviceToHost));
         if ((unsigned int)res[1]) return give_up("block headers disagree with the decoded values (corrupt image?)");
-        if (res[0] >= 0xFFFFFFFFull) return give_up("overflow area beyond 16 GB");
+        if (res[0] >= 0x7FFFFFFFull) return give_up("overflow area beyond 8 GB"); // (a slot stores XSLOT_SLOW | (offset + 1): 31 bits of offset)
         if (res[0] <= ovf_cap) {
             x->side_bytes = slot_bytes + tail_bytes + 4 * ovf_cap;
             x->extra_bytes += x->side_bytes;
