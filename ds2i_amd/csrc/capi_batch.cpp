@@ -1355,6 +1355,7 @@ int pipeline_launch(ds2i_hip_pipeline* p, size_t slot, int op, uint32_t k, const
     ds2i_hip_batch* b = p->slots[slot];
     // (capi_internal.hpp, stream_alt; with the pool-sized units above, GOV2 scale: 512 queries 536 k against 367 k queries/s on one set,
     // 1024: 833 k against 601 k, wand 512: 265 k against 181 k)
+    // (three sets, slot % 3: 256 queries 367 k against 403 k on two, 512: 564 k / 532 k, 1024: 831 k / 821 k, wand 512: 232 k / 261 k -- two)
     b->alt_streams = (slot & 1) != 0 && nq < 2048;
     b->pool_batches = (uint32_t)p->slots.size();
     int rc = plan_batch(b, op, k, terms, offs, nq, 0);
