@@ -467,6 +467,12 @@ def main():
                            "ms_all_launches": (wa[0] + tot + ra[0]) / n_all if n_all else None, "launches_all": n_all, "launches_timed": n,
                            "algorithmic_bytes": int(ab) if ab is not None else None,
                            "achieved_gbs": (ab / (ms * 1e-3) / 1e9) if ab is not None and ms > 0 else None})
+    # (a class row names the kernels its stream actually ran -- the launch groups above -- not the class-kernel family)
+    cls_of_row = [c for c in range(NCLS) if cls_stats[c][1] and mean_ms[c]]
+    for row, c in zip(per_class, cls_of_row):
+        names = [k["kernel"] for k in per_kernel if k["class"] == c]
+        if names:
+            row["kernel"] = " + ".join(names)
     # dominant kernel = the kernel that moves the most algorithmic bytes per launch. (Launch durations are not a good
     # criterion here: the class kernels of a batch run concurrently and the small many-list classes are stretched to the
     # length of the step by the big ones.)
